@@ -1,0 +1,228 @@
+/*
+ * asurf.h -- C ABI of the MI355X-native alphaSurf hot path (libasurf_hip.so).
+ *
+ * This is the drop-in boundary of the build: plain pointers and sizes, no torch
+ * types.  Every entry point names the reference interface it replaces; paths are
+ * relative to the reference checkout (ChikaYan/alphasurf).
+ *
+ *   reference pybind module      svox2/csrc/svox2.cpp:139-291   (`svox2.csrc`)
+ *   reference structs            svox2/csrc/include/data_spec.hpp:39-201
+ *
+ * Conventions
+ *   - All `const float*` / `int32_t*` / `uint8_t*` members are DEVICE pointers
+ *     (HBM resident, contiguous, row-major) unless a comment says HOST.
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream).  Calls
+ *     are asynchronous with respect to the host, exactly like the reference
+ *     launchers (no implicit synchronisation).
+ *   - Every call returns 0 on success and a negative ASURF_E_* code on failure;
+ *     asurf_last_error() returns a thread-local human readable message.  The
+ *     Python binding turns a non-zero return into RuntimeError, mirroring the
+ *     TORCH_CHECK -> RuntimeError behaviour of the reference
+ *     (svox2/csrc/include/util.hpp:3-13, data_spec.hpp:58-81).
+ *   - Gradient buffers are ACCUMULATED into (+=), never zeroed, and mask_out is
+ *     OR-ed, as in the reference (render_util.cuh:94-154, 1794-1821).
+ *   - No entry point allocates device memory.  Scratch comes from the caller
+ *     through (workspace, workspace_bytes); query the size with
+ *     asurf_workspace_bytes().  This keeps the launchers hipGraph-capturable.
+ */
+#ifndef ASURF_H_
+#define ASURF_H_
+
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ASURF_ABI_VERSION 1
+
+/* error codes */
+#define ASURF_OK 0
+#define ASURF_E_INVALID (-1)     /* bad argument (the TORCH_CHECK class of errors) */
+#define ASURF_E_UNSUPPORTED (-2) /* feature of the reference ABI outside this build's scope */
+#define ASURF_E_WORKSPACE (-3)   /* workspace missing / too small */
+#define ASURF_E_LAUNCH (-4)      /* HIP launch error */
+
+/* enums shared with the reference (data_spec.hpp:8-36) */
+#define ASURF_BASIS_TYPE_SH 1
+#define ASURF_BASIS_TYPE_3D_TEXTURE 4
+#define ASURF_BASIS_TYPE_MLP 255
+#define ASURF_SURFACE_TYPE_NONE 100
+#define ASURF_SURFACE_TYPE_SDF 102
+#define ASURF_SURFACE_TYPE_UDF 103
+#define ASURF_CUBIC_TYPE_NO_ROOT 200
+#define ASURF_CUBIC_TYPE_LINEAR 201
+#define ASURF_CUBIC_TYPE_POLY_ONE_R 202
+#define ASURF_CUBIC_TYPE_POLY 203
+#define ASURF_CUBIC_TYPE_CUBIC_THREE_R 205
+#define ASURF_CUBIC_TYPE_CUBIC_ONE_R_ 206
+#define ASURF_SIGMOID_FN 0
+#define ASURF_EXP_FN 1
+
+/* Replaces SparseGridSpec / PackedSparseGridSpec
+ * (data_spec.hpp:39-82, data_spec_packed.cuh:11-74). */
+typedef struct asurf_grid {
+    const int32_t* links;        /* [size0,size1,size2] int32, value = row id or <0 (empty) */
+    const float* density_data;   /* [capacity, 1] raw opacity */
+    const float* surface_data;   /* [capacity, 1] SDF / UDF scalar */
+    const float* sh_data;        /* [capacity, 3*basis_dim] */
+    const float* level_set_data; /* [level_set_num] */
+    int64_t capacity;            /* rows in the data tensors (N) */
+    int32_t size[3];             /* links.shape */
+    int32_t level_set_num;
+    int32_t basis_dim;           /* 1, 4, 9 or 16 SH functions per colour channel */
+    int32_t basis_type;          /* ASURF_BASIS_TYPE_SH only */
+    int32_t surface_type;
+    float offset[3];             /* HOST values: _offset * gsz (svox2.py:6250-6253) */
+    float scaling[3];            /* HOST values: _scaling * gsz */
+    float fake_sample_std;
+    float truncated_vol_render_a;
+    int32_t background_nlayers;  /* must be 0: MSI background is outside this build's scope */
+} asurf_grid;
+
+/* Replaces RaysSpec / PackedRaysSpec (data_spec.hpp:142-154). */
+typedef struct asurf_rays {
+    const float* origins;  /* [n_rays,3] world space */
+    const float* dirs;     /* [n_rays,3] world space, pre-normalised by the caller */
+    const uint8_t* masks;  /* [n_rays] bool; carried for ABI parity, unused (surf_trav.cu:1715) */
+    int64_t n_rays;
+} asurf_rays;
+
+/* Replaces RayVoxIntersecSpec (data_spec.hpp:156-166), legacy `surface` backend only. */
+typedef struct asurf_ray_vox {
+    const int32_t* voxel_ls;    /* [n_vox,3] */
+    const int32_t* vox_start_i; /* [n_rays] */
+    const int32_t* vox_num;     /* [n_rays] */
+    int64_t n_vox;
+} asurf_ray_vox;
+
+/* Replaces RenderOptions (data_spec.hpp:168-201); same field order. */
+typedef struct asurf_render_options {
+    float background_brightness;
+    float step_size;
+    float sigma_thresh;
+    float stop_thresh;
+    float near_clip;
+    int32_t use_spheric_clip;
+    int32_t last_sample_opaque;
+    int32_t surf_fake_sample;
+    float surf_fake_sample_min_vox_len;
+    int32_t limited_fake_sample;
+    int32_t no_surf_grad_from_sh;
+    int32_t alpha_activation_type;
+    int32_t fake_sample_l_dist;
+    int32_t fake_sample_normalize_surf;
+    int32_t only_outward_intersect;
+    int32_t truncated_vol_render;
+    float trunc_vol_weight_min;
+} asurf_render_options;
+
+/* Replaces GridOutputGrads / PackedGridOutputGrads (data_spec.hpp:84-120). Any
+ * pointer may be NULL (the matching gradient is then skipped). */
+typedef struct asurf_grads {
+    float* grad_density_out;         /* [capacity,1] */
+    float* grad_sh_out;              /* [capacity,3*basis_dim] */
+    float* grad_surface_out;         /* [capacity,1] */
+    float* grad_fake_sample_std_out; /* [1] */
+    uint8_t* mask_out;               /* [capacity] bool */
+} asurf_grads;
+
+/* The 20 scalars + rgb_gt of volume_render_surf_trav_fused
+ * (svox2.cpp:38-40; surf_trav.cu:3802-3828), same order. */
+typedef struct asurf_fused_params {
+    const float* rgb_gt; /* [n_rays,3] */
+    float beta_loss;
+    float sparsity_loss;
+    float fused_surf_norm_reg_scale; /* must be 0 (reference asserts, surf_trav.cu:2872-2875) */
+    int32_t fused_surf_norm_reg_con_check;
+    int32_t fused_surf_norm_reg_ignore_empty;
+    float lambda_l2;
+    float lambda_l1;
+    float lambda_l_dist;
+    float lambda_l_entropy;
+    int32_t no_norm_weight_l_entropy;
+    float lambda_l_dist_a;
+    float lambda_l_entropy_a;
+    float lambda_l_samp_dist;
+    float lambda_l_di;
+    float l_di_alpha_thresh;
+    float surf_sparse_alpha_thresh;
+    float lambda_inplace_surf_sparse;
+    float lambda_inwards_norm_loss;
+    float lambda_conv_mode_samp;
+    int32_t l_dist_max_sample;
+    /* Multi-GPU extension (no reference counterpart): the loss normaliser 1/(3Q)
+     * and the /Q lambdas (surf_trav.cu:3308-3309, 3896-3908) use this GLOBAL ray
+     * count when > 0, else rays.n_rays. */
+    int64_t global_n_rays;
+} asurf_fused_params;
+
+/* Per-call counters (optional; pass NULL to skip).  Device buffer of
+ * ASURF_N_COUNTERS uint64, accumulated with atomics by the kernels when non-NULL:
+ * used by bench.py to price the algorithmic bytes of SURVEY.md section 8(d). */
+#define ASURF_N_COUNTERS 4
+#define ASURF_CNT_TRAVERSED 0 /* V_t: voxels visited by the DDA */
+#define ASURF_CNT_ACTIVE 1    /* V_a: voxels with 8 live links that pass the density gate */
+#define ASURF_CNT_SAMPLES 2   /* S: samples composited (real + fake) */
+#define ASURF_CNT_RAYS 3
+
+int asurf_abi_version(void);
+const char* asurf_last_error(void);
+
+/* Scratch bytes needed by any of the surf_trav / surface entry points below for
+ * this grid size / ray count / sample-cache depth. */
+size_t asurf_workspace_bytes(const int32_t size[3], int64_t n_rays, int32_t l_dist_max_sample);
+
+/* Tensor volume_render_surf_trav(SparseGridSpec&, RaysSpec&, RenderOptions&)
+ *   svox2.cpp:33, surf_trav.cu:3596-3654.  rgb_out: [n_rays,3] (written). */
+int asurf_volume_render_surf_trav(const asurf_grid* grid, const asurf_rays* rays,
+                                  const asurf_render_options* opt, float* rgb_out,
+                                  void* workspace, size_t workspace_bytes,
+                                  uint64_t* counters, void* stream);
+
+/* void volume_render_surf_trav_backward(grid, rays, opt, grad_out, color_cache, grads)
+ *   svox2.cpp:36-37, surf_trav.cu:3708-3800. */
+int asurf_volume_render_surf_trav_backward(const asurf_grid* grid, const asurf_rays* rays,
+                                           const asurf_render_options* opt,
+                                           const float* grad_out, const float* color_cache,
+                                           const asurf_grads* grads, void* workspace,
+                                           size_t workspace_bytes, uint64_t* counters,
+                                           void* stream);
+
+/* void volume_render_surf_trav_fused(grid, rays, opt, rgb_gt, 20 scalars, rgb_out, grads)
+ *   svox2.cpp:38-40, surf_trav.cu:3802-3942. */
+int asurf_volume_render_surf_trav_fused(const asurf_grid* grid, const asurf_rays* rays,
+                                        const asurf_render_options* opt,
+                                        const asurf_fused_params* fused, float* rgb_out,
+                                        const asurf_grads* grads, void* workspace,
+                                        size_t workspace_bytes, uint64_t* counters,
+                                        void* stream);
+
+/* Legacy `surface` backend (precomputed per-ray voxel lists):
+ *   volume_render_surface / _backward / _fused, svox2.cpp:25-31,
+ *   render_lerp_kernel_surface.cu:1198-1439. */
+int asurf_volume_render_surface(const asurf_grid* grid, const asurf_rays* rays,
+                                const asurf_ray_vox* ray_vox, const asurf_render_options* opt,
+                                float* rgb_out, void* stream);
+int asurf_volume_render_surface_backward(const asurf_grid* grid, const asurf_rays* rays,
+                                         const asurf_ray_vox* ray_vox,
+                                         const asurf_render_options* opt, const float* grad_out,
+                                         const float* color_cache, const asurf_grads* grads,
+                                         void* stream);
+int asurf_volume_render_surface_fused(const asurf_grid* grid, const asurf_rays* rays,
+                                      const asurf_ray_vox* ray_vox,
+                                      const asurf_render_options* opt, const float* rgb_gt,
+                                      float beta_loss, float sparsity_loss, float* rgb_out,
+                                      const asurf_grads* grads, void* stream);
+
+/* Tensor test_cubic_root_grad(fs f64[N,4], st_ids i32[N], grad_fs f32[N,4] in/out,
+ *                             st f32[N,3] out, bool use_vieta)
+ *   svox2.cpp:12, test_cuda.cu:32-122.  All pointers are device pointers. */
+int asurf_test_cubic_root_grad(const double* fs, const int32_t* st_ids, float* grad_fs,
+                               float* st, int64_t n, int32_t use_vieta, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ASURF_H_ */

@@ -1,0 +1,66 @@
+"""Helpers shared by the golden-vector tests (CPU oracle and HIP path)."""
+import json
+import os
+
+import numpy as np
+
+GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+STORED_CASES = [
+    "r16_sh9_l1", "r16_sh9_l1_noconv", "r16_sh1_sigmoid", "r16_sh4_lv3", "r16_sh16",
+    "r16_sh9_l2", "r16_sh9_entropy", "r16_sh9_allfake", "r16_sh9_sparsity", "r32_sh4_l2",
+]
+ALL_CASES = STORED_CASES + ["cfg1_r64_sh1"]
+
+
+def load_case(name):
+    """Returns (arrays dict, meta dict).  For cases stored without inputs the scene is
+    regenerated from the recorded recipe and checked against the recorded checksums."""
+    z = dict(np.load(os.path.join(GOLDEN_DIR, name + ".npz")))
+    meta = json.loads(bytes(z.pop("meta")).decode())
+    if "links" not in z:
+        from alphasurf_amd import gridinit
+        import hashlib
+
+        def sha(a):
+            return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()[:16]
+
+        reso, B = meta["reso"], meta["basis_dim"]
+        links = gridinit.init_links([reso] * 3, use_z_order=meta["z_order"])
+        surface_init = z["surface_init"]
+        # our own constructor must reproduce the reference's SDF initialisation
+        np.testing.assert_allclose(gridinit.sphere_surface_init(links), surface_init, atol=2e-5)
+        rs = np.random.RandomState(meta["seed"])
+        n = int(links.max()) + 1
+        sh = rs.normal(0.0, 0.1, size=(n, 3 * B)).astype(np.float32)
+        sh[:, 0] = 0.5
+        density = rs.normal(0.5, 0.1, size=(n, 1)).astype(np.float32)
+        surface = (surface_init + (rs.rand(n, 1).astype(np.float32) - 0.5)).astype(np.float32)
+        got = dict(links=sha(links), surface_init=sha(surface_init), sh=sha(sh),
+                   density=sha(density), surface=sha(surface))
+        assert got == meta["sha"], f"regenerated inputs of {name} differ from the reference's: {got} vs {meta['sha']}"
+        z.update(links=links, sh=sh, density=density, surface=surface, surface_init=surface_init)
+    return z, meta
+
+
+def fused_args(z, meta):
+    """(rgb_gt, fused-params dict) reproducing the loss the golden gradients belong to."""
+    q = z["origins"].shape[0]
+    if meta["loss"] == "ref_l1":          # svox2.py:2817-2828: rgb_gt = 0, L1 only
+        gt = np.zeros((q, 3), np.float32)
+        fused = dict(lambda_l1=1.0, lambda_l2=0.0)
+    else:
+        gt = z["rgb_gt"]
+        fused = dict(lambda_l1=0.0, lambda_l2=1.0)
+    fused.update(lambda_conv_mode_samp=meta["conv_mode"], lambda_l_entropy=meta["l_entropy"],
+                 no_norm_weight_l_entropy=1, sparsity_loss=meta["sparsity"])
+    return gt, fused
+
+
+def grad_close(got, ref, rtol, what):
+    """|got-ref| <= rtol * max|ref| elementwise (gradients are sums over rays, so the
+    natural scale is the largest entry)."""
+    scale = max(float(np.abs(ref).max()), 1e-12)
+    err = float(np.abs(got.reshape(ref.shape) - ref).max())
+    assert err <= rtol * scale, f"{what}: max err {err:.3e} vs scale {scale:.3e} (rel {err / scale:.2e})"
+    return err / scale
