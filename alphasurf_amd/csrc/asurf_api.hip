@@ -1,0 +1,379 @@
+// asurf_api.hip -- C-ABI entry points of libasurf_hip.so (include/asurf.h).
+//
+// Host launchers that replace the reference's volume_render_surf_trav{,_backward,_fused}
+// (svox2/csrc/render_lerp_kernel_surf_trav.cu:3596-3942).  Validation mirrors the
+// reference's TORCH_CHECK/CHECK_INPUT set as far as raw pointers allow; failures return a
+// negative code + message instead of throwing.
+#include "asurf.h"
+
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+
+#include "asurf_kernels.h"
+
+namespace {
+
+thread_local char g_err[512] = "";
+
+int fail(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+using namespace asurf;
+
+struct MaskLayout {
+    int nb[3];
+    int nwz;
+    size_t n_bricks;
+    size_t coarse_words;
+    size_t off_fine_work, off_fine_live, off_coarse_work, off_coarse_live;
+    size_t off_cache_a, off_cache_w, off_cache_t, off_cache_n;
+    size_t total;
+};
+
+size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+MaskLayout layout_for(const int32_t size[3], int64_t n_rays, int32_t M) {
+    MaskLayout L;
+    for (int i = 0; i < 3; ++i) L.nb[i] = (size[i] + 7) / 8;
+    L.nwz = (L.nb[2] + 31) / 32;
+    L.n_bricks = (size_t)L.nb[0] * L.nb[1] * L.nb[2];
+    L.coarse_words = (size_t)L.nb[0] * L.nb[1] * L.nwz;
+    size_t off = 0;
+    L.off_fine_work = off;
+    off = align_up(off + L.n_bricks * 64, 256);
+    L.off_fine_live = off;
+    off = align_up(off + L.n_bricks * 64, 256);
+    L.off_coarse_work = off;
+    off = align_up(off + L.coarse_words * 4, 256);
+    L.off_coarse_live = off;
+    off = align_up(off + L.coarse_words * 4, 256);
+    const size_t plane = (size_t)(M > 0 ? M : 0) * (size_t)(n_rays > 0 ? n_rays : 0) * 4;
+    L.off_cache_a = off;
+    off = align_up(off + plane, 256);
+    L.off_cache_w = off;
+    off = align_up(off + plane, 256);
+    L.off_cache_t = off;
+    off = align_up(off + plane, 256);
+    L.off_cache_n = off;
+    off = align_up(off + (size_t)(n_rays > 0 ? n_rays : 0) * 4, 256);
+    L.total = off;
+    return L;
+}
+
+int check_grid(const asurf_grid* g) {
+    if (!g) return fail(ASURF_E_INVALID, "grid is NULL");
+    if (!g->links || !g->density_data || !g->sh_data)
+        return fail(ASURF_E_INVALID, "links, density_data and sh_data must be device tensors");
+    if (g->surface_type == ASURF_SURFACE_TYPE_NONE || !g->surface_data)
+        return fail(ASURF_E_INVALID, "surf_trav needs surface_data (surface_type != NONE)");
+    if (g->level_set_num < 0 || (g->level_set_num > 0 && !g->level_set_data))
+        return fail(ASURF_E_INVALID, "level_set_data missing");
+    if (g->basis_type != ASURF_BASIS_TYPE_SH)
+        return fail(ASURF_E_UNSUPPORTED, "basis_type %d: only BASIS_TYPE_SH is built (SURVEY.md 8f)",
+                    g->basis_type);
+    if (!(g->basis_dim == 1 || g->basis_dim == 4 || g->basis_dim == 9 || g->basis_dim == 16))
+        return fail(ASURF_E_INVALID, "basis_dim must be 1, 4, 9 or 16 (got %d)", g->basis_dim);
+    if (g->background_nlayers != 0)
+        return fail(ASURF_E_UNSUPPORTED, "MSI background layers are outside this build's scope");
+    for (int i = 0; i < 3; ++i)
+        if (g->size[i] < 2) return fail(ASURF_E_INVALID, "links.shape[%d] = %d < 2", i, g->size[i]);
+    if ((int64_t)g->size[0] * g->size[1] * g->size[2] >= (1ll << 31))
+        return fail(ASURF_E_INVALID, "links has >= 2^31 elements");
+    if (g->capacity <= 0) return fail(ASURF_E_INVALID, "capacity must be > 0");
+    return 0;
+}
+
+int check_rays(const asurf_rays* r) {
+    if (!r) return fail(ASURF_E_INVALID, "rays is NULL");
+    if (r->n_rays < 0) return fail(ASURF_E_INVALID, "n_rays < 0");
+    if (r->n_rays > 0 && (!r->origins || !r->dirs))
+        return fail(ASURF_E_INVALID, "rays.origins / rays.dirs must be device tensors");
+    if (r->n_rays * 3 >= (1ll << 31)) return fail(ASURF_E_INVALID, "too many rays for 32-bit indexing");
+    return 0;
+}
+
+KGrid make_kgrid(const asurf_grid* g, const MaskLayout& ML, char* ws, bool use_live_plane) {
+    KGrid k;
+    k.links = g->links;
+    k.density = g->density_data;
+    k.surface = g->surface_data;
+    k.sh = g->sh_data;
+    k.level_set = g->level_set_data;
+    for (int i = 0; i < 3; ++i) {
+        k.size[i] = g->size[i];
+        k.offset[i] = g->offset[i];
+        k.scaling[i] = g->scaling[i];
+        k.nb[i] = ML.nb[i];
+    }
+    k.offx = g->size[1] * g->size[2];
+    k.offy = g->size[2];
+    k.level_set_num = g->level_set_num;
+    k.fake_sample_std = g->fake_sample_std;
+    k.trunc_a = g->truncated_vol_render_a;
+    auto* fw = reinterpret_cast<unsigned long long*>(ws + ML.off_fine_work);
+    auto* fl = reinterpret_cast<unsigned long long*>(ws + ML.off_fine_live);
+    auto* cw = reinterpret_cast<unsigned int*>(ws + ML.off_coarse_work);
+    auto* cl = reinterpret_cast<unsigned int*>(ws + ML.off_coarse_live);
+    k.fine = use_live_plane ? fl : fw;
+    k.fine_live = fl;
+    k.coarse = use_live_plane ? cl : cw;
+    k.nwz = ML.nwz;
+    k.coarse_words = (int)ML.coarse_words;
+    return k;
+}
+
+KOpt make_kopt(const asurf_render_options* o) {
+    KOpt k;
+    k.background_brightness = o->background_brightness;
+    k.step_size = o->step_size;
+    k.sigma_thresh = o->sigma_thresh;
+    k.stop_thresh = o->stop_thresh;
+    k.near_clip = o->near_clip;
+    k.use_spheric_clip = o->use_spheric_clip;
+    k.surf_fake_sample = o->surf_fake_sample;
+    k.surf_fake_sample_min_vox_len = o->surf_fake_sample_min_vox_len;
+    k.limited_fake_sample = o->limited_fake_sample;
+    k.no_surf_grad_from_sh = o->no_surf_grad_from_sh;
+    k.alpha_activation_type = o->alpha_activation_type;
+    k.fake_sample_l_dist = o->fake_sample_l_dist;
+    k.fake_sample_normalize_surf = o->fake_sample_normalize_surf;
+    k.only_outward_intersect = o->only_outward_intersect;
+    k.truncated_vol_render = o->truncated_vol_render;
+    k.trunc_vol_weight_min = o->trunc_vol_weight_min;
+    return k;
+}
+
+constexpr size_t kMaxCoarseLds = 32 * 1024;
+
+struct Launch {
+    KGrid g;
+    KOpt o;
+    MaskLayout ML;
+    char* ws;
+    hipStream_t stream;
+    int coarse_in_lds;
+    size_t dyn_lds;
+    dim3 ray_grid;
+};
+
+int launch_error(const char* what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(ASURF_E_LAUNCH, "%s: %s", what, hipGetErrorString(e));
+    return 0;
+}
+
+// Common prologue: validation, workspace carve-up and the occupancy-pyramid pass.
+int prepare(const asurf_grid* grid, const asurf_rays* rays, const asurf_render_options* opt,
+            int32_t M, void* workspace, size_t workspace_bytes, void* stream, Launch& L) {
+    if (int e = check_grid(grid)) return e;
+    if (int e = check_rays(rays)) return e;
+    if (!opt) return fail(ASURF_E_INVALID, "render options are NULL");
+    if (opt->alpha_activation_type != ASURF_SIGMOID_FN && opt->alpha_activation_type != ASURF_EXP_FN)
+        return fail(ASURF_E_INVALID, "alpha_activation_type must be 0 (sigmoid) or 1 (exp)");
+    L.ML = layout_for(grid->size, rays->n_rays, M);
+    if (!workspace || workspace_bytes < L.ML.total)
+        return fail(ASURF_E_WORKSPACE, "workspace of %zu bytes needed, got %zu", L.ML.total,
+                    workspace ? workspace_bytes : (size_t)0);
+    L.ws = static_cast<char*>(workspace);
+    L.stream = static_cast<hipStream_t>(stream);
+    // A voxel that holds no level set contributes nothing unless unrestricted fake sampling
+    // is on (surf_trav.cu:423); and with stop_thresh > 1 the reference stops at the first
+    // voxel that passes the link/density gates (:544), so the walk must test that plane.
+    const bool need_surf = !(opt->surf_fake_sample && !opt->limited_fake_sample);
+    const bool use_live = !need_surf || (opt->stop_thresh > 1.f);
+    L.g = make_kgrid(grid, L.ML, L.ws, use_live);
+    L.o = make_kopt(opt);
+    L.coarse_in_lds = (L.ML.coarse_words * 4 <= kMaxCoarseLds) ? 1 : 0;
+    L.dyn_lds = L.coarse_in_lds ? L.ML.coarse_words * 4 : 0;
+    L.ray_grid = dim3((unsigned)((rays->n_rays + kBlock - 1) / kBlock));
+    hipLaunchKernelGGL(k_build_masks, dim3((unsigned)L.ML.coarse_words), dim3(512), 0, L.stream, L.g,
+                       opt->sigma_thresh, need_surf ? 1 : 0,
+                       reinterpret_cast<unsigned long long*>(L.ws + L.ML.off_fine_work),
+                       reinterpret_cast<unsigned long long*>(L.ws + L.ML.off_fine_live),
+                       reinterpret_cast<unsigned int*>(L.ws + L.ML.off_coarse_work),
+                       reinterpret_cast<unsigned int*>(L.ws + L.ML.off_coarse_live));
+    return launch_error("k_build_masks");
+}
+
+template <int B>
+int run_forward(const Launch& L, const asurf_rays* rays, float* rgb_out, int M, bool cache,
+                uint64_t* counters) {
+    float* ca = reinterpret_cast<float*>(L.ws + L.ML.off_cache_a);
+    float* cw = reinterpret_cast<float*>(L.ws + L.ML.off_cache_w);
+    float* ct = reinterpret_cast<float*>(L.ws + L.ML.off_cache_t);
+    int* cn = reinterpret_cast<int*>(L.ws + L.ML.off_cache_n);
+    auto* cnt = reinterpret_cast<unsigned long long*>(counters);
+#define ASURF_FWD(CACHE, COUNT)                                                                  \
+    hipLaunchKernelGGL((k_forward<B, CACHE, COUNT>), L.ray_grid, dim3(kBlock), L.dyn_lds, L.stream, \
+                       L.g, L.o, rays->origins, rays->dirs, (long long)rays->n_rays, rgb_out, M, \
+                       ca, cw, ct, cn, L.coarse_in_lds, cnt)
+    if (cache) {
+        if (counters) ASURF_FWD(true, true);
+        else ASURF_FWD(true, false);
+    } else {
+        if (counters) ASURF_FWD(false, true);
+        else ASURF_FWD(false, false);
+    }
+#undef ASURF_FWD
+    return launch_error("k_forward");
+}
+
+template <int B>
+int run_backward(const Launch& L, const asurf_rays* rays, const KLoss& loss, const KGrads& G,
+                 const float* grad_in, const float* color_cache, int M, bool fused) {
+    const float* ca = reinterpret_cast<const float*>(L.ws + L.ML.off_cache_a);
+    const float* cw = reinterpret_cast<const float*>(L.ws + L.ML.off_cache_w);
+    const float* ct = reinterpret_cast<const float*>(L.ws + L.ML.off_cache_t);
+    const int* cn = reinterpret_cast<const int*>(L.ws + L.ML.off_cache_n);
+    if (fused)
+        hipLaunchKernelGGL((k_backward<B, true>), L.ray_grid, dim3(kBlock), L.dyn_lds, L.stream, L.g,
+                           L.o, loss, G, rays->origins, rays->dirs, (long long)rays->n_rays, grad_in,
+                           color_cache, M, ca, cw, ct, cn, L.coarse_in_lds);
+    else
+        hipLaunchKernelGGL((k_backward<B, false>), L.ray_grid, dim3(kBlock), L.dyn_lds, L.stream, L.g,
+                           L.o, loss, G, rays->origins, rays->dirs, (long long)rays->n_rays, grad_in,
+                           color_cache, M, ca, cw, ct, cn, L.coarse_in_lds);
+    return launch_error("k_backward");
+}
+
+#define ASURF_DISPATCH_B(basis_dim, CALL)               \
+    switch (basis_dim) {                                \
+        case 1: { constexpr int B_ = 1; rc = CALL; } break;   \
+        case 4: { constexpr int B_ = 4; rc = CALL; } break;   \
+        case 9: { constexpr int B_ = 9; rc = CALL; } break;   \
+        default: { constexpr int B_ = 16; rc = CALL; } break; \
+    }
+
+KGrads make_grads(const asurf_grads* g) {
+    KGrads k;
+    k.grad_density = g->grad_density_out;
+    k.grad_sh = g->grad_sh_out;
+    k.grad_surface = g->grad_surface_out;
+    k.grad_fake_sample_std = g->grad_fake_sample_std_out;
+    k.mask = g->mask_out;
+    return k;
+}
+
+}  // namespace
+
+extern "C" {
+
+int asurf_abi_version(void) { return ASURF_ABI_VERSION; }
+const char* asurf_last_error(void) { return g_err; }
+
+size_t asurf_workspace_bytes(const int32_t size[3], int64_t n_rays, int32_t l_dist_max_sample) {
+    if (!size) return 0;
+    return layout_for(size, n_rays, l_dist_max_sample).total;
+}
+
+int asurf_volume_render_surf_trav(const asurf_grid* grid, const asurf_rays* rays,
+                                  const asurf_render_options* opt, float* rgb_out, void* workspace,
+                                  size_t workspace_bytes, uint64_t* counters, void* stream) {
+    Launch L;
+    if (int e = prepare(grid, rays, opt, 0, workspace, workspace_bytes, stream, L)) return e;
+    if (rays->n_rays == 0) return 0;
+    if (!rgb_out) return fail(ASURF_E_INVALID, "rgb_out is NULL");
+    int rc = 0;
+    ASURF_DISPATCH_B(grid->basis_dim, run_forward<B_>(L, rays, rgb_out, 0, false, counters));
+    return rc;
+}
+
+int asurf_volume_render_surf_trav_backward(const asurf_grid* grid, const asurf_rays* rays,
+                                           const asurf_render_options* opt, const float* grad_out,
+                                           const float* color_cache, const asurf_grads* grads,
+                                           void* workspace, size_t workspace_bytes,
+                                           uint64_t* counters, void* stream) {
+    (void)counters;
+    Launch L;
+    if (int e = prepare(grid, rays, opt, 0, workspace, workspace_bytes, stream, L)) return e;
+    if (!grads) return fail(ASURF_E_INVALID, "grads is NULL");
+    if (rays->n_rays == 0) return 0;
+    if (!grad_out || !color_cache) return fail(ASURF_E_INVALID, "grad_out / color_cache is NULL");
+    KLoss loss;
+    memset(&loss, 0, sizeof(loss));  // all fused-loss lambdas are 0 here (surf_trav.cu:3752-3773)
+    const KGrads G = make_grads(grads);
+    int rc = 0;
+    ASURF_DISPATCH_B(grid->basis_dim, run_backward<B_>(L, rays, loss, G, grad_out, color_cache, 0, false));
+    return rc;
+}
+
+int asurf_volume_render_surf_trav_fused(const asurf_grid* grid, const asurf_rays* rays,
+                                        const asurf_render_options* opt,
+                                        const asurf_fused_params* fused, float* rgb_out,
+                                        const asurf_grads* grads, void* workspace,
+                                        size_t workspace_bytes, uint64_t* counters, void* stream) {
+    if (!fused) return fail(ASURF_E_INVALID, "fused params are NULL");
+    if (fused->fused_surf_norm_reg_scale > 0.f)
+        return fail(ASURF_E_UNSUPPORTED,
+                    "fused_surf_norm_reg_scale > 0 is no longer supported by the reference either "
+                    "(assert(false) at surf_trav.cu:2875)");
+    const int M = fused->l_dist_max_sample;
+    if (M < 0) return fail(ASURF_E_INVALID, "l_dist_max_sample < 0");
+    Launch L;
+    if (int e = prepare(grid, rays, opt, M, workspace, workspace_bytes, stream, L)) return e;
+    if (!grads) return fail(ASURF_E_INVALID, "grads is NULL");
+    if (rays->n_rays == 0) return 0;
+    if (!fused->rgb_gt || !rgb_out) return fail(ASURF_E_INVALID, "rgb_gt / rgb_out is NULL");
+    const long long Qn = fused->global_n_rays > 0 ? fused->global_n_rays : rays->n_rays;
+    KLoss loss;  // launcher-side scaling, surf_trav.cu:3896-3915
+    loss.sparsity_loss = fused->sparsity_loss;
+    loss.lambda_l2 = fused->lambda_l2;
+    loss.lambda_l1 = fused->lambda_l1;
+    loss.lambda_l_dist = fused->lambda_l_dist / Qn;
+    loss.lambda_l_entropy = fused->lambda_l_entropy / Qn;
+    loss.no_norm_weight_l_entropy = fused->no_norm_weight_l_entropy;
+    loss.lambda_l_dist_a = fused->lambda_l_dist_a / Qn;
+    loss.lambda_l_entropy_a = fused->lambda_l_entropy_a / Qn;
+    loss.lambda_l_samp_dist = fused->lambda_l_samp_dist / Qn;
+    loss.lambda_l_di = fused->lambda_l_di;
+    loss.l_di_alpha_thresh = fused->l_di_alpha_thresh;
+    loss.surf_sparse_alpha_thresh = fused->surf_sparse_alpha_thresh;
+    loss.lambda_inplace_surf_sparse = fused->lambda_inplace_surf_sparse;
+    loss.lambda_inwards_norm_loss = fused->lambda_inwards_norm_loss;
+    loss.lambda_conv_mode_samp = fused->lambda_conv_mode_samp;
+    loss.norm_l2 = 2.f / (3 * (int)Qn);  // surf_trav.cu:3308-3309
+    loss.norm_l1 = 1.f / (3 * (int)Qn);
+    const KGrads G = make_grads(grads);
+    int rc = 0;
+    ASURF_DISPATCH_B(grid->basis_dim, run_forward<B_>(L, rays, rgb_out, M, true, counters));
+    if (rc) return rc;
+    ASURF_DISPATCH_B(grid->basis_dim, run_backward<B_>(L, rays, loss, G, fused->rgb_gt, rgb_out, M, true));
+    return rc;
+}
+
+int asurf_test_cubic_root_grad(const double* fs, const int32_t* st_ids, float* grad_fs, float* st,
+                               int64_t n, int32_t use_vieta, void* stream) {
+    if (!use_vieta)
+        return fail(ASURF_E_UNSUPPORTED, "only the Vieta solver (use_vieta=True) is on the live path");
+    if (n < 0 || (n > 0 && (!fs || !st_ids || !grad_fs || !st)))
+        return fail(ASURF_E_INVALID, "test_cubic_root_grad: NULL tensor");
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(k_test_cubic_root_grad, dim3((unsigned)((n + 127) / 128)), dim3(128), 0,
+                       static_cast<hipStream_t>(stream), fs, st_ids, grad_fs, st, (long long)n);
+    return launch_error("k_test_cubic_root_grad");
+}
+
+int asurf_volume_render_surface(const asurf_grid*, const asurf_rays*, const asurf_ray_vox*,
+                                const asurf_render_options*, float*, void*) {
+    return fail(ASURF_E_UNSUPPORTED, "legacy `surface` backend: not built yet (SURVEY.md 8a-14)");
+}
+int asurf_volume_render_surface_backward(const asurf_grid*, const asurf_rays*, const asurf_ray_vox*,
+                                         const asurf_render_options*, const float*, const float*,
+                                         const asurf_grads*, void*) {
+    return fail(ASURF_E_UNSUPPORTED, "legacy `surface` backend: not built yet (SURVEY.md 8a-14)");
+}
+int asurf_volume_render_surface_fused(const asurf_grid*, const asurf_rays*, const asurf_ray_vox*,
+                                      const asurf_render_options*, const float*, float, float, float*,
+                                      const asurf_grads*, void*) {
+    return fail(ASURF_E_UNSUPPORTED, "legacy `surface` backend: not built yet (SURVEY.md 8a-14)");
+}
+
+}  // extern "C"

@@ -1,0 +1,1058 @@
+// asurf_kernels.h -- HIP kernels of the surf_trav hot path for gfx950 (wave64).
+//
+// Design (DESIGN.md has the long form):
+//   * k_build_masks  -- per call, streams the dense `links` volume once and emits an
+//     occupancy pyramid: one bit per voxel ("this voxel can produce a sample") packed
+//     as 8 x uint64 per 8^3 brick (64 B = one cache line per brick) + one bit per brick.
+//     This replaces the reference's 8 dependent link loads per traversed voxel
+//     (surf_trav.cu:212-239) by register-cached bit tests; the DDA itself is unchanged.
+//   * k_forward / k_backward -- ONE RAY PER LANE.  Each wave runs a while-while loop:
+//     (A) every lane advances its own DDA until it reaches a work voxel, (B) lanes that
+//     found one form the cubic and solve it (f64, thread-per-ray, dense), (C) lanes with
+//     a valid sample are served one after another by the whole wave: the 8 x D spherical
+//     harmonic coefficients are read (and, backward, atomically accumulated) with the
+//     lanes spread over (corner, coefficient), i.e. contiguous 4*D-byte row segments.
+//     The reference instead runs the whole traversal redundantly on 3*basis_dim lanes of
+//     a 32-wide warp (surf_trav.cu:3139-3157).
+#pragma once
+#include "asurf_device.h"
+
+namespace asurf {
+
+// ------------------------------------------------------------------------------------
+// Occupancy pyramid
+// ------------------------------------------------------------------------------------
+// grid: nb[0]*nb[1]*nwz blocks of 512 threads; block = one (bx,by) brick column segment of
+// up to 32 bricks along z; thread = one voxel of the current brick.
+__global__ void __launch_bounds__(512)
+k_build_masks(KGrid g, float sigma_thresh, int need_surf, unsigned long long* fine_work,
+              unsigned long long* fine_live, unsigned int* coarse_work,
+              unsigned int* coarse_live) {
+    const int t = threadIdx.x;
+    const int lx = t >> 6, ly = (t >> 3) & 7, lz = t & 7;
+    const int wz = blockIdx.x % g.nwz;
+    const int bxy = blockIdx.x / g.nwz;
+    const int by = bxy % g.nb[1];
+    const int bx = bxy / g.nb[1];
+    __shared__ unsigned s_work[8], s_live[8];
+    unsigned word_work = 0, word_live = 0;
+    for (int bi = 0; bi < 32; ++bi) {
+        const int bz = wz * 32 + bi;
+        if (bz >= g.nb[2]) break;
+        const int x = bx * 8 + lx, y = by * 8 + ly, z = bz * 8 + lz;
+        bool live = false, work = false;
+        if (x + 1 < g.size[0] && y + 1 < g.size[1] && z + 1 < g.size[2]) {
+            const int32_t* p = g.links + ((size_t)x * g.offx + (size_t)y * g.offy + z);
+            const int32_t l0 = p[0], l1 = p[1], l2 = p[g.offy], l3 = p[g.offy + 1];
+            const int32_t l4 = p[g.offx], l5 = p[g.offx + 1], l6 = p[g.offx + g.offy],
+                          l7 = p[g.offx + g.offy + 1];
+            if ((l0 | l1 | l2 | l3 | l4 | l5 | l6 | l7) >= 0) {
+                const int32_t lk[8] = {l0, l1, l2, l3, l4, l5, l6, l7};
+                bool all_below = true;  // surf_trav.cu:230-239
+#pragma unroll
+                for (int i = 0; i < 8; ++i) all_below = all_below && (g.density[lk[i]] < sigma_thresh);
+                if (!all_below) {
+                    live = true;
+                    work = true;
+                    if (need_surf) {  // surf_trav.cu:265-277: some level set within [min,max]
+                        float smin = g.surface[lk[0]], smax = smin;
+#pragma unroll
+                        for (int i = 1; i < 8; ++i) {
+                            const float s = g.surface[lk[i]];
+                            smin = fminf(smin, s);
+                            smax = fmaxf(smax, s);
+                        }
+                        work = false;
+                        for (int li = 0; li < g.level_set_num; ++li) {
+                            const float lv = g.level_set[li];
+                            if (!(lv < smin || lv > smax)) work = true;
+                        }
+                    }
+                }
+            }
+        }
+        const unsigned long long bw = __ballot(work), bl = __ballot(live);
+        if ((t & 63) == 0) {
+            const size_t brick = ((size_t)bx * g.nb[1] + by) * g.nb[2] + bz;
+            fine_work[brick * 8 + lx] = bw;
+            fine_live[brick * 8 + lx] = bl;
+            s_work[lx] = bw != 0;
+            s_live[lx] = bl != 0;
+        }
+        __syncthreads();
+        if (t == 0) {
+            unsigned aw = 0, al = 0;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                aw |= s_work[i];
+                al |= s_live[i];
+            }
+            word_work |= aw << bi;
+            word_live |= al << bi;
+        }
+        __syncthreads();
+    }
+    if (t == 0) {
+        coarse_work[blockIdx.x] = word_work;
+        coarse_live[blockIdx.x] = word_live;
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// Per-lane voxel walk (the DDA of surf_trav.cu:67-79, 86-197)
+// ------------------------------------------------------------------------------------
+struct Walk {
+    int nx, ny, nz;  // next voxel
+    int vx, vy, vz;  // current voxel
+    float t, t_far;
+    // register cache of the occupancy pyramid
+    int cur_brick;
+    unsigned cur_flag;
+    int cur_lx;
+    unsigned long long cur_word;
+};
+
+__device__ __forceinline__ void walk_init(const KGrid& g, const Ray& r, Walk& w) {
+    w.t = r.tmin;
+    int v[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        v[j] = (int)fmaf(w.t, r.d[j], r.o[j]);
+        v[j] = min(max(v[j], 0), g.size[j] - 2);
+    }
+    w.nx = v[0];
+    w.ny = v[1];
+    w.nz = v[2];
+    w.vx = w.vy = w.vz = 0;
+    w.t_far = 0.f;
+    w.cur_brick = -1;
+    w.cur_flag = 0;
+    w.cur_lx = -1;
+    w.cur_word = 0;
+}
+
+// one DDA step: enters (nx,ny,nz), computes its far crossing, picks the next voxel
+__device__ __forceinline__ void walk_step(const KGrid& g, const Ray& r, Walk& w) {
+    w.vx = w.nx;
+    w.vy = w.ny;
+    w.vz = w.nz;
+    const float tf0 = ((float)(r.d[0] > 0.f ? w.vx + 1 : w.vx) - r.o[0]) / r.d[0];
+    const float tf1 = ((float)(r.d[1] > 0.f ? w.vy + 1 : w.vy) - r.o[1]) / r.d[1];
+    const float tf2 = ((float)(r.d[2] > 0.f ? w.vz + 1 : w.vz) - r.o[2]) / r.d[2];
+    const float t_far = fminf(fminf(tf0, tf1), tf2);
+    w.t_far = t_far;
+    w.t = t_far;
+    if (t_far == tf0) {
+        w.nx += (r.d[0] > 0.f) ? 1 : -1;
+        if (w.nx < 0 || w.nx >= g.size[0] - 1) w.t = r.tmax + 1.f;
+    } else if (t_far == tf1) {
+        w.ny += (r.d[1] > 0.f) ? 1 : -1;
+        if (w.ny < 0 || w.ny >= g.size[1] - 1) w.t = r.tmax + 1.f;
+    } else {
+        w.nz += (r.d[2] > 0.f) ? 1 : -1;
+        if (w.nz < 0 || w.nz >= g.size[2] - 1) w.t = r.tmax + 1.f;
+    }
+}
+
+__device__ __forceinline__ float walk_t_close(const Ray& r, const Walk& w) {
+    const float tc0 = ((float)(r.d[0] > 0.f ? w.vx : w.vx + 1) - r.o[0]) / r.d[0];
+    const float tc1 = ((float)(r.d[1] > 0.f ? w.vy : w.vy + 1) - r.o[1]) / r.d[1];
+    const float tc2 = ((float)(r.d[2] > 0.f ? w.vz : w.vz + 1) - r.o[2]) / r.d[2];
+    return fmaxf(fmaxf(fmaxf(tc0, tc1), tc2), 0.f);
+}
+
+// work bit of the current voxel; brick flag and the 64-voxel slab word are kept in registers
+__device__ __forceinline__ bool walk_test(const KGrid& g, const unsigned int* coarse, Walk& w) {
+    const int bx = w.vx >> 3, by = w.vy >> 3, bz = w.vz >> 3;
+    const int bxy = bx * g.nb[1] + by;
+    const int brick = bxy * g.nb[2] + bz;
+    if (brick != w.cur_brick) {
+        w.cur_brick = brick;
+        w.cur_flag = (coarse[bxy * g.nwz + (bz >> 5)] >> (bz & 31)) & 1u;
+        w.cur_lx = -1;
+    }
+    if (!w.cur_flag) return false;
+    const int lx = w.vx & 7;
+    if (lx != w.cur_lx) {
+        w.cur_lx = lx;
+        w.cur_word = g.fine[(size_t)brick * 8 + lx];
+    }
+    return (w.cur_word >> (((w.vy & 7) << 3) | (w.vz & 7))) & 1ull;
+}
+
+__device__ __forceinline__ bool live_test(const KGrid& g, const Walk& w) {
+    const int brick = ((w.vx >> 3) * g.nb[1] + (w.vy >> 3)) * g.nb[2] + (w.vz >> 3);
+    const unsigned long long word = g.fine_live[(size_t)brick * 8 + (w.vx & 7)];
+    return (word >> (((w.vy & 7) << 3) | (w.vz & 7))) & 1ull;
+}
+
+// all 8 corner links present?  (only needed for the backward loop quirk, surf_trav.cu:1925-1937)
+__device__ __forceinline__ bool links_present(const KGrid& g, const Walk& w) {
+    if (w.vx + 1 >= g.size[0] || w.vy + 1 >= g.size[1] || w.vz + 1 >= g.size[2]) return false;
+    const int32_t* p = g.links + ((size_t)w.vx * g.offx + (size_t)w.vy * g.offy + w.vz);
+    return (p[0] | p[1] | p[g.offy] | p[g.offy + 1] | p[g.offx] | p[g.offx + 1] |
+            p[g.offx + g.offy] | p[g.offx + g.offy + 1]) >= 0;
+}
+
+// ------------------------------------------------------------------------------------
+// Voxel geometry for a lane that reached a work voxel (surf_trav.cu:212-260)
+// ------------------------------------------------------------------------------------
+struct Vox {
+    int lk[8];
+    float dens[8];
+    float surf[8];
+    double fs[4];
+    float new_origin[3];  // o + t_close d  (float, as computed by the reference's FFMA)
+    float smin, smax;
+    float t_close;
+};
+
+__device__ __forceinline__ void load_voxel(const KGrid& g, const Ray& r, const Walk& w, Vox& v) {
+    v.t_close = walk_t_close(r, w);
+    const int32_t* p = g.links + ((size_t)w.vx * g.offx + (size_t)w.vy * g.offy + w.vz);
+    v.lk[0] = p[0];
+    v.lk[1] = p[1];
+    v.lk[2] = p[g.offy];
+    v.lk[3] = p[g.offy + 1];
+    v.lk[4] = p[g.offx];
+    v.lk[5] = p[g.offx + 1];
+    v.lk[6] = p[g.offx + g.offy];
+    v.lk[7] = p[g.offx + g.offy + 1];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        v.dens[i] = g.density[v.lk[i]];
+        v.surf[i] = g.surface[v.lk[i]];
+    }
+    double no[3];
+    const int vv[3] = {w.vx, w.vy, w.vz};
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        v.new_origin[k] = fmaf(v.t_close, r.d[k], r.o[k]);
+        no[k] = (double)v.new_origin[k] - (double)vv[k];
+    }
+    surface_cubic(v.surf, no, r.d, v.fs);
+    v.smin = v.surf[0];
+    v.smax = v.surf[0];
+#pragma unroll
+    for (int i = 1; i < 8; ++i) {
+        v.smin = fminf(v.smin, v.surf[i]);
+        v.smax = fmaxf(v.smax, v.surf[i]);
+    }
+}
+
+// sample position of root st inside the voxel; false when outside [0,1]^3 (surf_trav.cu:322-340)
+__device__ __forceinline__ bool root_position(const Ray& r, const Walk& w, const Vox& v, double st,
+                                              float* pos) {
+    const int vv[3] = {w.vx, w.vy, w.vz};
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        pos[k] = fmaf((float)st, r.d[k], v.new_origin[k]);
+        pos[k] -= (float)vv[k];  // l = min(voxel, size-2) == voxel: the walk never leaves [0,size-2]
+    }
+    return !((pos[0] < 0) | (pos[0] > 1) | (pos[1] < 0) | (pos[1] > 1) | (pos[2] < 0) | (pos[2] > 1));
+}
+
+// fake-sample geometry (surf_trav.cu:437-490)
+__device__ __forceinline__ void fake_position(const Ray& r, const Walk& w, const Vox& v, float* pos) {
+    const float tm = (w.t_far + v.t_close) / 2.f;
+    const int vv[3] = {w.vx, w.vy, w.vz};
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        pos[k] = fmaf(tm, r.d[k], r.o[k]);
+        pos[k] -= (float)vv[k];
+    }
+}
+__device__ __forceinline__ float fake_distance(const KGrid& g, const KOpt& o, const Vox& v,
+                                               const float* pos, double* miu_out, double* std_out) {
+    double miu = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) miu += (double)v.surf[i];
+    miu = miu / 8;
+    double var = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) var += sqrd((double)v.surf[i] - miu);
+    double sd = (double)sqrtf((float)fmax((double)1e-9f, var / 8));
+    if (!o.fake_sample_normalize_surf) sd = 1.;
+    float ns[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) ns[i] = (float)((double)v.surf[i] / sd);
+    const float fs_s = trilerp8(ns, pos);
+    float dist = INFINITY;
+    for (int i = 0; i < g.level_set_num; ++i) {
+        const float dd = fs_s - g.level_set[i];
+        dist = (fabsf(dd) < fabsf(dist)) ? dd : dist;
+    }
+    *miu_out = miu;
+    *std_out = sd;
+    return dist;
+}
+
+// ------------------------------------------------------------------------------------
+// Wave-cooperative shading.  Lane layout: lane = cs * D + e with cs the corner slot of
+// this round and e = ch * B + k the SH coefficient; CPR corners are served per round.
+// ------------------------------------------------------------------------------------
+struct LaneRec {
+    int link[8];
+};
+
+template <int B>
+struct Coop {
+    static constexpr int D = 3 * B;
+    static constexpr int CPR = (64 / D) < 8 ? (64 / D) : 8;
+    static constexpr int ROUNDS = (8 + CPR - 1) / CPR;
+};
+
+// trilinear weight of corner c (bit 2 = x, bit 1 = y, bit 0 = z)
+__device__ __forceinline__ float corner_w(int c, float px, float py, float pz) {
+    const float wx = (c & 4) ? px : 1.f - px;
+    const float wy = (c & 2) ? py : 1.f - py;
+    const float wz = (c & 1) ? pz : 1.f - pz;
+    return wx * wy * wz;
+}
+
+// Forward: colour[ch] = sum_k sph[k] * trilerp(sh[.., ch*B+k]) for every lane in `need`.
+template <int B>
+__device__ __forceinline__ void coop_shade_fwd(const KGrid& g, unsigned long long need,
+                                               const LaneRec* rec_wave, const float* sph_wave,
+                                               const float* pos, float* color) {
+    using C = Coop<B>;
+    const int lane = threadIdx.x & 63;
+    const int cs = lane / C::D;
+    const int e = lane - cs * C::D;
+    const int ch = e / B;
+    const int k = e - ch * B;
+    const bool on = cs < C::CPR;
+    while (need) {
+        const int r = __ffsll((long long)need) - 1;
+        need &= need - 1;
+        const float px = bcast_f(pos[0], r), py = bcast_f(pos[1], r), pz = bcast_f(pos[2], r);
+        float acc = 0.f;
+#pragma unroll
+        for (int rd = 0; rd < C::ROUNDS; ++rd) {
+            const int c = rd * C::CPR + cs;
+            if (on && c < 8) {
+                const int link = rec_wave[r].link[c];
+                const float val = g.sh[(size_t)link * C::D + e];
+                acc = fmaf(corner_w(c, px, py, pz), val, acc);
+            }
+        }
+        acc = on ? acc * sph_wave[r * kSphPad + k] : 0.f;
+        const float s0 = wave_sum(ch == 0 ? acc : 0.f);
+        const float s1 = wave_sum(ch == 1 ? acc : 0.f);
+        const float s2 = wave_sum(ch == 2 ? acc : 0.f);
+        if (lane == r) {
+            color[0] = s0;
+            color[1] = s1;
+            color[2] = s2;
+        }
+    }
+}
+
+// Backward: recomputes the colour, scatters d/d(sh) with row-contiguous atomics and
+// returns (to the owning lane) sum_c gout_c * max(colour_c + .5, 0) and d(loss)/d(pos)
+// through the SH coefficients.  surf_trav.cu:2089-2139, 2241-2264.
+template <int B>
+__device__ __forceinline__ void coop_shade_bwd(const KGrid& g, const KGrads& G, bool want_dpos,
+                                               unsigned long long need, const LaneRec* rec_wave,
+                                               const float* sph_wave, const float* pos, float weight,
+                                               const float* gout, float* total_color,
+                                               float* grad_xyz) {
+    using C = Coop<B>;
+    const int lane = threadIdx.x & 63;
+    const int cs = lane / C::D;
+    const int e = lane - cs * C::D;
+    const int ch = e / B;
+    const int k = e - ch * B;
+    const bool on = cs < C::CPR;
+    while (need) {
+        const int r = __ffsll((long long)need) - 1;
+        need &= need - 1;
+        const float px = bcast_f(pos[0], r), py = bcast_f(pos[1], r), pz = bcast_f(pos[2], r);
+        const float wgt = bcast_f(weight, r);
+        const float g0 = bcast_f(gout[0], r), g1 = bcast_f(gout[1], r), g2 = bcast_f(gout[2], r);
+        float acc = 0.f, ax = 0.f, ay = 0.f, az = 0.f;
+        int link_r[C::ROUNDS];
+        float w_r[C::ROUNDS];
+#pragma unroll
+        for (int rd = 0; rd < C::ROUNDS; ++rd) {
+            const int c = rd * C::CPR + cs;
+            link_r[rd] = -1;
+            w_r[rd] = 0.f;
+            if (on && c < 8) {
+                const int link = rec_wave[r].link[c];
+                const float val = g.sh[(size_t)link * C::D + e];
+                const float wx = (c & 4) ? px : 1.f - px;
+                const float wy = (c & 2) ? py : 1.f - py;
+                const float wz = (c & 1) ? pz : 1.f - pz;
+                const float w = wx * wy * wz;
+                acc = fmaf(w, val, acc);
+                ax = fmaf(((c & 4) ? wy : -wy) * wz, val, ax);
+                ay = fmaf(((c & 2) ? wx : -wx) * wz, val, ay);
+                az = fmaf(((c & 1) ? wx : -wx) * wy, val, az);
+                link_r[rd] = link;
+                w_r[rd] = w;
+            }
+        }
+        const float sphk = on ? sph_wave[r * kSphPad + k] : 0.f;
+        acc *= sphk;
+        const float s0 = wave_sum(ch == 0 ? acc : 0.f) + 0.5f;
+        const float s1 = wave_sum(ch == 1 ? acc : 0.f) + 0.5f;
+        const float s2 = wave_sum(ch == 2 ? acc : 0.f) + 0.5f;
+        const float t0 = fmaxf(s0, 0.f), t1 = fmaxf(s1, 0.f), t2 = fmaxf(s2, 0.f);
+        const float total = (t0 * g0 + t2 * g2) + t1 * g1;  // (c0 + c2) + c1, :2112-2115
+        const float in01 = (ch == 0) ? (t0 == s0 ? 1.f : 0.f)
+                                     : (ch == 1) ? (t1 == s1 ? 1.f : 0.f) : (t2 == s2 ? 1.f : 0.f);
+        const float gch = (ch == 0) ? g0 : (ch == 1) ? g1 : g2;
+        const float cg = sphk * (wgt * in01 * gch);
+        if (G.grad_sh != nullptr) {
+#pragma unroll
+            for (int rd = 0; rd < C::ROUNDS; ++rd) {
+                if (link_r[rd] >= 0)
+                    atomicAdd(&G.grad_sh[(size_t)link_r[rd] * C::D + e], w_r[rd] * cg);
+            }
+        }
+        float gx = 0.f, gy = 0.f, gz = 0.f;
+        if (want_dpos) {
+            gx = wave_sum(cg * ax);
+            gy = wave_sum(cg * ay);
+            gz = wave_sum(cg * az);
+        }
+        if (lane == r) {
+            *total_color = total;
+            grad_xyz[0] = gx;
+            grad_xyz[1] = gy;
+            grad_xyz[2] = gz;
+        }
+    }
+}
+
+// per-lane scatter of 8 corner contributions into a [N,1] gradient plane + touched mask
+__device__ __forceinline__ void scatter8(float* out, uint8_t* mask, const int* lk, const float* w) {
+    if (out == nullptr) return;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        atomicAdd(&out[lk[i]], w[i]);
+        if (mask != nullptr) mask[lk[i]] = 1;
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// Forward kernel: trace_ray_surf_trav (surf_trav.cu:37-562) for one ray per lane.
+//   CACHE: also record (rwalpha, weight, t) of the first M samples for the fused losses.
+//   COUNT: accumulate the V_t / V_a / S counters of SURVEY.md section 8(d).
+// Sample cache layout: entry i of ray q at [i * Q + q] (lane-coalesced); cache_n[q] entries
+// are valid, the rest are implicit zeros.
+// ------------------------------------------------------------------------------------
+template <int B, bool CACHE, bool COUNT>
+__global__ void __launch_bounds__(kBlock)
+k_forward(KGrid g, KOpt o, const float* __restrict__ origins, const float* __restrict__ dirs,
+          long long Q, float* __restrict__ rgb_out, int M, float* __restrict__ cache_a,
+          float* __restrict__ cache_w, float* __restrict__ cache_t, int* __restrict__ cache_n,
+          int coarse_in_lds, unsigned long long* counters) {
+    extern __shared__ unsigned int s_coarse[];
+    __shared__ float s_sph[kBlock * kSphPad];
+    __shared__ LaneRec s_rec[kBlock];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const unsigned int* coarse = g.coarse;
+    if (coarse_in_lds) {
+        for (int i = tid; i < g.coarse_words; i += kBlock) s_coarse[i] = g.coarse[i];
+        __syncthreads();
+        coarse = s_coarse;
+    }
+    const float* sph_wave = s_sph + (tid & ~63) * kSphPad;
+    const LaneRec* rec_wave = s_rec + (tid & ~63);
+
+    const long long q = (long long)blockIdx.x * kBlock + tid;
+    const bool valid = q < Q;
+    Ray r;
+    r.tmin = 1.f;
+    r.tmax = 0.f;
+    if (valid) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            r.o[k] = origins[3 * q + k];
+            r.d[k] = dirs[3 * q + k];
+        }
+        float sph[B];
+        eval_sh<B>(r.d, sph);
+#pragma unroll
+        for (int k = 0; k < B; ++k) s_sph[tid * kSphPad + k] = sph[k];
+        setup_ray(g, o, r);
+    }
+    float outv[3] = {0.f, 0.f, 0.f};
+    float log_transmit = 0.f;
+    int sample_i = 0;
+    int intersect_i = -1;
+    int n_trav = 0, n_act = 0, n_samp = 0;
+    bool active = valid && !(r.tmin > r.tmax);
+    Walk w;
+    if (active) walk_init(g, r, w);
+
+    while (__any(active)) {
+        // (A) advance to the next work voxel
+        bool found = false;
+        while (active && !found) {
+            walk_step(g, r, w);
+            found = walk_test(g, coarse, w);
+            if (COUNT) {
+                ++n_trav;
+                n_act += live_test(g, w) ? 1 : 0;
+            }
+            active = (w.t <= r.tmax);
+        }
+        // (B) geometry
+        Vox v;
+        if (found) load_voxel(g, r, w, v);
+        bool vox_has_sample = false, vox_has_surf = false;
+        // (C) real intersections, one level set at a time
+        for (int li = 0; li < g.level_set_num; ++li) {
+            const float lvf = g.level_set[li];
+            const bool lv_ok = found && !(lvf < v.smin || lvf > v.smax);
+            if (!__any(lv_ok)) continue;
+            double st[3] = {-1, -1, -1};
+            if (lv_ok) {
+                vox_has_surf = true;
+                solve_cubic_vieta(v.fs[0] - (double)lvf, v.fs[1], v.fs[2], v.fs[3], st);
+            }
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                bool cand = lv_ok && (st[j] > 0);
+                float pos[3] = {0.f, 0.f, 0.f};
+                if (cand) cand = root_position(r, w, v, st[j], pos);
+                if (cand) vox_has_sample = true;
+                if (cand && o.only_outward_intersect) {  // :350-367
+                    float sg[3];
+                    field_grad(v.surf, pos, sg);
+                    const float ndd = -(sg[0] * r.d[0] + sg[1] * r.d[1] + sg[2] * r.d[2]);
+                    if (ndd >= 0.f) cand = false;
+                }
+                bool shade = false;
+                float rwalpha = 0.f;
+                if (cand) {
+                    ++intersect_i;
+                    const float raw_alpha = trilerp8(v.dens, pos);
+                    if (raw_alpha > o.sigma_thresh) {
+                        const float alpha = alpha_act(raw_alpha, o.alpha_activation_type);
+                        const float rw = o.truncated_vol_render
+                                             ? trunc_rw((float)intersect_i, g.trunc_a, o.trunc_vol_weight_min)
+                                             : 1.f;
+                        rwalpha = alpha * rw;
+                        shade = true;
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) s_rec[tid].link[i] = v.lk[i];
+                    }
+                }
+                const unsigned long long need = __ballot(shade);
+                if (need) {
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                    float color[3] = {0.f, 0.f, 0.f};
+                    coop_shade_fwd<B>(g, need, rec_wave, sph_wave, pos, color);
+                    if (shade) {
+                        const float pcnt = -1 * logf(1 - rwalpha);
+                        const float weight = expf(log_transmit) * (1.f - expf(-pcnt));
+                        log_transmit -= pcnt;
+#pragma unroll
+                        for (int c = 0; c < 3; ++c) outv[c] += weight * fmaxf(color[c] + 0.5f, 0.f);
+                        if (COUNT) ++n_samp;
+                        if (CACHE && sample_i < M) {
+                            const size_t ci = (size_t)sample_i * Q + q;
+                            cache_a[ci] = rwalpha;
+                            cache_w[ci] = weight;
+                            cache_t[ci] = (float)((double)v.t_close + st[j]);
+                            sample_i += 1;
+                        }
+                    }
+                }
+            }
+        }
+        // fake sample (surf_trav.cu:423-541)
+        {
+            bool fk = found && o.surf_fake_sample && !vox_has_sample &&
+                      (!o.limited_fake_sample || vox_has_surf) &&
+                      ((w.t_far - v.t_close) > o.surf_fake_sample_min_vox_len);
+            float pos[3] = {0.f, 0.f, 0.f};
+            float alpha = 0.f;
+            if (fk) {
+                fake_position(r, w, v, pos);
+                alpha = trilerp8(v.dens, pos);
+                fk = alpha > o.sigma_thresh;
+            }
+            if (fk) {
+                alpha = alpha_act(alpha, o.alpha_activation_type);
+                double miu, sd;
+                const float dist = fake_distance(g, o, v, pos, &miu, &sd);
+                alpha = alpha * expf((float)(-.5 * (double)sqrf(dist / g.fake_sample_std)));
+                const float rw = o.truncated_vol_render
+                                     ? trunc_rw((float)intersect_i, g.trunc_a, o.trunc_vol_weight_min)
+                                     : 1.f;
+                alpha = alpha * rw;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) s_rec[tid].link[i] = v.lk[i];
+            }
+            const unsigned long long need = __ballot(fk);
+            if (need) {
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                float color[3] = {0.f, 0.f, 0.f};
+                coop_shade_fwd<B>(g, need, rec_wave, sph_wave, pos, color);
+                if (fk) {
+                    const float pcnt = -1 * logf(1 - alpha);
+                    const float weight = expf(log_transmit) * (1.f - expf(-pcnt));
+                    log_transmit -= pcnt;
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) outv[c] += weight * fmaxf(color[c] + 0.5f, 0.f);
+                    if (COUNT) ++n_samp;
+                    if (CACHE && sample_i < M && o.fake_sample_l_dist) {
+                        const size_t ci = (size_t)sample_i * Q + q;
+                        cache_a[ci] = alpha;
+                        cache_w[ci] = weight;
+                        cache_t[ci] = (w.t_far + v.t_close) / 2.f;
+                        sample_i += 1;
+                    }
+                }
+            }
+        }
+        if (found && expf(log_transmit) < o.stop_thresh) {  // :544-547
+            log_transmit = -1e3f;
+            active = false;
+        }
+    }
+    if (valid) {
+        const float bg = expf(log_transmit) * o.background_brightness;  // :553-555 (== bg for a miss)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) rgb_out[3 * q + c] = outv[c] + bg;
+        if (CACHE) cache_n[q] = sample_i;
+    }
+    if (COUNT && counters != nullptr) {
+        const float ft = wave_sum((float)n_trav), fa = wave_sum((float)n_act),
+                    fs = wave_sum((float)n_samp), fr = wave_sum(valid ? 1.f : 0.f);
+        if (lane == 0) {
+            atomicAdd(&counters[0], (unsigned long long)ft);
+            atomicAdd(&counters[1], (unsigned long long)fa);
+            atomicAdd(&counters[2], (unsigned long long)fs);
+            atomicAdd(&counters[3], (unsigned long long)fr);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// Backward kernel: render_ray_backward_kernel prologue + trace_ray_surf_trav_backward
+// (surf_trav.cu:3241-3368, 1710-2911), one ray per lane.
+//   FUSED: grad_in is rgb_gt and the image-loss gradient is formed here (:3306-3316);
+//          otherwise grad_in is dL/drgb.
+// ------------------------------------------------------------------------------------
+template <int B, bool FUSED>
+__global__ void __launch_bounds__(kBlock)
+k_backward(KGrid g, KOpt o, KLoss L, KGrads G, const float* __restrict__ origins,
+           const float* __restrict__ dirs, long long Q, const float* __restrict__ grad_in,
+           const float* __restrict__ color_cache, int M, const float* __restrict__ cache_a,
+           const float* __restrict__ cache_w, const float* __restrict__ cache_t,
+           const int* __restrict__ cache_n, int coarse_in_lds) {
+    extern __shared__ unsigned int s_coarse[];
+    __shared__ float s_sph[kBlock * kSphPad];
+    __shared__ LaneRec s_rec[kBlock];
+    const int tid = threadIdx.x;
+    const unsigned int* coarse = g.coarse;
+    if (coarse_in_lds) {
+        for (int i = tid; i < g.coarse_words; i += kBlock) s_coarse[i] = g.coarse[i];
+        __syncthreads();
+        coarse = s_coarse;
+    }
+    const float* sph_wave = s_sph + (tid & ~63) * kSphPad;
+    const LaneRec* rec_wave = s_rec + (tid & ~63);
+
+    const long long q = (long long)blockIdx.x * kBlock + tid;
+    const bool valid = q < Q;
+    Ray r;
+    r.tmin = 1.f;
+    r.tmax = 0.f;
+    float gout[3] = {0.f, 0.f, 0.f};
+    float accum = 0.f;
+    if (valid) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            r.o[k] = origins[3 * q + k];
+            r.d[k] = dirs[3 * q + k];
+        }
+        float sph[B];
+        eval_sh<B>(r.d, sph);
+#pragma unroll
+        for (int k = 0; k < B; ++k) s_sph[tid * kSphPad + k] = sph[k];
+        setup_ray(g, o, r);
+        float cc[3];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            cc[i] = color_cache[3 * q + i];
+            if (FUSED) {
+                const float resid = cc[i] - grad_in[3 * q + i];
+                gout[i] = resid * L.norm_l2 * L.lambda_l2;
+                gout[i] += (resid > 0.f) ? (L.norm_l1 * L.lambda_l1) : (-L.norm_l1 * L.lambda_l1);
+            } else {
+                gout[i] = grad_in[3 * q + i];
+            }
+        }
+        accum = fmaf(cc[0], gout[0], fmaf(cc[1], gout[1], cc[2] * gout[2]));  // :1800-1802
+    }
+
+    // prologue over this ray's sample cache (:1756-1793); entries >= n are zeros
+    const int n = (FUSED && valid && M > 0) ? min(cache_n[q], M) : 0;
+    auto AL = [&](int i) -> float { return (i < n) ? cache_a[(size_t)i * Q + q] : 0.f; };
+    auto WE = [&](int i) -> float { return (i < n) ? cache_w[(size_t)i * Q + q] : 0.f; };
+    auto TS = [&](int i) -> float { return (i < n) ? cache_t[(size_t)i * Q + q] : 0.f; };
+    float sample_alpha_sum = 0.f, sample_weight_sum = 0.f;
+    for (int i = 0; i < n; ++i) {
+        sample_alpha_sum += AL(i);
+        sample_weight_sum += WE(i);
+    }
+    sample_alpha_sum = clamp_lo(sample_alpha_sum);
+    sample_weight_sum = clamp_lo(sample_weight_sum);
+    float Den_Dasum = 0.f, Den_Dwsum = 0.f, sample_t_mean = 0.f;
+    int valid_sample_n = 0;
+    float shared_Dmeant_sign = 0.f;
+    int max_sample_id = 0;
+    {
+        float max_weight = 0.f;
+        for (int i = 0; i < n; ++i) {
+            const float a = AL(i), ww = WE(i);
+            Den_Dasum += a * (log_ratio(a, sample_alpha_sum) + 1.f) / sqrf(sample_alpha_sum);
+            Den_Dwsum += ww * (log_ratio(ww, sample_weight_sum) + 1.f) / sqrf(sample_weight_sum);
+            sample_t_mean += ww / sample_weight_sum * TS(i);
+            if (ww > max_weight) {
+                max_weight = ww;
+                max_sample_id = i;
+            }
+        }
+        for (int i = 0; i < n; ++i) {
+            const float ts = TS(i);
+            if (ts > 0.f) {
+                valid_sample_n++;
+                shared_Dmeant_sign += (sample_t_mean > ts) ? 1.f : ((sample_t_mean < ts) ? -1.f : 0.f);
+            }
+        }
+    }
+
+    float log_transmit = 0.f;
+    int sample_i = 0;
+    int intersect_i = -1;
+    bool active = valid && !(r.tmin > r.tmax);
+    Walk w;
+    if (active) walk_init(g, r, w);
+
+    // l_dist / l_entropy terms of d/d(rwalpha) (:2141-2210, 2602-2666)
+    auto aux_rwalpha = [&](float rwalpha, float& curr) {
+        const float denom = fminf(rwalpha - 1.f, -1e-8f);
+        if (L.lambda_l_dist > 0.f) {
+            float Dl = 0.f;
+            float log_Tk = log_transmit;
+            for (int k = sample_i; k < valid_sample_n; ++k) {
+                float Dwk = 0.f;
+                const float tk = TS(k);
+                for (int j = 0; j < n; ++j) Dwk += WE(j) * fabsf(tk - TS(j));
+                if (k == sample_i) {
+                    Dl += Dwk * expf(log_transmit);
+                } else {
+                    log_Tk += logf(clamp_lo(1.f - AL(k - 1)));
+                    Dl += Dwk * expf(log_Tk) * AL(k) / denom;
+                }
+            }
+            curr += L.lambda_l_dist * Dl;
+        }
+        if (L.lambda_l_entropy > 0.f) {
+            auto Den_Dw = [&](int k) -> float {
+                if (L.no_norm_weight_l_entropy) return -(logf(clamp_lo(WE(k))) + 1.f);
+                return -(log_ratio(WE(k), sample_weight_sum) + 1.f) / sample_weight_sum + Den_Dwsum;
+            };
+            float Den_Dai = Den_Dw(sample_i) * expf(log_transmit);
+            float log_Tk = log_transmit;
+            for (int k = sample_i + 1; k < valid_sample_n; ++k) {
+                const float Dwk = Den_Dw(k);
+                log_Tk += logf(clamp_lo(1.f - AL(k - 1)));
+                Den_Dai += Dwk * expf(log_Tk) * AL(k) / denom;
+            }
+            curr += L.lambda_l_entropy * Den_Dai;
+        }
+    };
+    auto sparsity_term = [&](float curr, float a, float weight) -> float {  // :2286-2300
+        const float _1_a = clamp_lo(1.f - a);
+        const double add = -(double)L.sparsity_loss * (1.0 / fmin((double)(_1_a * logf(_1_a)), -1e-8)) *
+                           (double)(1.f - weight / sample_weight_sum);
+        return (float)((double)curr + add);
+    };
+
+    while (__any(active)) {
+        bool found = false;
+        while (active && !found) {
+            walk_step(g, r, w);
+            found = walk_test(g, coarse, w);
+            active = (w.t <= r.tmax);
+            // backward-only loop quirk: `t += step_size` on voxels with a missing corner
+            // (:1935-1936) can end the loop one voxel early near the exit face.
+            if (active && !found && (w.t + o.step_size > r.tmax)) {
+                if (!links_present(g, w)) active = false;
+            }
+        }
+        Vox v;
+        if (found) load_voxel(g, r, w, v);
+        bool vox_has_sample = false, vox_has_surf = false;
+
+        for (int li = 0; li < g.level_set_num; ++li) {
+            const float lvf = g.level_set[li];
+            const bool lv_ok = found && !(lvf < v.smin || lvf > v.smax);
+            if (!__any(lv_ok)) continue;
+            double st[3] = {-1, -1, -1};
+            double fs[4] = {0, 0, 0, 0};
+            int root_type = CUBIC_NO_ROOT;
+            if (lv_ok) {
+                vox_has_surf = true;
+                fs[0] = v.fs[0] - (double)lvf;
+                fs[1] = v.fs[1];
+                fs[2] = v.fs[2];
+                fs[3] = v.fs[3];
+                root_type = solve_cubic_vieta(fs[0], fs[1], fs[2], fs[3], st);
+            }
+#pragma unroll
+            for (int st_id = 0; st_id < 3; ++st_id) {
+                bool cand = lv_ok && (st[st_id] > 0);
+                float pos[3] = {0.f, 0.f, 0.f};
+                if (cand) cand = root_position(r, w, v, st[st_id], pos);
+                if (cand) vox_has_sample = true;
+                if (cand && o.only_outward_intersect) {
+                    float sg[3];
+                    field_grad(v.surf, pos, sg);
+                    const float ndd = -(sg[0] * r.d[0] + sg[1] * r.d[1] + sg[2] * r.d[2]);
+                    if (ndd >= 0.f) cand = false;
+                }
+                bool shade = false;
+                float raw_alpha = 0.f, alpha = 0.f, trunc_reweight = 1.f, rwalpha = 0.f, pcnt = 0.f,
+                      weight = 0.f;
+                if (cand) {
+                    ++intersect_i;
+                    raw_alpha = trilerp8(v.dens, pos);
+                    if (raw_alpha > o.sigma_thresh) {
+                        alpha = alpha_act(raw_alpha, o.alpha_activation_type);
+                        trunc_reweight = o.truncated_vol_render
+                                             ? trunc_rw((float)intersect_i, g.trunc_a, o.trunc_vol_weight_min)
+                                             : 1.f;
+                        rwalpha = alpha * trunc_reweight;
+                        pcnt = -logf(clamp_lo(1.f - rwalpha));
+                        weight = expf(log_transmit) * (1.f - expf(-pcnt));
+                        shade = true;
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) s_rec[tid].link[i] = v.lk[i];
+                    }
+                }
+                const unsigned long long need = __ballot(shade);
+                if (!need) continue;
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                float total_color = 0.f;
+                float grad_xyz[3] = {0.f, 0.f, 0.f};
+                coop_shade_bwd<B>(g, G, !o.no_surf_grad_from_sh, need, rec_wave, sph_wave, pos, weight,
+                                  gout, &total_color, grad_xyz);
+                if (!shade) continue;
+                accum -= weight * total_color;
+                float curr_grad_rwalpha =
+                    accum / fminf(rwalpha - 1.f, -1e-8f) + total_color * expf(log_transmit);
+                aux_rwalpha(rwalpha, curr_grad_rwalpha);
+                log_transmit -= pcnt;
+
+                // the reference's lane-0 section (:2266-2448), here per ray
+                const float ts_i = TS(sample_i);
+                if (L.lambda_l_dist_a > 0.f) {
+                    float ga = 0.f;
+                    for (int j = 0; j < n; ++j) ga += AL(j) * fabsf(ts_i - TS(j));
+                    curr_grad_rwalpha += L.lambda_l_dist_a * ga;
+                }
+                if (L.lambda_l_entropy_a > 0.f) {
+                    const float Den_Dai = -(log_ratio(AL(sample_i), sample_alpha_sum) + 1.f) / sample_alpha_sum;
+                    curr_grad_rwalpha += L.lambda_l_entropy_a * (Den_Dai + Den_Dasum);
+                }
+                if (L.sparsity_loss > 0.f && raw_alpha > 0.f)
+                    curr_grad_rwalpha = sparsity_term(curr_grad_rwalpha, alpha, weight);
+                if (L.lambda_inwards_norm_loss > 0.f) {  // :2302-2323
+                    float sg[3];
+                    field_grad(v.surf, pos, sg);
+                    const float nn = clamp_lo(sqrtf(sqrf(sg[0]) + sqrf(sg[1]) + sqrf(sg[2])));
+                    const float nd = (-sg[0] / nn) * r.d[0] + (-sg[1] / nn) * r.d[1] + (-sg[2] / nn) * r.d[2];
+                    if (nd > 0.f) curr_grad_rwalpha += L.lambda_inwards_norm_loss * sqrf(nd);
+                }
+                const float curr_grad_alpha = curr_grad_rwalpha * trunc_reweight;
+                float curr_grad_raw_alpha = curr_grad_alpha * alpha_act_grad(alpha, o.alpha_activation_type);
+                {
+                    float cw[8];
+                    corner_weights(pos, curr_grad_raw_alpha, cw);
+                    scatter8(G.grad_density, G.mask, v.lk, cw);
+                }
+                if (L.lambda_l_di > 0.f && alpha < L.l_di_alpha_thresh)
+                    curr_grad_raw_alpha += L.lambda_l_di * (-1.f) * alpha_act_grad(alpha, o.alpha_activation_type);
+                trilerp_dpos(v.dens, pos, curr_grad_raw_alpha, grad_xyz);
+                float grad_st = grad_xyz[0] * r.d[0] + grad_xyz[1] * r.d[1] + grad_xyz[2] * r.d[2];
+                if (L.lambda_l_dist > 0.f || L.lambda_l_dist_a > 0.f) {
+                    float gw = 0.f, ga = 0.f;
+                    const float wi = WE(sample_i), ai = AL(sample_i);
+                    for (int j = 0; j < n; ++j) {
+                        const float tj = TS(j);
+                        const float sgn = (ts_i > tj) ? 1.f : (ts_i < tj) ? -1.f : 0.f;
+                        gw += sgn * wi * WE(j);
+                        ga += sgn * ai * AL(j);
+                    }
+                    grad_st += L.lambda_l_dist * gw + L.lambda_l_dist_a * ga;
+                }
+                if (L.lambda_l_samp_dist > 0.f) {
+                    const float sgn = (sample_t_mean > ts_i) ? 1.f : (sample_t_mean < ts_i) ? -1.f : 0.f;
+                    grad_st += L.lambda_l_samp_dist *
+                               (shared_Dmeant_sign * AL(sample_i) / sample_weight_sum + sgn * (-1.f));
+                }
+                if (L.lambda_conv_mode_samp > 0.f && trunc_reweight > o.trunc_vol_weight_min) {
+                    const float tm = TS(max_sample_id);
+                    const float gcm = (ts_i > tm) ? 1.f : (ts_i < tm) ? -1.f : 0.f;
+                    grad_st += L.lambda_conv_mode_samp * gcm;
+                }
+                float grad_fs[4] = {grad_st, grad_st, grad_st, grad_st};
+                cubic_root_grad_vieta(root_type, st_id, fs, grad_fs);
+                float gsurf[8];
+                const float nof[3] = {(float)((double)v.new_origin[0] - (double)w.vx),
+                                      (float)((double)v.new_origin[1] - (double)w.vy),
+                                      (float)((double)v.new_origin[2] - (double)w.vz)};
+                surface_cubic_grad(nof, r.d, grad_fs, gsurf);
+                scatter8(G.grad_surface, G.mask, v.lk, gsurf);
+                if (alpha < L.surf_sparse_alpha_thresh) {  // :2436-2445
+                    float cw[8];
+                    corner_weights(pos, L.lambda_inplace_surf_sparse, cw);
+                    scatter8(G.grad_surface, G.mask, v.lk, cw);
+                }
+                if (sample_i < M - 1) sample_i += 1;
+            }
+        }
+
+        // fake-sample gradient (:2460-2866)
+        {
+            bool fk = found && o.surf_fake_sample && !vox_has_sample &&
+                      (!o.limited_fake_sample || vox_has_surf) &&
+                      ((w.t_far - v.t_close) > o.surf_fake_sample_min_vox_len);
+            float pos[3] = {0.f, 0.f, 0.f};
+            float raw_alpha = 0.f;
+            if (fk) {
+                fake_position(r, w, v, pos);
+                raw_alpha = trilerp8(v.dens, pos);
+                fk = raw_alpha > o.sigma_thresh;
+            }
+            float alpha = 0.f, reweight = 0.f, trunc_reweight = 1.f, rw_alpha = 0.f, pcnt = 0.f,
+                  weight = 0.f, dist = 0.f;
+            double miu = 0., sd = 1.;
+            if (fk) {
+                alpha = alpha_act(raw_alpha, o.alpha_activation_type);
+                dist = fake_distance(g, o, v, pos, &miu, &sd);
+                reweight = expf((float)(-.5 * (double)sqrf(dist / g.fake_sample_std)));
+                trunc_reweight = o.truncated_vol_render
+                                     ? trunc_rw((float)intersect_i, g.trunc_a, o.trunc_vol_weight_min)
+                                     : 1.f;
+                rw_alpha = alpha * reweight * trunc_reweight;
+                pcnt = -1 * logf(clamp_lo(1.f - rw_alpha));
+                weight = expf(log_transmit) * (1.f - expf(-pcnt));
+#pragma unroll
+                for (int i = 0; i < 8; ++i) s_rec[tid].link[i] = v.lk[i];
+            }
+            const unsigned long long need = __ballot(fk);
+            if (need) {
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                float total_color = 0.f;
+                float gx_unused[3] = {0.f, 0.f, 0.f};
+                // fake samples carry no d/dpos (:2722)
+                coop_shade_bwd<B>(g, G, false, need, rec_wave, sph_wave, pos, weight, gout,
+                                  &total_color, gx_unused);
+                if (fk) {
+                    accum -= weight * total_color;
+                    float curr_grad_rwalpha =
+                        accum / fminf(rw_alpha - 1.f, -1e-8f) + total_color * expf(log_transmit);
+                    if (o.fake_sample_l_dist) aux_rwalpha(rw_alpha, curr_grad_rwalpha);
+                    log_transmit -= pcnt;
+                    if (o.fake_sample_l_dist) {
+                        if (L.lambda_l_dist_a > 0.f) {
+                            float ga = 0.f;
+                            const float ts_i = TS(sample_i);
+                            for (int j = 0; j < n; ++j) ga += AL(j) * fabsf(ts_i - TS(j));
+                            curr_grad_rwalpha += L.lambda_l_dist_a * ga;
+                        }
+                        if (L.lambda_l_entropy_a > 0.f) {
+                            const float Den_Dai =
+                                -(log_ratio(AL(sample_i), sample_alpha_sum) + 1.f) / sample_alpha_sum;
+                            curr_grad_rwalpha += L.lambda_l_entropy_a * (Den_Dai + Den_Dasum);
+                        }
+                        if (sample_i < M - 1) sample_i += 1;
+                    }
+                    if (L.sparsity_loss > 0.f && raw_alpha > 0.f)
+                        curr_grad_rwalpha = sparsity_term(curr_grad_rwalpha, rw_alpha, weight);
+                    if (L.lambda_inwards_norm_loss > 0.f) {
+                        float sg[3];
+                        field_grad(v.surf, pos, sg);
+                        const float nn = clamp_lo(sqrtf(sqrf(sg[0]) + sqrf(sg[1]) + sqrf(sg[2])));
+                        const float nd = (-sg[0] / nn) * r.d[0] + (-sg[1] / nn) * r.d[1] + (-sg[2] / nn) * r.d[2];
+                        if (nd > 0.f) curr_grad_rwalpha += L.lambda_inwards_norm_loss * sqrf(nd);
+                    }
+                    const float curr_grad_alpha = curr_grad_rwalpha * reweight * trunc_reweight;
+                    const float curr_grad_raw_alpha =
+                        curr_grad_alpha * alpha_act_grad(alpha, o.alpha_activation_type);
+                    {
+                        float cw[8];
+                        corner_weights(pos, curr_grad_raw_alpha, cw);
+                        scatter8(G.grad_density, G.mask, v.lk, cw);
+                    }
+                    // surface gradient through the gaussian re-weighting (:2792-2851)
+                    const float grad_fake_dist =
+                        curr_grad_rwalpha * (-alpha * trunc_reweight * dist * reweight / sqrf(g.fake_sample_std));
+                    float grad_ns[8];
+                    corner_weights(pos, grad_fake_dist, grad_ns);
+                    float gsurf[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+                    if (!o.fake_sample_normalize_surf) {
+#pragma unroll
+                        for (int ks = 0; ks < 8; ++ks) gsurf[ks] = grad_ns[ks];
+                    } else {
+                        const double std3 = cubd(sd);
+#pragma unroll
+                        for (int ks = 0; ks < 8; ++ks) {
+#pragma unroll
+                            for (int kn = 0; kn < 8; ++kn) {
+                                double jac = (double)v.surf[kn] * (miu - (double)v.surf[ks]) / 8.f / std3;
+                                if (ks == kn) jac += 1.f / sd;
+                                gsurf[ks] = (float)((double)gsurf[ks] + (double)grad_ns[kn] * jac);
+                            }
+                        }
+                    }
+                    scatter8(G.grad_surface, G.mask, v.lk, gsurf);
+                    if (G.grad_fake_sample_std != nullptr) {
+                        const float gstd = curr_grad_rwalpha * alpha * sqrf(dist) * reweight * trunc_reweight /
+                                           (g.fake_sample_std * g.fake_sample_std * g.fake_sample_std);
+                        atomicAdd(G.grad_fake_sample_std, gstd);
+                    }
+                }
+            }
+        }
+        if (found && expf(log_transmit) < o.stop_thresh) active = false;  // :2893-2895
+    }
+}
+
+// test_cubic_root_grad_kernel (test_cuda.cu:32-106), one row per thread
+__global__ void k_test_cubic_root_grad(const double* __restrict__ fs, const int* __restrict__ st_ids,
+                                       float* __restrict__ grad_fs, float* __restrict__ st_out,
+                                       long long n) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    double f[4] = {fs[4 * i], fs[4 * i + 1], fs[4 * i + 2], fs[4 * i + 3]};
+    double st[3] = {-1, -1, -1};
+    const int type = solve_cubic_vieta(f[0], f[1], f[2], f[3], st);
+#pragma unroll
+    for (int j = 0; j < 3; ++j) st_out[3 * i + j] = (float)st[j];
+    int root_num = 1;
+    if (type == CUBIC_POLY) root_num = 2;
+    else if (type == CUBIC_THREE_R) root_num = 3;
+    float g[4] = {grad_fs[4 * i], grad_fs[4 * i + 1], grad_fs[4 * i + 2], grad_fs[4 * i + 3]};
+    if (type == CUBIC_NO_ROOT || st_ids[i] >= root_num) {
+        g[0] = g[1] = g[2] = g[3] = 0.f;
+    } else {
+        cubic_root_grad_vieta(type, st_ids[i], f, g);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) grad_fs[4 * i + j] = g[j];
+}
+
+}  // namespace asurf

@@ -1,0 +1,419 @@
+"""`svox2.csrc`-compatible operator module on top of libasurf_hip.so.
+
+Mirrors the pybind surface the reference's Python layer binds to
+(svox2/csrc/svox2.cpp:139-291): the six spec classes with read/write attributes and the
+hot-path functions with the same positional signatures.  torch is used for what it is
+good at here -- owning device memory and naming the current HIP stream -- and nothing
+else: every function below packs raw pointers into the C ABI of include/asurf.h.
+
+Functions outside the build's scope raise NotImplementedError naming the SURVEY.md
+section 8(f) row they belong to.
+"""
+import ctypes as C
+
+import torch
+
+from . import lib as _L
+
+__all__ = [
+    "SparseGridSpec", "CameraSpec", "RaysSpec", "RayVoxIntersecSpec", "RenderOptions",
+    "GridOutputGrads", "volume_render_surf_trav", "volume_render_surf_trav_backward",
+    "volume_render_surf_trav_fused", "volume_render_surface", "volume_render_surface_backward",
+    "volume_render_surface_fused", "test_cubic_root_grad", "sample_grid",
+]
+
+
+class SparseGridSpec:
+    """svox2.cpp:209-225 / data_spec.hpp:39-82"""
+
+    def __init__(self):
+        self.density_data = None
+        self.surface_data = None
+        self.level_set_data = None
+        self.sh_data = None
+        self.links = None
+        self._offset = None
+        self._scaling = None
+        self.basis_dim = 0
+        self.basis_type = 1
+        self.surface_type = 100
+        self.basis_data = None
+        self.background_links = None
+        self.background_data = None
+        self.fake_sample_std = 1.0
+        self.truncated_vol_render_a = 1.0
+
+
+class CameraSpec:
+    """svox2.cpp:227-237"""
+
+    def __init__(self):
+        self.c2w = None
+        self.fx = self.fy = self.cx = self.cy = 0.0
+        self.width = self.height = 0
+        self.ndc_coeffx = self.ndc_coeffy = -1.0
+
+
+class RaysSpec:
+    """svox2.cpp:239-243"""
+
+    def __init__(self):
+        self.origins = None
+        self.dirs = None
+        self.masks = None
+
+
+class RayVoxIntersecSpec:
+    """svox2.cpp:245-249"""
+
+    def __init__(self):
+        self.voxel_ls = None
+        self.vox_start_i = None
+        self.vox_num = None
+
+
+class RenderOptions:
+    """svox2.cpp:251-270 / data_spec.hpp:168-201"""
+
+    def __init__(self):
+        self.background_brightness = 1.0
+        self.step_size = 0.5
+        self.sigma_thresh = 1e-10
+        self.stop_thresh = 1e-7
+        self.near_clip = 0.0
+        self.use_spheric_clip = False
+        self.last_sample_opaque = False
+        self.surf_fake_sample = False
+        self.surf_fake_sample_min_vox_len = 0.1
+        self.limited_fake_sample = False
+        self.no_surf_grad_from_sh = False
+        self.alpha_activation_type = 1
+        self.fake_sample_l_dist = True
+        self.fake_sample_normalize_surf = True
+        self.only_outward_intersect = False
+        self.truncated_vol_render = False
+        self.trunc_vol_weight_min = 0.0
+
+
+class GridOutputGrads:
+    """svox2.cpp:279-290 / data_spec.hpp:84-120"""
+
+    def __init__(self):
+        self.grad_density_out = None
+        self.grad_sh_out = None
+        self.grad_surface_out = None
+        self.grad_fake_sample_std_out = None
+        self.grad_basis_out = None
+        self.grad_background_out = None
+        self.mask_out = None
+        self.mask_background_out = None
+
+
+# --------------------------------------------------------------------------------------
+# argument checking (the CHECK_INPUT / TORCH_CHECK set of util.hpp:3-13, data_spec.hpp:58-81)
+# --------------------------------------------------------------------------------------
+def _check_input(t, name, dtype=None):
+    if not torch.is_tensor(t):
+        raise RuntimeError(f"{name} must be a tensor")
+    if not t.is_cuda:
+        raise RuntimeError(f"{name} must be a CUDA tensor")
+    if not t.is_contiguous():
+        raise RuntimeError(f"{name} must be contiguous")
+    if dtype is not None and t.dtype != dtype:
+        raise RuntimeError(f"{name} must have dtype {dtype}, got {t.dtype}")
+    return t
+
+
+def _check_cpu(t, name):
+    if not torch.is_tensor(t) or t.is_cuda or not t.is_contiguous():
+        raise RuntimeError(f"{name} must be a contiguous CPU tensor")
+    return t
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None and t.numel() > 0 else C.c_void_p(0)
+
+
+def _defined(t):
+    return torch.is_tensor(t) and t.numel() > 0
+
+
+def _pack_grid(grid):
+    _check_input(grid.density_data, "density_data", torch.float32)
+    _check_input(grid.sh_data, "sh_data", torch.float32)
+    _check_input(grid.links, "links", torch.int32)
+    if grid.surface_type == 100 or grid.surface_data is None:
+        raise RuntimeError("surf_trav requires a surface grid (surface_type != SURFACE_TYPE_NONE)")
+    _check_input(grid.surface_data, "surface_data", torch.float32)
+    _check_input(grid.level_set_data, "level_set_data", torch.float32)
+    _check_cpu(grid._offset, "_offset")
+    _check_cpu(grid._scaling, "_scaling")
+    if grid.density_data.dim() != 2 or grid.sh_data.dim() != 2 or grid.links.dim() != 3:
+        raise RuntimeError("density_data/sh_data must be 2-D and links 3-D")
+    if _defined(grid.background_links) or _defined(grid.background_data):
+        raise NotImplementedError("MSI background layers are outside this build's scope")
+    if _defined(grid.basis_data) or grid.basis_type != 1:
+        raise NotImplementedError("learned bases (3D texture / MLP) are outside this build's scope")
+    if grid.sh_data.shape[1] != 3 * grid.basis_dim:
+        raise RuntimeError("sh_data.shape[1] must equal 3 * basis_dim")
+    if grid.sh_data.shape[0] != grid.density_data.shape[0] or \
+            grid.surface_data.shape[0] != grid.density_data.shape[0]:
+        raise RuntimeError("density/surface/sh row counts differ")
+    g = _L.AsurfGrid()
+    g.links = _ptr(grid.links)
+    g.density_data = _ptr(grid.density_data)
+    g.surface_data = _ptr(grid.surface_data)
+    g.sh_data = _ptr(grid.sh_data)
+    g.level_set_data = _ptr(grid.level_set_data)
+    g.capacity = grid.density_data.shape[0]
+    g.size = (C.c_int32 * 3)(*grid.links.shape)
+    g.level_set_num = grid.level_set_data.numel()
+    g.basis_dim = int(grid.basis_dim)
+    g.basis_type = int(grid.basis_type)
+    g.surface_type = int(grid.surface_type)
+    off = grid._offset.to(torch.float32).tolist()
+    scl = grid._scaling.to(torch.float32).tolist()
+    g.offset = (C.c_float * 3)(*off)
+    g.scaling = (C.c_float * 3)(*scl)
+    g.fake_sample_std = float(grid.fake_sample_std)
+    g.truncated_vol_render_a = float(grid.truncated_vol_render_a)
+    g.background_nlayers = 0
+    return g
+
+
+def _pack_rays(rays):
+    _check_input(rays.origins, "origins", torch.float32)
+    _check_input(rays.dirs, "dirs", torch.float32)
+    if rays.masks is not None:
+        _check_input(rays.masks, "masks")
+    if rays.origins.dim() != 2 or rays.origins.shape[1] != 3 or rays.dirs.shape != rays.origins.shape:
+        raise RuntimeError("origins and dirs must both be [Q, 3]")
+    r = _L.AsurfRays()
+    r.origins = _ptr(rays.origins)
+    r.dirs = _ptr(rays.dirs)
+    r.masks = _ptr(rays.masks)
+    r.n_rays = rays.origins.shape[0]
+    return r
+
+
+def _pack_opt(opt):
+    o = _L.AsurfRenderOptions()
+    for name, ctype in _L.RENDER_OPTION_FIELDS:
+        v = getattr(opt, name)
+        setattr(o, name, int(v) if ctype is C.c_int32 else float(v))
+    return o
+
+
+def _pack_grads(grads, grid):
+    n = grid.density_data.shape[0]
+    g = _L.AsurfGrads()
+
+    def chk(t, name, shape, dtype=torch.float32):
+        if not _defined(t):
+            return C.c_void_p(0)
+        _check_input(t, name, dtype)
+        if tuple(t.shape) != tuple(shape):
+            raise RuntimeError(f"{name} has shape {tuple(t.shape)}, expected {tuple(shape)}")
+        return _ptr(t)
+
+    g.grad_density_out = chk(grads.grad_density_out, "grad_density_out", grid.density_data.shape)
+    g.grad_sh_out = chk(grads.grad_sh_out, "grad_sh_out", grid.sh_data.shape)
+    g.grad_surface_out = chk(grads.grad_surface_out, "grad_surface_out", grid.surface_data.shape)
+    if _defined(grads.grad_fake_sample_std_out):
+        _check_input(grads.grad_fake_sample_std_out, "grad_fake_sample_std_out", torch.float32)
+        g.grad_fake_sample_std_out = _ptr(grads.grad_fake_sample_std_out)
+    g.mask_out = chk(grads.mask_out, "mask_out", (n,), torch.bool)
+    if _defined(grads.grad_basis_out) or _defined(grads.grad_background_out) or \
+            _defined(grads.mask_background_out):
+        raise NotImplementedError("basis / background gradients are outside this build's scope")
+    return g
+
+
+_ws_cache = {}
+
+
+def _workspace(device, nbytes):
+    """Scratch for one call.  A per-device buffer is grown on demand and reused: the
+    launches are stream-ordered, so back-to-back calls on one stream may share it."""
+    key = (device.type, device.index, torch.cuda.current_stream(device).cuda_stream)
+    buf = _ws_cache.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(int(nbytes), dtype=torch.uint8, device=device)
+        _ws_cache[key] = buf
+    return buf
+
+
+def _stream(device):
+    return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def _counters_ptr(counters):
+    if counters is None:
+        return C.c_void_p(0)
+    if counters.dtype != torch.int64 or counters.numel() < _L.N_COUNTERS or not counters.is_cuda:
+        raise RuntimeError("counters must be a CUDA int64 tensor with >= 4 elements")
+    return _ptr(counters)
+
+
+# --------------------------------------------------------------------------------------
+# operators
+# --------------------------------------------------------------------------------------
+def volume_render_surf_trav(grid, rays, opt, counters=None):
+    """Tensor volume_render_surf_trav(SparseGridSpec&, RaysSpec&, RenderOptions&)
+    (svox2.cpp:33; surf_trav.cu:3596-3654).  Returns rgb [Q,3]."""
+    g, r, o = _pack_grid(grid), _pack_rays(rays), _pack_opt(opt)
+    dev = grid.sh_data.device
+    with torch.cuda.device(dev):
+        out = torch.empty_like(rays.origins)
+        nb = _L.workspace_bytes(grid.links.shape, r.n_rays, 0)
+        ws = _workspace(dev, nb)
+        _L.check(_L.lib().asurf_volume_render_surf_trav(
+            C.byref(g), C.byref(r), C.byref(o), _ptr(out), _ptr(ws), nb, _counters_ptr(counters),
+            _stream(dev)))
+    return out
+
+
+def volume_render_surf_trav_backward(grid, rays, opt, grad_out, color_cache, grads):
+    """void volume_render_surf_trav_backward(grid, rays, opt, grad_out, color_cache, grads)
+    (svox2.cpp:36-37; surf_trav.cu:3708-3800)."""
+    g, r, o = _pack_grid(grid), _pack_rays(rays), _pack_opt(opt)
+    _check_input(grad_out, "grad_out", torch.float32)
+    _check_input(color_cache, "color_cache", torch.float32)
+    if grad_out.shape != rays.origins.shape or color_cache.shape != rays.origins.shape:
+        raise RuntimeError("grad_out / color_cache must be [Q, 3]")
+    gg = _pack_grads(grads, grid)
+    dev = grid.sh_data.device
+    with torch.cuda.device(dev):
+        nb = _L.workspace_bytes(grid.links.shape, r.n_rays, 0)
+        ws = _workspace(dev, nb)
+        _L.check(_L.lib().asurf_volume_render_surf_trav_backward(
+            C.byref(g), C.byref(r), C.byref(o), _ptr(grad_out), _ptr(color_cache), C.byref(gg),
+            _ptr(ws), nb, C.c_void_p(0), _stream(dev)))
+
+
+def volume_render_surf_trav_fused(grid, rays, opt, rgb_gt, beta_loss, sparsity_loss,
+                                  fused_surf_norm_reg_scale, fused_surf_norm_reg_con_check,
+                                  fused_surf_norm_reg_ignore_empty, lambda_l2, lambda_l1,
+                                  lambda_l_dist, lambda_l_entropy, no_norm_weight_l_entropy,
+                                  lambda_l_dist_a, lambda_l_entropy_a, lambda_l_samp_dist,
+                                  lambda_l_di, l_di_alpha_thresh, surf_sparse_alpha_thresh,
+                                  lambda_inplace_surf_sparse, lambda_inwards_norm_loss,
+                                  lambda_conv_mode_samp, l_dist_max_sample, rgb_out, grads,
+                                  global_n_rays=0, counters=None):
+    """void volume_render_surf_trav_fused(...) -- svox2.cpp:38-40; surf_trav.cu:3802-3942;
+    call site svox2/svox2.py:3594-3621.  `global_n_rays` and `counters` are extensions."""
+    g, r, o = _pack_grid(grid), _pack_rays(rays), _pack_opt(opt)
+    _check_input(rgb_gt, "rgb_gt", torch.float32)
+    _check_input(rgb_out, "rgb_out", torch.float32)
+    if rgb_gt.shape != rays.origins.shape or rgb_out.shape != rays.origins.shape:
+        raise RuntimeError("rgb_gt / rgb_out must be [Q, 3]")
+    gg = _pack_grads(grads, grid)
+    f = _L.AsurfFusedParams()
+    f.rgb_gt = _ptr(rgb_gt)
+    f.beta_loss = beta_loss
+    f.sparsity_loss = sparsity_loss
+    f.fused_surf_norm_reg_scale = fused_surf_norm_reg_scale
+    f.fused_surf_norm_reg_con_check = int(fused_surf_norm_reg_con_check)
+    f.fused_surf_norm_reg_ignore_empty = int(fused_surf_norm_reg_ignore_empty)
+    f.lambda_l2 = lambda_l2
+    f.lambda_l1 = lambda_l1
+    f.lambda_l_dist = lambda_l_dist
+    f.lambda_l_entropy = lambda_l_entropy
+    f.no_norm_weight_l_entropy = int(no_norm_weight_l_entropy)
+    f.lambda_l_dist_a = lambda_l_dist_a
+    f.lambda_l_entropy_a = lambda_l_entropy_a
+    f.lambda_l_samp_dist = lambda_l_samp_dist
+    f.lambda_l_di = lambda_l_di
+    f.l_di_alpha_thresh = l_di_alpha_thresh
+    f.surf_sparse_alpha_thresh = surf_sparse_alpha_thresh
+    f.lambda_inplace_surf_sparse = lambda_inplace_surf_sparse
+    f.lambda_inwards_norm_loss = lambda_inwards_norm_loss
+    f.lambda_conv_mode_samp = lambda_conv_mode_samp
+    f.l_dist_max_sample = int(l_dist_max_sample)
+    f.global_n_rays = int(global_n_rays)
+    dev = grid.sh_data.device
+    with torch.cuda.device(dev):
+        nb = _L.workspace_bytes(grid.links.shape, r.n_rays, int(l_dist_max_sample))
+        ws = _workspace(dev, nb)
+        _L.check(_L.lib().asurf_volume_render_surf_trav_fused(
+            C.byref(g), C.byref(r), C.byref(o), C.byref(f), _ptr(rgb_out), C.byref(gg), _ptr(ws),
+            nb, _counters_ptr(counters), _stream(dev)))
+
+
+def _pack_ray_vox(rv):
+    _check_input(rv.voxel_ls, "voxel_ls", torch.int32)
+    _check_input(rv.vox_start_i, "vox_start_i", torch.int32)
+    _check_input(rv.vox_num, "vox_num", torch.int32)
+    v = _L.AsurfRayVox()
+    v.voxel_ls, v.vox_start_i, v.vox_num = _ptr(rv.voxel_ls), _ptr(rv.vox_start_i), _ptr(rv.vox_num)
+    v.n_vox = rv.voxel_ls.shape[0]
+    return v
+
+
+def volume_render_surface(grid, rays, ray_vox, opt):
+    """Tensor volume_render_surface(grid, rays, ray_vox, opt) -- svox2.cpp:25;
+    render_lerp_kernel_surface.cu:1198-1291."""
+    g, r, v, o = _pack_grid(grid), _pack_rays(rays), _pack_ray_vox(ray_vox), _pack_opt(opt)
+    dev = grid.sh_data.device
+    with torch.cuda.device(dev):
+        out = torch.empty_like(rays.origins)
+        _L.check(_L.lib().asurf_volume_render_surface(C.byref(g), C.byref(r), C.byref(v), C.byref(o),
+                                                       _ptr(out), _stream(dev)))
+    return out
+
+
+def volume_render_surface_backward(grid, rays, ray_vox, opt, grad_out, color_cache, grads):
+    """svox2.cpp:26-28; render_lerp_kernel_surface.cu:1293-1353."""
+    g, r, v, o = _pack_grid(grid), _pack_rays(rays), _pack_ray_vox(ray_vox), _pack_opt(opt)
+    _check_input(grad_out, "grad_out", torch.float32)
+    _check_input(color_cache, "color_cache", torch.float32)
+    gg = _pack_grads(grads, grid)
+    dev = grid.sh_data.device
+    with torch.cuda.device(dev):
+        _L.check(_L.lib().asurf_volume_render_surface_backward(
+            C.byref(g), C.byref(r), C.byref(v), C.byref(o), _ptr(grad_out), _ptr(color_cache),
+            C.byref(gg), _stream(dev)))
+
+
+def volume_render_surface_fused(grid, rays, ray_vox, opt, rgb_gt, beta_loss, sparsity_loss, rgb_out,
+                                grads):
+    """svox2.cpp:29-31; render_lerp_kernel_surface.cu:1355-1439."""
+    g, r, v, o = _pack_grid(grid), _pack_rays(rays), _pack_ray_vox(ray_vox), _pack_opt(opt)
+    _check_input(rgb_gt, "rgb_gt", torch.float32)
+    _check_input(rgb_out, "rgb_out", torch.float32)
+    gg = _pack_grads(grads, grid)
+    dev = grid.sh_data.device
+    with torch.cuda.device(dev):
+        _L.check(_L.lib().asurf_volume_render_surface_fused(
+            C.byref(g), C.byref(r), C.byref(v), C.byref(o), _ptr(rgb_gt), float(beta_loss),
+            float(sparsity_loss), _ptr(rgb_out), C.byref(gg), _stream(dev)))
+
+
+def test_cubic_root_grad(T_fs, T_st_ids, T_grad_fs, T_st, use_vieta):
+    """Tensor test_cubic_root_grad(fs f64[N,4], st_ids i32[N], grad_fs f32[N,4] in/out,
+    st f32[N,3] out, bool use_vieta) -- svox2.cpp:12; test_cuda.cu:108-122."""
+    _check_input(T_fs, "fs", torch.float64)
+    _check_input(T_st_ids, "st_ids", torch.int32)
+    _check_input(T_grad_fs, "grad_fs", torch.float32)
+    _check_input(T_st, "st", torch.float32)
+    n = T_fs.shape[0]
+    if T_fs.shape != (n, 4) or T_grad_fs.shape != (n, 4) or T_st.shape != (n, 3) or T_st_ids.shape != (n,):
+        raise RuntimeError("test_cubic_root_grad: shape mismatch")
+    dev = T_fs.device
+    with torch.cuda.device(dev):
+        _L.check(_L.lib().asurf_test_cubic_root_grad(_ptr(T_fs), _ptr(T_st_ids), _ptr(T_grad_fs),
+                                                     _ptr(T_st), n, int(bool(use_vieta)), _stream(dev)))
+    return T_grad_fs
+
+
+def sample_grid(*args, **kwargs):
+    """Present because the reference's loader rejects an extension without it
+    (svox2/utils.py:36); point sampling itself is a SURVEY.md 8(f) N4 row."""
+    raise NotImplementedError("sample_grid is outside the hot-path scope (SURVEY.md section 8f, N4)")
+
+
+def _out_of_scope(name, row):
+    def fn(*args, **kwargs):
+        raise NotImplementedError(f"{name} is outside the hot-path scope (SURVEY.md section 8f, {row})")
+    fn.__name__ = name
+    return fn

@@ -1,0 +1,135 @@
+"""ctypes binding of libasurf_hip.so (the C ABI declared in include/asurf.h).
+
+This is the only way compute is reached: there is NO CPU fallback.  If the shared
+library is missing or fails to load, every entry point raises.
+"""
+import ctypes as C
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(_HERE, "csrc")
+LIB_PATH = os.path.join(CSRC, "libasurf_hip.so")
+
+c_f = C.POINTER(C.c_float)
+c_i = C.POINTER(C.c_int32)
+c_u8 = C.POINTER(C.c_uint8)
+
+
+class AsurfGrid(C.Structure):
+    _fields_ = [
+        ("links", C.c_void_p), ("density_data", C.c_void_p), ("surface_data", C.c_void_p),
+        ("sh_data", C.c_void_p), ("level_set_data", C.c_void_p), ("capacity", C.c_int64),
+        ("size", C.c_int32 * 3), ("level_set_num", C.c_int32), ("basis_dim", C.c_int32),
+        ("basis_type", C.c_int32), ("surface_type", C.c_int32), ("offset", C.c_float * 3),
+        ("scaling", C.c_float * 3), ("fake_sample_std", C.c_float),
+        ("truncated_vol_render_a", C.c_float), ("background_nlayers", C.c_int32),
+    ]
+
+
+class AsurfRays(C.Structure):
+    _fields_ = [("origins", C.c_void_p), ("dirs", C.c_void_p), ("masks", C.c_void_p),
+                ("n_rays", C.c_int64)]
+
+
+class AsurfRayVox(C.Structure):
+    _fields_ = [("voxel_ls", C.c_void_p), ("vox_start_i", C.c_void_p), ("vox_num", C.c_void_p),
+                ("n_vox", C.c_int64)]
+
+
+RENDER_OPTION_FIELDS = [
+    ("background_brightness", C.c_float), ("step_size", C.c_float), ("sigma_thresh", C.c_float),
+    ("stop_thresh", C.c_float), ("near_clip", C.c_float), ("use_spheric_clip", C.c_int32),
+    ("last_sample_opaque", C.c_int32), ("surf_fake_sample", C.c_int32),
+    ("surf_fake_sample_min_vox_len", C.c_float), ("limited_fake_sample", C.c_int32),
+    ("no_surf_grad_from_sh", C.c_int32), ("alpha_activation_type", C.c_int32),
+    ("fake_sample_l_dist", C.c_int32), ("fake_sample_normalize_surf", C.c_int32),
+    ("only_outward_intersect", C.c_int32), ("truncated_vol_render", C.c_int32),
+    ("trunc_vol_weight_min", C.c_float),
+]
+
+
+class AsurfRenderOptions(C.Structure):
+    _fields_ = RENDER_OPTION_FIELDS
+
+
+class AsurfGrads(C.Structure):
+    _fields_ = [("grad_density_out", C.c_void_p), ("grad_sh_out", C.c_void_p),
+                ("grad_surface_out", C.c_void_p), ("grad_fake_sample_std_out", C.c_void_p),
+                ("mask_out", C.c_void_p)]
+
+
+FUSED_FIELDS = [
+    ("rgb_gt", C.c_void_p), ("beta_loss", C.c_float), ("sparsity_loss", C.c_float),
+    ("fused_surf_norm_reg_scale", C.c_float), ("fused_surf_norm_reg_con_check", C.c_int32),
+    ("fused_surf_norm_reg_ignore_empty", C.c_int32), ("lambda_l2", C.c_float),
+    ("lambda_l1", C.c_float), ("lambda_l_dist", C.c_float), ("lambda_l_entropy", C.c_float),
+    ("no_norm_weight_l_entropy", C.c_int32), ("lambda_l_dist_a", C.c_float),
+    ("lambda_l_entropy_a", C.c_float), ("lambda_l_samp_dist", C.c_float),
+    ("lambda_l_di", C.c_float), ("l_di_alpha_thresh", C.c_float),
+    ("surf_sparse_alpha_thresh", C.c_float), ("lambda_inplace_surf_sparse", C.c_float),
+    ("lambda_inwards_norm_loss", C.c_float), ("lambda_conv_mode_samp", C.c_float),
+    ("l_dist_max_sample", C.c_int32), ("global_n_rays", C.c_int64),
+]
+
+
+class AsurfFusedParams(C.Structure):
+    _fields_ = FUSED_FIELDS
+
+
+N_COUNTERS = 4
+
+EXPORTS = [
+    "asurf_abi_version", "asurf_last_error", "asurf_workspace_bytes",
+    "asurf_volume_render_surf_trav", "asurf_volume_render_surf_trav_backward",
+    "asurf_volume_render_surf_trav_fused", "asurf_volume_render_surface",
+    "asurf_volume_render_surface_backward", "asurf_volume_render_surface_fused",
+    "asurf_test_cubic_root_grad",
+]
+
+_lib = None
+
+
+def build(force=False, verbose=False):
+    """Compile csrc/ into libasurf_hip.so with hipcc for gfx950 (cross-compiles without a GPU)."""
+    cmd = ["make", "-C", CSRC] + (["-B"] if force else []) + ["libasurf_hip.so"]
+    subprocess.check_call(cmd, stdout=None if verbose else subprocess.DEVNULL)
+    return LIB_PATH
+
+
+def lib():
+    """The loaded library; raises if the HIP extension is missing (no fallback exists)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; "
+                f"g.build()'` or `make -C {CSRC}`.  alphasurf_amd has no CPU fallback.")
+        L = C.CDLL(LIB_PATH)
+        L.asurf_last_error.restype = C.c_char_p
+        L.asurf_workspace_bytes.restype = C.c_size_t
+        L.asurf_workspace_bytes.argtypes = [C.POINTER(C.c_int32), C.c_int64, C.c_int32]
+        vp = C.c_void_p
+        L.asurf_volume_render_surf_trav.argtypes = [vp, vp, vp, vp, vp, C.c_size_t, vp, vp]
+        L.asurf_volume_render_surf_trav_backward.argtypes = [vp, vp, vp, vp, vp, vp, vp, C.c_size_t, vp, vp]
+        L.asurf_volume_render_surf_trav_fused.argtypes = [vp, vp, vp, vp, vp, vp, vp, C.c_size_t, vp, vp]
+        L.asurf_volume_render_surface.argtypes = [vp, vp, vp, vp, vp, vp]
+        L.asurf_volume_render_surface_backward.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp]
+        L.asurf_volume_render_surface_fused.argtypes = [vp, vp, vp, vp, vp, C.c_float, C.c_float, vp, vp, vp]
+        L.asurf_test_cubic_root_grad.argtypes = [vp, vp, vp, vp, C.c_int64, C.c_int32, vp]
+        if L.asurf_abi_version() != 1:
+            raise RuntimeError("libasurf_hip.so ABI version mismatch")
+        _lib = L
+    return _lib
+
+
+def check(rc):
+    """Non-zero return -> RuntimeError carrying the library's message (the reference raises
+    RuntimeError through TORCH_CHECK for the same class of misuse)."""
+    if rc != 0:
+        raise RuntimeError(f"asurf: {lib().asurf_last_error().decode()} (code {rc})")
+
+
+def workspace_bytes(size, n_rays, l_dist_max_sample):
+    arr = (C.c_int32 * 3)(*[int(s) for s in size])
+    return int(lib().asurf_workspace_bytes(arr, int(n_rays), int(l_dist_max_sample)))
