@@ -164,6 +164,19 @@ struct Launch {
     dim3 ray_grid;
 };
 
+// --- optional per-kernel timing (asurf_profile_enable) ---
+bool g_prof_on = false;
+hipEvent_t g_ev[4] = {nullptr, nullptr, nullptr, nullptr};
+int g_ev_last = -1;  // index of the last event recorded by the last call
+bool g_fwd_in_last_call = false;
+
+void prof_mark(int i, hipStream_t s) {
+    if (!g_prof_on) return;
+    if (!g_ev[i]) hipEventCreate(&g_ev[i]);
+    hipEventRecord(g_ev[i], s);
+    g_ev_last = i;
+}
+
 int launch_error(const char* what) {
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(ASURF_E_LAUNCH, "%s: %s", what, hipGetErrorString(e));
@@ -194,12 +207,16 @@ int prepare(const asurf_grid* grid, const asurf_rays* rays, const asurf_render_o
     L.coarse_in_lds = (L.ML.coarse_words * 4 <= kMaxCoarseLds) ? 1 : 0;
     L.dyn_lds = L.coarse_in_lds ? L.ML.coarse_words * 4 : 0;
     L.ray_grid = dim3((unsigned)((rays->n_rays + kBlock - 1) / kBlock));
+    g_ev_last = -1;
+    g_fwd_in_last_call = false;
+    prof_mark(0, L.stream);
     hipLaunchKernelGGL(k_build_masks, dim3((unsigned)L.ML.coarse_words), dim3(512), 0, L.stream, L.g,
                        opt->sigma_thresh, need_surf ? 1 : 0,
                        reinterpret_cast<unsigned long long*>(L.ws + L.ML.off_fine_work),
                        reinterpret_cast<unsigned long long*>(L.ws + L.ML.off_fine_live),
                        reinterpret_cast<unsigned int*>(L.ws + L.ML.off_coarse_work),
                        reinterpret_cast<unsigned int*>(L.ws + L.ML.off_coarse_live));
+    prof_mark(1, L.stream);
     return launch_error("k_build_masks");
 }
 
@@ -223,6 +240,8 @@ int run_forward(const Launch& L, const asurf_rays* rays, float* rgb_out, int M, 
         else ASURF_FWD(false, false);
     }
 #undef ASURF_FWD
+    prof_mark(2, L.stream);
+    g_fwd_in_last_call = true;
     return launch_error("k_forward");
 }
 
@@ -241,6 +260,7 @@ int run_backward(const Launch& L, const asurf_rays* rays, const KLoss& loss, con
         hipLaunchKernelGGL((k_backward<B, false>), L.ray_grid, dim3(kBlock), L.dyn_lds, L.stream, L.g,
                            L.o, loss, G, rays->origins, rays->dirs, (long long)rays->n_rays, grad_in,
                            color_cache, M, ca, cw, ct, cn, L.coarse_in_lds);
+    prof_mark(3, L.stream);
     return launch_error("k_backward");
 }
 
@@ -347,6 +367,31 @@ int asurf_volume_render_surf_trav_fused(const asurf_grid* grid, const asurf_rays
     if (rc) return rc;
     ASURF_DISPATCH_B(grid->basis_dim, run_backward<B_>(L, rays, loss, G, fused->rgb_gt, rgb_out, M, true));
     return rc;
+}
+
+int asurf_profile_enable(int on) {
+    g_prof_on = on != 0;
+    return 0;
+}
+
+int asurf_profile_read(float* ms, int n) {
+    if (!ms || n < 3) return fail(ASURF_E_INVALID, "asurf_profile_read needs room for 3 floats");
+    ms[0] = ms[1] = ms[2] = 0.f;
+    if (!g_prof_on || g_ev_last < 1) return fail(ASURF_E_INVALID, "profiling is off or no call was made");
+    hipEventSynchronize(g_ev[g_ev_last]);
+    hipEventElapsedTime(&ms[0], g_ev[0], g_ev[1]);
+    // a backward-only call records events 0,1,3; a forward-only call 0,1,2
+    if (g_ev_last == 2) {
+        hipEventElapsedTime(&ms[1], g_ev[1], g_ev[2]);
+    } else if (g_ev_last == 3) {
+        if (g_fwd_in_last_call) {
+            hipEventElapsedTime(&ms[1], g_ev[1], g_ev[2]);
+            hipEventElapsedTime(&ms[2], g_ev[2], g_ev[3]);
+        } else {
+            hipEventElapsedTime(&ms[2], g_ev[1], g_ev[3]);
+        }
+    }
+    return 0;
 }
 
 int asurf_test_cubic_root_grad(const double* fs, const int32_t* st_ids, float* grad_fs, float* st,

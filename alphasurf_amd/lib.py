@@ -84,7 +84,7 @@ EXPORTS = [
     "asurf_volume_render_surf_trav", "asurf_volume_render_surf_trav_backward",
     "asurf_volume_render_surf_trav_fused", "asurf_volume_render_surface",
     "asurf_volume_render_surface_backward", "asurf_volume_render_surface_fused",
-    "asurf_test_cubic_root_grad",
+    "asurf_test_cubic_root_grad", "asurf_profile_enable", "asurf_profile_read",
 ]
 
 _lib = None
@@ -128,6 +128,17 @@ def check(rc):
     RuntimeError through TORCH_CHECK for the same class of misuse)."""
     if rc != 0:
         raise RuntimeError(f"asurf: {lib().asurf_last_error().decode()} (code {rc})")
+
+
+def profile_enable(on=True):
+    check(lib().asurf_profile_enable(int(bool(on))))
+
+
+def profile_read():
+    """(masks_ms, forward_ms, backward_ms) of the last call, HIP-event timed on its stream."""
+    ms = (C.c_float * 3)()
+    check(lib().asurf_profile_read(ms, 3))
+    return float(ms[0]), float(ms[1]), float(ms[2])
 
 
 def workspace_bytes(size, n_rays, l_dist_max_sample):

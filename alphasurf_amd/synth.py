@@ -5,12 +5,12 @@ numpy only; used by bench.py, the tests and __graft_entry__.smoke().  No dataset
 import numpy as np
 
 
-def sphere_union_sdf(reso, n_spheres=8, seed=1234):
+def sphere_union_sdf(reso, n_spheres=8, seed=1234, center_range=(0.3, 0.7), radius_range=(0.10, 0.22)):
     """SDF (in voxel units, |grad| ~ 1) of a union of random spheres sampled at the
     grid vertices of a reso^3 volume."""
     rs = np.random.RandomState(seed)
-    centers = rs.uniform(0.3, 0.7, size=(n_spheres, 3)) * reso
-    radii = rs.uniform(0.10, 0.22, size=n_spheres) * reso
+    centers = rs.uniform(center_range[0], center_range[1], size=(n_spheres, 3)) * reso
+    radii = rs.uniform(radius_range[0], radius_range[1], size=n_spheres) * reso
     ax = np.arange(reso, dtype=np.float32)
     sdf = np.full((reso, reso, reso), 1e9, np.float32)
     # evaluate slab by slab to bound memory at large reso
@@ -39,12 +39,13 @@ def _dilate(mask, it):
 
 
 def make_sparse_scene(reso, basis_dim, band=3.0, dilate=2, seed=1234, level_set=(0.0,),
-                      n_spheres=8, fake_sample_std=1.0, trunc_a=1.0):
+                      n_spheres=8, fake_sample_std=1.0, trunc_a=1.0, center_range=(0.3, 0.7),
+                      radius_range=(0.10, 0.22)):
     """A pruned-grid look-alike: vertices within `band` voxels of the surface (dilated
     `dilate` times) are active, rows are numbered in raster order (svox2.py:2940-2945),
     everything else links to -1.  Parameter distributions follow the reference's own
     gradcheck (test/test_render_gradcheck_surface.py:71-77)."""
-    sdf = sphere_union_sdf(reso, n_spheres, seed)
+    sdf = sphere_union_sdf(reso, n_spheres, seed, center_range, radius_range)
     active = _dilate(np.abs(sdf) < band, dilate)
     n = int(active.sum())
     links = np.full((reso, reso, reso), -1, np.int32)
@@ -117,5 +118,8 @@ SYN_OPTS = dict(
     alpha_activation_type=1, fake_sample_l_dist=False, fake_sample_normalize_surf=True,
     only_outward_intersect=True, truncated_vol_render=True, trunc_vol_weight_min=1e-10,
 )
+# bench scene: 16 spheres spread over the volume -> ~1.3 M active voxels at 256^3 (8 %),
+# inside the 1-1.7 M range SURVEY.md section 8 assumes for a pruned lego-like grid
+BENCH_SCENE = dict(n_spheres=16, center_range=(0.2, 0.8), radius_range=(0.08, 0.2), seed=1234)
 SYN_FUSED = dict(lambda_l2=1.0, lambda_l1=0.0, lambda_l_entropy=1e-4, lambda_conv_mode_samp=1e-6,
                  l_dist_max_sample=64, l_di_alpha_thresh=0.1, surf_sparse_alpha_thresh=0.15)

@@ -1,0 +1,230 @@
+#!/usr/bin/env python3
+"""Headline benchmark: Mrays/s of one fused forward+backward pass of the surf_trav hot
+path (`volume_render_surf_trav_fused`) over an 800x800 view of a 256^3 sparse SDF grid,
+SH degree 2 (BASELINE.json configs[1]), plus the HBM-roofline fraction of the dominant
+kernel and the CPU oracle timed beside it.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+
+One step = one fused call on one batch of synthetic rays (one 800x800 view per rank,
+inputs resident in HBM).  With N > 1 (launched by torch.distributed.run, one rank per GPU)
+every rank renders its own view of the replicated grid and the gradient buffers are
+all-reduced over RCCL inside the timed step: weak scaling, value = total rays / time.
+Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--reso", type=int, default=256)
+    ap.add_argument("--basis-dim", type=int, default=9)
+    ap.add_argument("--width", type=int, default=800)
+    ap.add_argument("--shuffle", action="store_true", help="training-order (shuffled) rays")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-rays", type=int, default=40000)
+    return ap.parse_args()
+
+
+def algorithmic_bytes(n_rays, v_t, v_a, s, D, stat_loss, M):
+    """compulsory-traffic model of the REFERENCE algorithm.
+    Returns (forward bytes, backward bytes) for the whole batch."""
+    b_f = n_rays * (24 + 12) + 32 * v_t + 64 * v_a + s * 8 * 4 * (1 + D)
+    b_b = b_f + n_rays * 12 + s * 2 * 8 * 4 * (D + 2) + s * 16
+    if stat_loss:
+        b_b += 2 * 3 * 4 * min(s, n_rays * M)
+    return float(b_f), float(b_b)
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl")  # RCCL on ROCm
+    dev = torch.device("cuda", local_rank if world > 1 else 0)
+    torch.cuda.set_device(dev)
+
+    from alphasurf_amd import csrc_api as _C, lib as _lib, synth
+
+    # ---- synthetic workload (seeded; identical grid on every rank) ----
+    R, B = args.reso, args.basis_dim
+    D = 3 * B
+    sc = synth.make_sparse_scene(R, B, trunc_a=5.0, **synth.BENCH_SCENE)
+    o_np, d_np = synth.pinhole_rays(synth.orbit_camera(rank % 8), args.width, args.width)
+    if args.shuffle:
+        perm = np.random.RandomState(11 + rank).permutation(o_np.shape[0])
+        o_np, d_np = o_np[perm], d_np[perm]
+    Q = o_np.shape[0]
+    gt_np = np.random.RandomState(7 + rank).rand(Q, 3).astype(np.float32)
+
+    g = _C.SparseGridSpec()
+    g.density_data = torch.from_numpy(sc["density"]).to(dev)
+    g.surface_data = torch.from_numpy(sc["surface"]).to(dev)
+    g.sh_data = torch.from_numpy(sc["sh"]).to(dev)
+    g.links = torch.from_numpy(sc["links"]).to(dev)
+    g.level_set_data = torch.from_numpy(sc["level_set"]).to(dev)
+    g._offset = torch.from_numpy(sc["offset"])
+    g._scaling = torch.from_numpy(sc["scaling"])
+    g.basis_dim, g.basis_type, g.surface_type = B, 1, 102
+    g.fake_sample_std, g.truncated_vol_render_a = sc["fake_sample_std"], sc["truncated_vol_render_a"]
+    r = _C.RaysSpec()
+    r.origins, r.dirs = torch.from_numpy(o_np).to(dev), torch.from_numpy(d_np).to(dev)
+    r.masks = torch.ones(Q, dtype=torch.bool, device=dev)
+    opt = _C.RenderOptions()
+    for k, v in synth.SYN_OPTS.items():
+        setattr(opt, k, v)
+    gt = torch.from_numpy(gt_np).to(dev)
+    rgb = torch.zeros_like(gt)
+    gr = _C.GridOutputGrads()
+    gr.grad_density_out = torch.zeros_like(g.density_data)
+    gr.grad_sh_out = torch.zeros_like(g.sh_data)
+    gr.grad_surface_out = torch.zeros_like(g.surface_data)
+    gr.mask_out = torch.zeros(g.density_data.shape[0], dtype=torch.bool, device=dev)
+    F = synth.SYN_FUSED
+    M = F["l_dist_max_sample"]
+    Q_global = Q * world
+
+    def step(counters=None):
+        gr.mask_out.zero_()  # the reference allocates a fresh sparse_grad_indexer per call (svox2.py:3535)
+        _C.volume_render_surf_trav_fused(
+            g, r, opt, gt, 0.0, 0.0, 0.0, True, False, F["lambda_l2"], F["lambda_l1"], 0.0,
+            F["lambda_l_entropy"], False, 0.0, 0.0, 0.0, 0.0, F["l_di_alpha_thresh"],
+            F["surf_sparse_alpha_thresh"], 0.0, 0.0, F["lambda_conv_mode_samp"], M, rgb, gr,
+            global_n_rays=Q_global, counters=counters)
+        if world > 1:
+            # data-parallel exchange: sum of per-shard gradients == gradient of the global batch
+            dist.all_reduce(gr.grad_sh_out)
+            dist.all_reduce(gr.grad_density_out)
+            dist.all_reduce(gr.grad_surface_out)
+            m8 = gr.mask_out.view(torch.uint8)
+            dist.all_reduce(m8, op=dist.ReduceOp.MAX)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    ms_per_step = dt / args.steps * 1e3
+    value = Q_global / (dt / args.steps) / 1e6
+
+    out = None
+    if rank == 0:
+        # ---- counters (V_t, V_a, S) and per-kernel HIP-event times, outside the timed region ----
+        cnt = torch.zeros(4, dtype=torch.int64, device=dev)
+        step(cnt)
+        torch.cuda.synchronize()
+        v_t, v_a, s_cnt, n_r = [int(x) for x in cnt.cpu().tolist()]
+        _lib.profile_enable(True)
+        t_mask, t_fwd, t_bwd = [], [], []
+        for _ in range(max(5, min(args.steps, 20))):
+            gr.mask_out.zero_()
+            _C.volume_render_surf_trav_fused(
+                g, r, opt, gt, 0.0, 0.0, 0.0, True, False, F["lambda_l2"], F["lambda_l1"], 0.0,
+                F["lambda_l_entropy"], False, 0.0, 0.0, 0.0, 0.0, F["l_di_alpha_thresh"],
+                F["surf_sparse_alpha_thresh"], 0.0, 0.0, F["lambda_conv_mode_samp"], M, rgb, gr,
+                global_n_rays=Q_global)
+            a, b, c = _lib.profile_read()
+            t_mask.append(a), t_fwd.append(b), t_bwd.append(c)
+        _lib.profile_enable(False)
+        t_mask, t_fwd, t_bwd = float(np.mean(t_mask)), float(np.mean(t_fwd)), float(np.mean(t_bwd))
+        b_f, b_b = algorithmic_bytes(Q, v_t, v_a, s_cnt, D, True, M)
+        dom_name, dom_ms, dom_bytes = ("k_backward", t_bwd, b_b) if t_bwd >= t_fwd else ("k_forward", t_fwd, b_f)
+        achieved = dom_bytes / (dom_ms * 1e-3) / 1e9
+        peak = 8000.0
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tpath):
+            try:
+                tj = json.load(open(tpath))
+                traffic = tj.get(dom_name, {}).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        roofline = dict(bound="hbm", kernel=dom_name, achieved=round(achieved, 1), peak=peak, unit="GB/s",
+                        frac=round(achieved / peak, 4), traffic=traffic,
+                        algorithmic_bytes_per_launch=dom_bytes, avg_launch_ms=round(dom_ms, 4),
+                        per_kernel_ms=dict(k_build_masks=round(t_mask, 4), k_forward=round(t_fwd, 4),
+                                           k_backward=round(t_bwd, 4)),
+                        whole_call=dict(algorithmic_bytes=b_f + b_b,
+                                        achieved=round((b_f + b_b) / ((t_mask + t_fwd + t_bwd) * 1e-3) / 1e9, 1)))
+
+        cpu = None
+        if not args.no_cpu_baseline:
+            # the oracle (CPU restatement) on a bounded, strided sample of the same rays
+            from oracle import oracle as O
+            n_cpu = min(args.cpu_rays, Q)
+            idx = np.linspace(0, Q - 1, n_cpu).astype(np.int64)
+            osc = O.make_scene(sc["links"], sc["density"], sc["surface"], sc["sh"], sc["level_set"],
+                               sc["offset"], sc["scaling"], B, sc["fake_sample_std"],
+                               sc["truncated_vol_render_a"])
+            fused = dict(lambda_l2=F["lambda_l2"], lambda_l1=F["lambda_l1"],
+                         lambda_l_entropy=F["lambda_l_entropy"],
+                         lambda_conv_mode_samp=F["lambda_conv_mode_samp"], l_dist_max_sample=M,
+                         l_di_alpha_thresh=F["l_di_alpha_thresh"],
+                         surf_sparse_alpha_thresh=F["surf_sparse_alpha_thresh"], global_n_rays=Q_global)
+            O.render_fused(osc, o_np[idx[:2000]], d_np[idx[:2000]], synth.SYN_OPTS, gt_np[idx[:2000]], fused)
+            reps, tc = 0, time.perf_counter()
+            while True:
+                O.render_fused(osc, o_np[idx], d_np[idx], synth.SYN_OPTS, gt_np[idx], fused)
+                reps += 1
+                if time.perf_counter() - tc > 10.0 or reps >= 50:
+                    break
+            tcpu = (time.perf_counter() - tc) / reps
+            cpu = dict(value=round(n_cpu / tcpu / 1e6, 4), unit="Mrays/s", cores=O.num_threads(), kind="port",
+                       sample=f"{n_cpu} rays strided over the same {args.width}x{args.width} view, fused fwd+bwd, "
+                              f"{reps} repetitions, OpenMP over rays")
+
+        out = {
+            "metric": "Mrays/s fwd+bwd, 800x800 on 256^3 SDF grid; achieved HBM GB/s vs peak",
+            "value": round(value, 3), "unit": "Mrays/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{R}^3 sparse SDF grid ({g.density_data.shape[0]} active voxels, union of 16 "
+                                   f"spheres), SH deg {int(round(B ** 0.5)) - 1} (basis_dim {B}), "
+                                   f"{args.width}x{args.width} pinhole view per GPU "
+                                   f"({'shuffled' if args.shuffle else 'image-order'} rays), "
+                                   "volume_render_surf_trav_fused fwd+bwd, surface_cuda_syn.yaml options",
+                       "rays_per_step_per_gpu": Q, "active_voxels": int(g.density_data.shape[0]),
+                       "avg_per_ray": {"V_t": round(v_t / Q, 2), "V_a": round(v_a / Q, 2), "S": round(s_cnt / Q, 3)},
+                       "parallelism": f"ray-sharded dp{world}, dense RCCL all-reduce of grads" if world > 1 else "single GPU"},
+            "roofline": roofline, "cpu_baseline": cpu,
+        }
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

@@ -222,6 +222,14 @@ int asurf_volume_render_surface_fused(const asurf_grid* grid, const asurf_rays* 
 int asurf_test_cubic_root_grad(const double* fs, const int32_t* st_ids, float* grad_fs,
                                float* st, int64_t n, int32_t use_vieta, void* stream);
 
+/* Measurement hooks (no reference counterpart; used by bench.py).  When enabled, the
+ * surf_trav launchers bracket each kernel of a call with hipEvents on the call's stream.
+ * asurf_profile_read() waits for the last call and returns, in milliseconds,
+ * ms[0] = occupancy-pyramid pass, ms[1] = forward kernel, ms[2] = backward kernel
+ * (0 for a kernel the call did not launch).  Not graph-capturable while enabled. */
+int asurf_profile_enable(int on);
+int asurf_profile_read(float* ms, int n);
+
 #ifdef __cplusplus
 }
 #endif
