@@ -10,6 +10,7 @@
 
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 
 #include "asurf_kernels.h"
@@ -148,6 +149,8 @@ KOpt make_kopt(const asurf_render_options* o) {
     k.only_outward_intersect = o->only_outward_intersect;
     k.truncated_vol_render = o->truncated_vol_render;
     k.trunc_vol_weight_min = o->trunc_vol_weight_min;
+    const char* dbg = getenv("ASURF_DEBUG");
+    k.debug = dbg ? atoi(dbg) : 0;
     return k;
 }
 
@@ -228,17 +231,23 @@ int run_forward(const Launch& L, const asurf_rays* rays, float* rgb_out, int M, 
     float* ct = reinterpret_cast<float*>(L.ws + L.ML.off_cache_t);
     int* cn = reinterpret_cast<int*>(L.ws + L.ML.off_cache_n);
     auto* cnt = reinterpret_cast<unsigned long long*>(counters);
-#define ASURF_FWD(CACHE, COUNT)                                                                  \
-    hipLaunchKernelGGL((k_forward<B, CACHE, COUNT>), L.ray_grid, dim3(kBlock), L.dyn_lds, L.stream, \
-                       L.g, L.o, rays->origins, rays->dirs, (long long)rays->n_rays, rgb_out, M, \
-                       ca, cw, ct, cn, L.coarse_in_lds, cnt)
+#define ASURF_FWD(CACHE, COUNT, CLDS)                                                            \
+    hipLaunchKernelGGL((k_forward<B, CACHE, COUNT, CLDS>), L.ray_grid, dim3(kBlock), L.dyn_lds,  \
+                       L.stream, L.g, L.o, rays->origins, rays->dirs, (long long)rays->n_rays,   \
+                       rgb_out, M, ca, cw, ct, cn, cnt)
+#define ASURF_FWD2(CACHE, COUNT)             \
+    do {                                     \
+        if (L.coarse_in_lds) ASURF_FWD(CACHE, COUNT, true); \
+        else ASURF_FWD(CACHE, COUNT, false); \
+    } while (0)
     if (cache) {
-        if (counters) ASURF_FWD(true, true);
-        else ASURF_FWD(true, false);
+        if (counters) ASURF_FWD2(true, true);
+        else ASURF_FWD2(true, false);
     } else {
-        if (counters) ASURF_FWD(false, true);
-        else ASURF_FWD(false, false);
+        if (counters) ASURF_FWD2(false, true);
+        else ASURF_FWD2(false, false);
     }
+#undef ASURF_FWD2
 #undef ASURF_FWD
     prof_mark(2, L.stream);
     g_fwd_in_last_call = true;
@@ -252,14 +261,18 @@ int run_backward(const Launch& L, const asurf_rays* rays, const KLoss& loss, con
     const float* cw = reinterpret_cast<const float*>(L.ws + L.ML.off_cache_w);
     const float* ct = reinterpret_cast<const float*>(L.ws + L.ML.off_cache_t);
     const int* cn = reinterpret_cast<const int*>(L.ws + L.ML.off_cache_n);
-    if (fused)
-        hipLaunchKernelGGL((k_backward<B, true>), L.ray_grid, dim3(kBlock), L.dyn_lds, L.stream, L.g,
-                           L.o, loss, G, rays->origins, rays->dirs, (long long)rays->n_rays, grad_in,
-                           color_cache, M, ca, cw, ct, cn, L.coarse_in_lds);
-    else
-        hipLaunchKernelGGL((k_backward<B, false>), L.ray_grid, dim3(kBlock), L.dyn_lds, L.stream, L.g,
-                           L.o, loss, G, rays->origins, rays->dirs, (long long)rays->n_rays, grad_in,
-                           color_cache, M, ca, cw, ct, cn, L.coarse_in_lds);
+#define ASURF_BWD(FUSED, CLDS)                                                                    \
+    hipLaunchKernelGGL((k_backward<B, FUSED, CLDS>), L.ray_grid, dim3(kBlock), L.dyn_lds, L.stream, \
+                       L.g, L.o, loss, G, rays->origins, rays->dirs, (long long)rays->n_rays,     \
+                       grad_in, color_cache, M, ca, cw, ct, cn)
+    if (fused) {
+        if (L.coarse_in_lds) ASURF_BWD(true, true);
+        else ASURF_BWD(true, false);
+    } else {
+        if (L.coarse_in_lds) ASURF_BWD(false, true);
+        else ASURF_BWD(false, false);
+    }
+#undef ASURF_BWD
     prof_mark(3, L.stream);
     return launch_error("k_backward");
 }

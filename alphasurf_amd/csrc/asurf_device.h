@@ -58,6 +58,7 @@ struct KOpt {
     int limited_fake_sample, no_surf_grad_from_sh, alpha_activation_type, fake_sample_l_dist,
         fake_sample_normalize_surf, only_outward_intersect, truncated_vol_render;
     float trunc_vol_weight_min;
+    int debug;  // ASURF_DEBUG env var; 0 in production (bit 0: traversal only, results invalid)
 };
 
 struct KGrads {

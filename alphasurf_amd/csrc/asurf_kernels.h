@@ -100,17 +100,30 @@ k_build_masks(KGrid g, float sigma_thresh, int need_surf, unsigned long long* fi
 
 // ------------------------------------------------------------------------------------
 // Per-lane voxel walk (the DDA of surf_trav.cu:67-79, 86-197)
+//
+// The reference recomputes all three far-plane crossing times of the current voxel every
+// step.  The two on the axes that were not stepped are the same expression on the same
+// operands as in the previous step, so only the stepped axis is re-divided here; every
+// value, comparison and tie-break is bit-identical to the reference's.
 // ------------------------------------------------------------------------------------
 struct Walk {
-    int nx, ny, nz;  // next voxel
-    int vx, vy, vz;  // current voxel
+    int nx, ny, nz;      // next voxel
+    int vx, vy, vz;      // current voxel
+    float tf0, tf1, tf2; // far-plane crossing times of the NEXT voxel
+    int sx, sy, sz;      // step direction per axis (+1 / -1)
     float t, t_far;
     // register cache of the occupancy pyramid
-    int cur_brick;
+    int cur_key;         // packed brick coordinates
+    int cur_brick;       // linear brick index
     unsigned cur_flag;
     int cur_lx;
     unsigned long long cur_word;
 };
+
+__device__ __forceinline__ float plane_time(int n, int s, float o, float d) {
+    // ((float)far_plane - origin) / dir with far_plane = n + (dir > 0)
+    return ((float)(n + ((s + 1) >> 1)) - o) / d;
+}
 
 __device__ __forceinline__ void walk_init(const KGrid& g, const Ray& r, Walk& w) {
     w.t = r.tmin;
@@ -123,59 +136,72 @@ __device__ __forceinline__ void walk_init(const KGrid& g, const Ray& r, Walk& w)
     w.nx = v[0];
     w.ny = v[1];
     w.nz = v[2];
+    w.sx = (r.d[0] > 0.f) ? 1 : -1;
+    w.sy = (r.d[1] > 0.f) ? 1 : -1;
+    w.sz = (r.d[2] > 0.f) ? 1 : -1;
+    w.tf0 = plane_time(w.nx, w.sx, r.o[0], r.d[0]);
+    w.tf1 = plane_time(w.ny, w.sy, r.o[1], r.d[1]);
+    w.tf2 = plane_time(w.nz, w.sz, r.o[2], r.d[2]);
     w.vx = w.vy = w.vz = 0;
     w.t_far = 0.f;
-    w.cur_brick = -1;
+    w.cur_key = -1;
+    w.cur_brick = 0;
     w.cur_flag = 0;
     w.cur_lx = -1;
     w.cur_word = 0;
 }
 
-// one DDA step: enters (nx,ny,nz), computes its far crossing, picks the next voxel
+// one DDA step: enters (nx,ny,nz), takes its far crossing, picks the next voxel
 __device__ __forceinline__ void walk_step(const KGrid& g, const Ray& r, Walk& w) {
     w.vx = w.nx;
     w.vy = w.ny;
     w.vz = w.nz;
-    const float tf0 = ((float)(r.d[0] > 0.f ? w.vx + 1 : w.vx) - r.o[0]) / r.d[0];
-    const float tf1 = ((float)(r.d[1] > 0.f ? w.vy + 1 : w.vy) - r.o[1]) / r.d[1];
-    const float tf2 = ((float)(r.d[2] > 0.f ? w.vz + 1 : w.vz) - r.o[2]) / r.d[2];
-    const float t_far = fminf(fminf(tf0, tf1), tf2);
+    const float t_far = fminf(fminf(w.tf0, w.tf1), w.tf2);
     w.t_far = t_far;
-    w.t = t_far;
-    if (t_far == tf0) {
-        w.nx += (r.d[0] > 0.f) ? 1 : -1;
-        if (w.nx < 0 || w.nx >= g.size[0] - 1) w.t = r.tmax + 1.f;
-    } else if (t_far == tf1) {
-        w.ny += (r.d[1] > 0.f) ? 1 : -1;
-        if (w.ny < 0 || w.ny >= g.size[1] - 1) w.t = r.tmax + 1.f;
+    const bool a0 = (t_far == w.tf0);
+    const bool a1 = !a0 && (t_far == w.tf1);
+    const int n_new = a0 ? w.nx + w.sx : (a1 ? w.ny + w.sy : w.nz + w.sz);
+    const int lim = a0 ? g.size[0] - 1 : (a1 ? g.size[1] - 1 : g.size[2] - 1);
+    const int s = a0 ? w.sx : (a1 ? w.sy : w.sz);
+    const float o = a0 ? r.o[0] : (a1 ? r.o[1] : r.o[2]);
+    const float d = a0 ? r.d[0] : (a1 ? r.d[1] : r.d[2]);
+    const bool leaves = (n_new < 0) || (n_new >= lim);
+    w.t = leaves ? r.tmax + 1.f : t_far;
+    const float q = plane_time(n_new, s, o, d);
+    if (a0) {
+        w.nx = n_new;
+        w.tf0 = q;
+    } else if (a1) {
+        w.ny = n_new;
+        w.tf1 = q;
     } else {
-        w.nz += (r.d[2] > 0.f) ? 1 : -1;
-        if (w.nz < 0 || w.nz >= g.size[2] - 1) w.t = r.tmax + 1.f;
+        w.nz = n_new;
+        w.tf2 = q;
     }
 }
 
-__device__ __forceinline__ float walk_t_close(const Ray& r, const Walk& w) {
-    const float tc0 = ((float)(r.d[0] > 0.f ? w.vx : w.vx + 1) - r.o[0]) / r.d[0];
-    const float tc1 = ((float)(r.d[1] > 0.f ? w.vy : w.vy + 1) - r.o[1]) / r.d[1];
-    const float tc2 = ((float)(r.d[2] > 0.f ? w.vz : w.vz + 1) - r.o[2]) / r.d[2];
-    return fmaxf(fmaxf(fmaxf(tc0, tc1), tc2), 0.f);
-}
-
-// work bit of the current voxel; brick flag and the 64-voxel slab word are kept in registers
-__device__ __forceinline__ bool walk_test(const KGrid& g, const unsigned int* coarse, Walk& w) {
-    const int bx = w.vx >> 3, by = w.vy >> 3, bz = w.vz >> 3;
-    const int bxy = bx * g.nb[1] + by;
-    const int brick = bxy * g.nb[2] + bz;
-    if (brick != w.cur_brick) {
-        w.cur_brick = brick;
-        w.cur_flag = (coarse[bxy * g.nwz + (bz >> 5)] >> (bz & 31)) & 1u;
+// work bit of the current voxel; brick flag and the 64-voxel slab word are kept in registers.
+// LDS: the per-brick flags were staged in `lds_coarse` (address space resolved at compile time).
+template <bool LDS>
+__device__ __forceinline__ bool walk_test(const KGrid& g, const unsigned int* lds_coarse, Walk& w) {
+    const int key = ((w.vx >> 3) << 20) | ((w.vy >> 3) << 10) | (w.vz >> 3);
+    if (key != w.cur_key) {
+        w.cur_key = key;
+        const int bz = w.vz >> 3;
+        const int bxy = (w.vx >> 3) * g.nb[1] + (w.vy >> 3);
+        w.cur_brick = bxy * g.nb[2] + bz;
+        const int wi = bxy * g.nwz + (bz >> 5);
+        unsigned word;
+        if constexpr (LDS) word = lds_coarse[wi];
+        else word = g.coarse[wi];
+        w.cur_flag = (word >> (bz & 31)) & 1u;
         w.cur_lx = -1;
     }
     if (!w.cur_flag) return false;
     const int lx = w.vx & 7;
     if (lx != w.cur_lx) {
         w.cur_lx = lx;
-        w.cur_word = g.fine[(size_t)brick * 8 + lx];
+        w.cur_word = g.fine[(size_t)w.cur_brick * 8 + lx];
     }
     return (w.cur_word >> (((w.vy & 7) << 3) | (w.vz & 7))) & 1ull;
 }
@@ -198,17 +224,38 @@ __device__ __forceinline__ bool links_present(const KGrid& g, const Walk& w) {
 // Voxel geometry for a lane that reached a work voxel (surf_trav.cu:212-260)
 // ------------------------------------------------------------------------------------
 struct Vox {
+    int vx, vy, vz;
     int lk[8];
     float dens[8];
     float surf[8];
     double fs[4];
     float new_origin[3];  // o + t_close d  (float, as computed by the reference's FFMA)
     float smin, smax;
-    float t_close;
+    float t_close, t_far;
 };
 
-__device__ __forceinline__ void load_voxel(const KGrid& g, const Ray& r, const Walk& w, Vox& v) {
-    v.t_close = walk_t_close(r, w);
+// Work voxels found by the walk are parked in a small per-lane FIFO (LDS) so that the lanes
+// of a wave do not have to rendezvous at every one of them: x,y,z packed 10 bits each.
+constexpr int kQueueDepth = 8;
+__device__ __forceinline__ int pack_voxel(int x, int y, int z) { return (x << 20) | (y << 10) | z; }
+
+// Entry/exit times are recomputed from the voxel coordinates with the DDA's own expressions
+// (surf_trav.cu:162-184), so they are bit-identical to what the walk saw.
+__device__ __forceinline__ void load_voxel(const KGrid& g, const Ray& r, int packed, Vox& v) {
+    v.vx = packed >> 20;
+    v.vy = (packed >> 10) & 1023;
+    v.vz = packed & 1023;
+    {
+        const float tc0 = ((float)(r.d[0] > 0.f ? v.vx : v.vx + 1) - r.o[0]) / r.d[0];
+        const float tc1 = ((float)(r.d[1] > 0.f ? v.vy : v.vy + 1) - r.o[1]) / r.d[1];
+        const float tc2 = ((float)(r.d[2] > 0.f ? v.vz : v.vz + 1) - r.o[2]) / r.d[2];
+        v.t_close = fmaxf(fmaxf(fmaxf(tc0, tc1), tc2), 0.f);
+        const float tf0 = ((float)(r.d[0] > 0.f ? v.vx + 1 : v.vx) - r.o[0]) / r.d[0];
+        const float tf1 = ((float)(r.d[1] > 0.f ? v.vy + 1 : v.vy) - r.o[1]) / r.d[1];
+        const float tf2 = ((float)(r.d[2] > 0.f ? v.vz + 1 : v.vz) - r.o[2]) / r.d[2];
+        v.t_far = fminf(fminf(tf0, tf1), tf2);
+    }
+    struct { int vx, vy, vz; } w = {v.vx, v.vy, v.vz};
     const int32_t* p = g.links + ((size_t)w.vx * g.offx + (size_t)w.vy * g.offy + w.vz);
     v.lk[0] = p[0];
     v.lk[1] = p[1];
@@ -241,9 +288,8 @@ __device__ __forceinline__ void load_voxel(const KGrid& g, const Ray& r, const W
 }
 
 // sample position of root st inside the voxel; false when outside [0,1]^3 (surf_trav.cu:322-340)
-__device__ __forceinline__ bool root_position(const Ray& r, const Walk& w, const Vox& v, double st,
-                                              float* pos) {
-    const int vv[3] = {w.vx, w.vy, w.vz};
+__device__ __forceinline__ bool root_position(const Ray& r, const Vox& v, double st, float* pos) {
+    const int vv[3] = {v.vx, v.vy, v.vz};
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
         pos[k] = fmaf((float)st, r.d[k], v.new_origin[k]);
@@ -253,9 +299,9 @@ __device__ __forceinline__ bool root_position(const Ray& r, const Walk& w, const
 }
 
 // fake-sample geometry (surf_trav.cu:437-490)
-__device__ __forceinline__ void fake_position(const Ray& r, const Walk& w, const Vox& v, float* pos) {
-    const float tm = (w.t_far + v.t_close) / 2.f;
-    const int vv[3] = {w.vx, w.vy, w.vz};
+__device__ __forceinline__ void fake_position(const Ray& r, const Vox& v, float* pos) {
+    const float tm = (v.t_far + v.t_close) / 2.f;
+    const int vv[3] = {v.vx, v.vy, v.vz};
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
         pos[k] = fmaf(tm, r.d[k], r.o[k]);
@@ -443,22 +489,20 @@ __device__ __forceinline__ void scatter8(float* out, uint8_t* mask, const int* l
 // Sample cache layout: entry i of ray q at [i * Q + q] (lane-coalesced); cache_n[q] entries
 // are valid, the rest are implicit zeros.
 // ------------------------------------------------------------------------------------
-template <int B, bool CACHE, bool COUNT>
+template <int B, bool CACHE, bool COUNT, bool CLDS>
 __global__ void __launch_bounds__(kBlock)
 k_forward(KGrid g, KOpt o, const float* __restrict__ origins, const float* __restrict__ dirs,
           long long Q, float* __restrict__ rgb_out, int M, float* __restrict__ cache_a,
           float* __restrict__ cache_w, float* __restrict__ cache_t, int* __restrict__ cache_n,
-          int coarse_in_lds, unsigned long long* counters) {
+          unsigned long long* counters) {
     extern __shared__ unsigned int s_coarse[];
     __shared__ float s_sph[kBlock * kSphPad];
     __shared__ LaneRec s_rec[kBlock];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    const unsigned int* coarse = g.coarse;
-    if (coarse_in_lds) {
+    if constexpr (CLDS) {
         for (int i = tid; i < g.coarse_words; i += kBlock) s_coarse[i] = g.coarse[i];
         __syncthreads();
-        coarse = s_coarse;
     }
     const float* sph_wave = s_sph + (tid & ~63) * kSphPad;
     const LaneRec* rec_wave = s_rec + (tid & ~63);
@@ -489,21 +533,34 @@ k_forward(KGrid g, KOpt o, const float* __restrict__ origins, const float* __res
     Walk w;
     if (active) walk_init(g, r, w);
 
-    while (__any(active)) {
-        // (A) advance to the next work voxel
-        bool found = false;
-        while (active && !found) {
+    // Counting mode keeps a queue of one so that a ray stopped by stop_thresh is not walked
+    // (and counted) past the voxel the reference would stop at.
+    constexpr int QD = COUNT ? 1 : kQueueDepth;
+    __shared__ int s_queue[QD * kBlock];
+    int qn = 0;
+    while (true) {
+        // (A) walk; park work voxels in this lane's FIFO until it is full or the ray ends
+        while (active && qn < QD) {
             walk_step(g, r, w);
-            found = walk_test(g, coarse, w);
+            const bool hit = walk_test<CLDS>(g, s_coarse, w);
             if (COUNT) {
                 ++n_trav;
                 n_act += live_test(g, w) ? 1 : 0;
             }
             active = (w.t <= r.tmax);
+            if (hit) {
+                s_queue[qn * kBlock + tid] = pack_voxel(w.vx, w.vy, w.vz);
+                ++qn;
+            }
         }
+        if (o.debug & 1) qn = 0;  // measurement aid: traversal only
+        if (!__any(qn > 0)) break;
+      // (B,C) drain the FIFOs in order, slot by slot
+      for (int qi = 0; __any(qi < qn); ++qi) {
+        const bool found = qi < qn;
         // (B) geometry
         Vox v;
-        if (found) load_voxel(g, r, w, v);
+        if (found) load_voxel(g, r, s_queue[qi * kBlock + tid], v);
         bool vox_has_sample = false, vox_has_surf = false;
         // (C) real intersections, one level set at a time
         for (int li = 0; li < g.level_set_num; ++li) {
@@ -519,7 +576,7 @@ k_forward(KGrid g, KOpt o, const float* __restrict__ origins, const float* __res
             for (int j = 0; j < 3; ++j) {
                 bool cand = lv_ok && (st[j] > 0);
                 float pos[3] = {0.f, 0.f, 0.f};
-                if (cand) cand = root_position(r, w, v, st[j], pos);
+                if (cand) cand = root_position(r, v, st[j], pos);
                 if (cand) vox_has_sample = true;
                 if (cand && o.only_outward_intersect) {  // :350-367
                     float sg[3];
@@ -570,11 +627,11 @@ k_forward(KGrid g, KOpt o, const float* __restrict__ origins, const float* __res
         {
             bool fk = found && o.surf_fake_sample && !vox_has_sample &&
                       (!o.limited_fake_sample || vox_has_surf) &&
-                      ((w.t_far - v.t_close) > o.surf_fake_sample_min_vox_len);
+                      ((v.t_far - v.t_close) > o.surf_fake_sample_min_vox_len);
             float pos[3] = {0.f, 0.f, 0.f};
             float alpha = 0.f;
             if (fk) {
-                fake_position(r, w, v, pos);
+                fake_position(r, v, pos);
                 alpha = trilerp8(v.dens, pos);
                 fk = alpha > o.sigma_thresh;
             }
@@ -606,7 +663,7 @@ k_forward(KGrid g, KOpt o, const float* __restrict__ origins, const float* __res
                         const size_t ci = (size_t)sample_i * Q + q;
                         cache_a[ci] = alpha;
                         cache_w[ci] = weight;
-                        cache_t[ci] = (w.t_far + v.t_close) / 2.f;
+                        cache_t[ci] = (v.t_far + v.t_close) / 2.f;
                         sample_i += 1;
                     }
                 }
@@ -615,7 +672,10 @@ k_forward(KGrid g, KOpt o, const float* __restrict__ origins, const float* __res
         if (found && expf(log_transmit) < o.stop_thresh) {  // :544-547
             log_transmit = -1e3f;
             active = false;
+            qn = 0;  // voxels parked beyond the stopping point are dropped
         }
+      }
+        qn = 0;
     }
     if (valid) {
         const float bg = expf(log_transmit) * o.background_brightness;  // :553-555 (== bg for a miss)
@@ -641,22 +701,20 @@ k_forward(KGrid g, KOpt o, const float* __restrict__ origins, const float* __res
 //   FUSED: grad_in is rgb_gt and the image-loss gradient is formed here (:3306-3316);
 //          otherwise grad_in is dL/drgb.
 // ------------------------------------------------------------------------------------
-template <int B, bool FUSED>
+template <int B, bool FUSED, bool CLDS>
 __global__ void __launch_bounds__(kBlock)
 k_backward(KGrid g, KOpt o, KLoss L, KGrads G, const float* __restrict__ origins,
            const float* __restrict__ dirs, long long Q, const float* __restrict__ grad_in,
            const float* __restrict__ color_cache, int M, const float* __restrict__ cache_a,
            const float* __restrict__ cache_w, const float* __restrict__ cache_t,
-           const int* __restrict__ cache_n, int coarse_in_lds) {
+           const int* __restrict__ cache_n) {
     extern __shared__ unsigned int s_coarse[];
     __shared__ float s_sph[kBlock * kSphPad];
     __shared__ LaneRec s_rec[kBlock];
     const int tid = threadIdx.x;
-    const unsigned int* coarse = g.coarse;
-    if (coarse_in_lds) {
+    if constexpr (CLDS) {
         for (int i = tid; i < g.coarse_words; i += kBlock) s_coarse[i] = g.coarse[i];
         __syncthreads();
-        coarse = s_coarse;
     }
     const float* sph_wave = s_sph + (tid & ~63) * kSphPad;
     const LaneRec* rec_wave = s_rec + (tid & ~63);
@@ -779,20 +837,30 @@ k_backward(KGrid g, KOpt o, KLoss L, KGrads G, const float* __restrict__ origins
         return (float)((double)curr + add);
     };
 
-    while (__any(active)) {
-        bool found = false;
-        while (active && !found) {
+    constexpr int QD = kQueueDepth;
+    __shared__ int s_queue[QD * kBlock];
+    int qn = 0;
+    while (true) {
+        while (active && qn < QD) {
             walk_step(g, r, w);
-            found = walk_test(g, coarse, w);
+            const bool hit = walk_test<CLDS>(g, s_coarse, w);
             active = (w.t <= r.tmax);
             // backward-only loop quirk: `t += step_size` on voxels with a missing corner
             // (:1935-1936) can end the loop one voxel early near the exit face.
-            if (active && !found && (w.t + o.step_size > r.tmax)) {
+            if (active && !hit && (w.t + o.step_size > r.tmax)) {
                 if (!links_present(g, w)) active = false;
             }
+            if (hit) {
+                s_queue[qn * kBlock + tid] = pack_voxel(w.vx, w.vy, w.vz);
+                ++qn;
+            }
         }
+        if (o.debug & 1) qn = 0;  // measurement aid: traversal only
+        if (!__any(qn > 0)) break;
+      for (int qi = 0; __any(qi < qn); ++qi) {
+        const bool found = qi < qn;
         Vox v;
-        if (found) load_voxel(g, r, w, v);
+        if (found) load_voxel(g, r, s_queue[qi * kBlock + tid], v);
         bool vox_has_sample = false, vox_has_surf = false;
 
         for (int li = 0; li < g.level_set_num; ++li) {
@@ -814,7 +882,7 @@ k_backward(KGrid g, KOpt o, KLoss L, KGrads G, const float* __restrict__ origins
             for (int st_id = 0; st_id < 3; ++st_id) {
                 bool cand = lv_ok && (st[st_id] > 0);
                 float pos[3] = {0.f, 0.f, 0.f};
-                if (cand) cand = root_position(r, w, v, st[st_id], pos);
+                if (cand) cand = root_position(r, v, st[st_id], pos);
                 if (cand) vox_has_sample = true;
                 if (cand && o.only_outward_intersect) {
                     float sg[3];
@@ -910,9 +978,9 @@ k_backward(KGrid g, KOpt o, KLoss L, KGrads G, const float* __restrict__ origins
                 float grad_fs[4] = {grad_st, grad_st, grad_st, grad_st};
                 cubic_root_grad_vieta(root_type, st_id, fs, grad_fs);
                 float gsurf[8];
-                const float nof[3] = {(float)((double)v.new_origin[0] - (double)w.vx),
-                                      (float)((double)v.new_origin[1] - (double)w.vy),
-                                      (float)((double)v.new_origin[2] - (double)w.vz)};
+                const float nof[3] = {(float)((double)v.new_origin[0] - (double)v.vx),
+                                      (float)((double)v.new_origin[1] - (double)v.vy),
+                                      (float)((double)v.new_origin[2] - (double)v.vz)};
                 surface_cubic_grad(nof, r.d, grad_fs, gsurf);
                 scatter8(G.grad_surface, G.mask, v.lk, gsurf);
                 if (alpha < L.surf_sparse_alpha_thresh) {  // :2436-2445
@@ -928,11 +996,11 @@ k_backward(KGrid g, KOpt o, KLoss L, KGrads G, const float* __restrict__ origins
         {
             bool fk = found && o.surf_fake_sample && !vox_has_sample &&
                       (!o.limited_fake_sample || vox_has_surf) &&
-                      ((w.t_far - v.t_close) > o.surf_fake_sample_min_vox_len);
+                      ((v.t_far - v.t_close) > o.surf_fake_sample_min_vox_len);
             float pos[3] = {0.f, 0.f, 0.f};
             float raw_alpha = 0.f;
             if (fk) {
-                fake_position(r, w, v, pos);
+                fake_position(r, v, pos);
                 raw_alpha = trilerp8(v.dens, pos);
                 fk = raw_alpha > o.sigma_thresh;
             }
@@ -1027,7 +1095,12 @@ k_backward(KGrid g, KOpt o, KLoss L, KGrads G, const float* __restrict__ origins
                 }
             }
         }
-        if (found && expf(log_transmit) < o.stop_thresh) active = false;  // :2893-2895
+        if (found && expf(log_transmit) < o.stop_thresh) {  // :2893-2895
+            active = false;
+            qn = 0;
+        }
+      }
+        qn = 0;
     }
 }
 
