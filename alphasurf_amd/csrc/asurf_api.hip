@@ -36,8 +36,13 @@ struct MaskLayout {
     size_t coarse_words;
     size_t off_fine_work, off_fine_live, off_coarse_work, off_coarse_live;
     size_t off_cache_a, off_cache_w, off_cache_t, off_cache_n;
+    size_t off_rec_v, off_rec_m, off_rec_n;
     size_t total;
 };
+
+// per-ray capacity of the sample records the fused forward leaves for the replaying
+// backward; rays with more samples fall back to the walking backward kernel
+constexpr int kRecDepth = 16;
 
 size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
@@ -64,6 +69,15 @@ MaskLayout layout_for(const int32_t size[3], int64_t n_rays, int32_t M) {
     L.off_cache_t = off;
     off = align_up(off + plane, 256);
     L.off_cache_n = off;
+    off = align_up(off + (size_t)(n_rays > 0 ? n_rays : 0) * 4, 256);
+    // sample records exist only for fused calls (M > 0 is not required for them, but a
+    // forward-only / backward-only call never passes through the fused path)
+    const size_t rplane = (size_t)kRecDepth * (size_t)(n_rays > 0 ? n_rays : 0) * 4;
+    L.off_rec_v = off;
+    off = align_up(off + rplane, 256);
+    L.off_rec_m = off;
+    off = align_up(off + rplane, 256);
+    L.off_rec_n = off;
     off = align_up(off + (size_t)(n_rays > 0 ? n_rays : 0) * 4, 256);
     L.total = off;
     return L;
@@ -225,16 +239,19 @@ int prepare(const asurf_grid* grid, const asurf_rays* rays, const asurf_render_o
 
 template <int B>
 int run_forward(const Launch& L, const asurf_rays* rays, float* rgb_out, int M, bool cache,
-                uint64_t* counters) {
+                bool record, uint64_t* counters) {
     float* ca = reinterpret_cast<float*>(L.ws + L.ML.off_cache_a);
     float* cw = reinterpret_cast<float*>(L.ws + L.ML.off_cache_w);
     float* ct = reinterpret_cast<float*>(L.ws + L.ML.off_cache_t);
     int* cn = reinterpret_cast<int*>(L.ws + L.ML.off_cache_n);
+    int* rv = record ? reinterpret_cast<int*>(L.ws + L.ML.off_rec_v) : nullptr;
+    int* rm = record ? reinterpret_cast<int*>(L.ws + L.ML.off_rec_m) : nullptr;
+    int* rn = record ? reinterpret_cast<int*>(L.ws + L.ML.off_rec_n) : nullptr;
     auto* cnt = reinterpret_cast<unsigned long long*>(counters);
 #define ASURF_FWD(CACHE, COUNT, CLDS)                                                            \
     hipLaunchKernelGGL((k_forward<B, CACHE, COUNT, CLDS>), L.ray_grid, dim3(kBlock), L.dyn_lds,  \
                        L.stream, L.g, L.o, rays->origins, rays->dirs, (long long)rays->n_rays,   \
-                       rgb_out, M, ca, cw, ct, cn, cnt)
+                       rgb_out, M, ca, cw, ct, cn, rv, rm, rn, kRecDepth, cnt)
 #define ASURF_FWD2(CACHE, COUNT)             \
     do {                                     \
         if (L.coarse_in_lds) ASURF_FWD(CACHE, COUNT, true); \
@@ -254,26 +271,35 @@ int run_forward(const Launch& L, const asurf_rays* rays, float* rgb_out, int M, 
     return launch_error("k_forward");
 }
 
+// mode 0: walking backward over all rays; 1: record replay (fused only);
+// 2: walking backward restricted to the rays whose record overflowed (fused only)
 template <int B>
 int run_backward(const Launch& L, const asurf_rays* rays, const KLoss& loss, const KGrads& G,
-                 const float* grad_in, const float* color_cache, int M, bool fused) {
+                 const float* grad_in, const float* color_cache, int M, bool fused, int mode) {
     const float* ca = reinterpret_cast<const float*>(L.ws + L.ML.off_cache_a);
     const float* cw = reinterpret_cast<const float*>(L.ws + L.ML.off_cache_w);
     const float* ct = reinterpret_cast<const float*>(L.ws + L.ML.off_cache_t);
     const int* cn = reinterpret_cast<const int*>(L.ws + L.ML.off_cache_n);
-#define ASURF_BWD(FUSED, CLDS)                                                                    \
-    hipLaunchKernelGGL((k_backward<B, FUSED, CLDS>), L.ray_grid, dim3(kBlock), L.dyn_lds, L.stream, \
-                       L.g, L.o, loss, G, rays->origins, rays->dirs, (long long)rays->n_rays,     \
-                       grad_in, color_cache, M, ca, cw, ct, cn)
-    if (fused) {
-        if (L.coarse_in_lds) ASURF_BWD(true, true);
-        else ASURF_BWD(true, false);
+    const int* rv = reinterpret_cast<const int*>(L.ws + L.ML.off_rec_v);
+    const int* rm = reinterpret_cast<const int*>(L.ws + L.ML.off_rec_m);
+    const int* rn = reinterpret_cast<const int*>(L.ws + L.ML.off_rec_n);
+    const int* filter = (mode == 2) ? rn : nullptr;
+#define ASURF_BWD(FUSED, CLDS, REC)                                                               \
+    hipLaunchKernelGGL((k_backward<B, FUSED, CLDS, REC>), L.ray_grid, dim3(kBlock),               \
+                       (REC) ? 0 : L.dyn_lds, L.stream, L.g, L.o, loss, G, rays->origins,          \
+                       rays->dirs, (long long)rays->n_rays, grad_in, color_cache, M, ca, cw, ct,  \
+                       cn, rv, rm, rn, filter)
+    if (mode == 1) {
+        ASURF_BWD(true, false, true);
+    } else if (fused) {
+        if (L.coarse_in_lds) ASURF_BWD(true, true, false);
+        else ASURF_BWD(true, false, false);
     } else {
-        if (L.coarse_in_lds) ASURF_BWD(false, true);
-        else ASURF_BWD(false, false);
+        if (L.coarse_in_lds) ASURF_BWD(false, true, false);
+        else ASURF_BWD(false, false, false);
     }
 #undef ASURF_BWD
-    prof_mark(3, L.stream);
+    if (mode != 1) prof_mark(3, L.stream);
     return launch_error("k_backward");
 }
 
@@ -315,7 +341,7 @@ int asurf_volume_render_surf_trav(const asurf_grid* grid, const asurf_rays* rays
     if (rays->n_rays == 0) return 0;
     if (!rgb_out) return fail(ASURF_E_INVALID, "rgb_out is NULL");
     int rc = 0;
-    ASURF_DISPATCH_B(grid->basis_dim, run_forward<B_>(L, rays, rgb_out, 0, false, counters));
+    ASURF_DISPATCH_B(grid->basis_dim, run_forward<B_>(L, rays, rgb_out, 0, false, false, counters));
     return rc;
 }
 
@@ -334,7 +360,7 @@ int asurf_volume_render_surf_trav_backward(const asurf_grid* grid, const asurf_r
     memset(&loss, 0, sizeof(loss));  // all fused-loss lambdas are 0 here (surf_trav.cu:3752-3773)
     const KGrads G = make_grads(grads);
     int rc = 0;
-    ASURF_DISPATCH_B(grid->basis_dim, run_backward<B_>(L, rays, loss, G, grad_out, color_cache, 0, false));
+    ASURF_DISPATCH_B(grid->basis_dim, run_backward<B_>(L, rays, loss, G, grad_out, color_cache, 0, false, 0));
     return rc;
 }
 
@@ -376,9 +402,21 @@ int asurf_volume_render_surf_trav_fused(const asurf_grid* grid, const asurf_rays
     loss.norm_l1 = 1.f / (3 * (int)Qn);
     const KGrads G = make_grads(grads);
     int rc = 0;
-    ASURF_DISPATCH_B(grid->basis_dim, run_forward<B_>(L, rays, rgb_out, M, true, counters));
+    // Replay instead of re-walking when the backward provably visits the forward's samples:
+    // not with 0 < stop_thresh < 2e-8 (the two passes clamp log(1-alpha) differently,
+    // surf_trav.cu:397 vs :2099) and not with more level sets than the record encodes.
+    const char* norec = getenv("ASURF_NO_REPLAY");
+    const bool replay = !(norec && atoi(norec)) && grid->level_set_num <= 32 &&
+                        (opt->stop_thresh <= 0.f || opt->stop_thresh >= 2e-8f);
+    ASURF_DISPATCH_B(grid->basis_dim, run_forward<B_>(L, rays, rgb_out, M, true, replay, counters));
     if (rc) return rc;
-    ASURF_DISPATCH_B(grid->basis_dim, run_backward<B_>(L, rays, loss, G, fused->rgb_gt, rgb_out, M, true));
+    if (replay) {
+        ASURF_DISPATCH_B(grid->basis_dim, run_backward<B_>(L, rays, loss, G, fused->rgb_gt, rgb_out, M, true, 1));
+        if (rc) return rc;
+        ASURF_DISPATCH_B(grid->basis_dim, run_backward<B_>(L, rays, loss, G, fused->rgb_gt, rgb_out, M, true, 2));
+    } else {
+        ASURF_DISPATCH_B(grid->basis_dim, run_backward<B_>(L, rays, loss, G, fused->rgb_gt, rgb_out, M, true, 0));
+    }
     return rc;
 }
 

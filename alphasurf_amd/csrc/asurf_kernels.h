@@ -494,12 +494,20 @@ __global__ void __launch_bounds__(kBlock)
 k_forward(KGrid g, KOpt o, const float* __restrict__ origins, const float* __restrict__ dirs,
           long long Q, float* __restrict__ rgb_out, int M, float* __restrict__ cache_a,
           float* __restrict__ cache_w, float* __restrict__ cache_t, int* __restrict__ cache_n,
+          int* __restrict__ rec_v, int* __restrict__ rec_m, int* __restrict__ rec_n, int R,
           unsigned long long* counters) {
     extern __shared__ unsigned int s_coarse[];
     __shared__ float s_sph[kBlock * kSphPad];
     __shared__ LaneRec s_rec[kBlock];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
+    // Sample records for the replaying backward kernel (k_backward<REC>): one entry per
+    // composited sample, in order.  rec_cut = ordinal of the first work voxel the
+    // reference's BACKWARD walk would not reach (its `t += step_size` quirk, :1935-1936).
+    const bool do_rec = CACHE && (rec_v != nullptr);
+    int rec_cnt = 0;
+    bool rec_over = false;
+    int n_pushed = 0, n_drained = 0, rec_cut = 0x7fffffff;
     if constexpr (CLDS) {
         for (int i = tid; i < g.coarse_words; i += kBlock) s_coarse[i] = g.coarse[i];
         __syncthreads();
@@ -551,6 +559,9 @@ k_forward(KGrid g, KOpt o, const float* __restrict__ origins, const float* __res
             if (hit) {
                 s_queue[qn * kBlock + tid] = pack_voxel(w.vx, w.vy, w.vz);
                 ++qn;
+                ++n_pushed;
+            } else if (do_rec && active && (w.t + o.step_size > r.tmax) && rec_cut == 0x7fffffff) {
+                if (!links_present(g, w)) rec_cut = n_pushed;
             }
         }
         if (o.debug & 1) qn = 0;  // measurement aid: traversal only
@@ -558,6 +569,8 @@ k_forward(KGrid g, KOpt o, const float* __restrict__ origins, const float* __res
       // (B,C) drain the FIFOs in order, slot by slot
       for (int qi = 0; __any(qi < qn); ++qi) {
         const bool found = qi < qn;
+        const bool rec_ok = do_rec && found && (n_drained < rec_cut);
+        if (found) ++n_drained;
         // (B) geometry
         Vox v;
         if (found) load_voxel(g, r, s_queue[qi * kBlock + tid], v);
@@ -565,7 +578,7 @@ k_forward(KGrid g, KOpt o, const float* __restrict__ origins, const float* __res
         // (C) real intersections, one level set at a time
         for (int li = 0; li < g.level_set_num; ++li) {
             const float lvf = g.level_set[li];
-            const bool lv_ok = found && !(lvf < v.smin || lvf > v.smax);
+            const bool lv_ok = found && !(lvf < v.smin || lvf > v.smax) && !(o.debug & 2);
             if (!__any(lv_ok)) continue;
             double st[3] = {-1, -1, -1};
             if (lv_ok) {
@@ -574,7 +587,7 @@ k_forward(KGrid g, KOpt o, const float* __restrict__ origins, const float* __res
             }
 #pragma unroll
             for (int j = 0; j < 3; ++j) {
-                bool cand = lv_ok && (st[j] > 0);
+                bool cand = lv_ok && (st[j] > 0) && !(o.debug & 4);
                 float pos[3] = {0.f, 0.f, 0.f};
                 if (cand) cand = root_position(r, v, st[j], pos);
                 if (cand) vox_has_sample = true;
@@ -618,6 +631,15 @@ k_forward(KGrid g, KOpt o, const float* __restrict__ origins, const float* __res
                             cache_w[ci] = weight;
                             cache_t[ci] = (float)((double)v.t_close + st[j]);
                             sample_i += 1;
+                        }
+                        if (rec_ok) {
+                            if (rec_cnt < R) {
+                                rec_v[(size_t)rec_cnt * Q + q] = pack_voxel(v.vx, v.vy, v.vz);
+                                rec_m[(size_t)rec_cnt * Q + q] = ((intersect_i + 1) << 8) | (li << 3) | (j << 1);
+                                ++rec_cnt;
+                            } else {
+                                rec_over = true;
+                            }
                         }
                     }
                 }
@@ -666,6 +688,15 @@ k_forward(KGrid g, KOpt o, const float* __restrict__ origins, const float* __res
                         cache_t[ci] = (v.t_far + v.t_close) / 2.f;
                         sample_i += 1;
                     }
+                    if (rec_ok) {
+                        if (rec_cnt < R) {
+                            rec_v[(size_t)rec_cnt * Q + q] = pack_voxel(v.vx, v.vy, v.vz);
+                            rec_m[(size_t)rec_cnt * Q + q] = ((intersect_i + 1) << 8) | 1;
+                            ++rec_cnt;
+                        } else {
+                            rec_over = true;
+                        }
+                    }
                 }
             }
         }
@@ -682,6 +713,7 @@ k_forward(KGrid g, KOpt o, const float* __restrict__ origins, const float* __res
 #pragma unroll
         for (int c = 0; c < 3; ++c) rgb_out[3 * q + c] = outv[c] + bg;
         if (CACHE) cache_n[q] = sample_i;
+        if (do_rec) rec_n[q] = rec_over ? -1 : rec_cnt;
     }
     if (COUNT && counters != nullptr) {
         const float ft = wave_sum((float)n_trav), fa = wave_sum((float)n_act),
@@ -701,18 +733,24 @@ k_forward(KGrid g, KOpt o, const float* __restrict__ origins, const float* __res
 //   FUSED: grad_in is rgb_gt and the image-loss gradient is formed here (:3306-3316);
 //          otherwise grad_in is dL/drgb.
 // ------------------------------------------------------------------------------------
-template <int B, bool FUSED, bool CLDS>
+//   REC:   (fused only) no walk at all -- replay the sample records the forward kernel left
+//          behind (voxel, level set, root index, intersection ordinal per composited sample);
+//          rays whose record overflowed (rec_n < 0) are left to a second, walking launch that
+//          is restricted to them through `ray_filter`.
+template <int B, bool FUSED, bool CLDS, bool REC>
 __global__ void __launch_bounds__(kBlock)
 k_backward(KGrid g, KOpt o, KLoss L, KGrads G, const float* __restrict__ origins,
            const float* __restrict__ dirs, long long Q, const float* __restrict__ grad_in,
            const float* __restrict__ color_cache, int M, const float* __restrict__ cache_a,
            const float* __restrict__ cache_w, const float* __restrict__ cache_t,
-           const int* __restrict__ cache_n) {
+           const int* __restrict__ cache_n, const int* __restrict__ rec_v,
+           const int* __restrict__ rec_m, const int* __restrict__ rec_n,
+           const int* __restrict__ ray_filter) {
     extern __shared__ unsigned int s_coarse[];
     __shared__ float s_sph[kBlock * kSphPad];
     __shared__ LaneRec s_rec[kBlock];
     const int tid = threadIdx.x;
-    if constexpr (CLDS) {
+    if constexpr (CLDS && !REC) {
         for (int i = tid; i < g.coarse_words; i += kBlock) s_coarse[i] = g.coarse[i];
         __syncthreads();
     }
@@ -720,7 +758,11 @@ k_backward(KGrid g, KOpt o, KLoss L, KGrads G, const float* __restrict__ origins
     const LaneRec* rec_wave = s_rec + (tid & ~63);
 
     const long long q = (long long)blockIdx.x * kBlock + tid;
-    const bool valid = q < Q;
+    bool valid = q < Q;
+    if (valid) {
+        if constexpr (REC) valid = rec_n[q] >= 0;
+        else if (ray_filter != nullptr) valid = ray_filter[q] < 0;
+    }
     Ray r;
     r.tmin = 1.f;
     r.tmax = 0.f;
@@ -837,35 +879,59 @@ k_backward(KGrid g, KOpt o, KLoss L, KGrads G, const float* __restrict__ origins
         return (float)((double)curr + add);
     };
 
-    constexpr int QD = kQueueDepth;
+    constexpr int QD = REC ? 1 : kQueueDepth;
     __shared__ int s_queue[QD * kBlock];
     int qn = 0;
+    // record replay state (REC)
+    int rec_i = 0;
+    int n_rec = (REC && valid) ? rec_n[q] : 0;
+    int rec_meta = 0;
+    bool rec_last_of_voxel = true;
     while (true) {
-        while (active && qn < QD) {
-            walk_step(g, r, w);
-            const bool hit = walk_test<CLDS>(g, s_coarse, w);
-            active = (w.t <= r.tmax);
-            // backward-only loop quirk: `t += step_size` on voxels with a missing corner
-            // (:1935-1936) can end the loop one voxel early near the exit face.
-            if (active && !hit && (w.t + o.step_size > r.tmax)) {
-                if (!links_present(g, w)) active = false;
+        if constexpr (REC) {
+            qn = 0;
+            if (rec_i < n_rec) {
+                const int pv = rec_v[(size_t)rec_i * Q + q];
+                s_queue[tid] = pv;
+                rec_meta = rec_m[(size_t)rec_i * Q + q];
+                ++rec_i;
+                rec_last_of_voxel = (rec_i >= n_rec) || (rec_v[(size_t)rec_i * Q + q] != pv);
+                qn = 1;
             }
-            if (hit) {
-                s_queue[qn * kBlock + tid] = pack_voxel(w.vx, w.vy, w.vz);
-                ++qn;
+        } else {
+            while (active && qn < QD) {
+                walk_step(g, r, w);
+                const bool hit = walk_test<CLDS>(g, s_coarse, w);
+                active = (w.t <= r.tmax);
+                // backward-only loop quirk: `t += step_size` on voxels with a missing corner
+                // (:1935-1936) can end the loop one voxel early near the exit face.
+                if (active && !hit && (w.t + o.step_size > r.tmax)) {
+                    if (!links_present(g, w)) active = false;
+                }
+                if (hit) {
+                    s_queue[qn * kBlock + tid] = pack_voxel(w.vx, w.vy, w.vz);
+                    ++qn;
+                }
             }
+            if (o.debug & 1) qn = 0;  // measurement aid: traversal only
         }
-        if (o.debug & 1) qn = 0;  // measurement aid: traversal only
         if (!__any(qn > 0)) break;
       for (int qi = 0; __any(qi < qn); ++qi) {
         const bool found = qi < qn;
         Vox v;
         if (found) load_voxel(g, r, s_queue[qi * kBlock + tid], v);
         bool vox_has_sample = false, vox_has_surf = false;
+        // record fields: bit0 fake, bits1-2 root index, bits3-7 level-set index,
+        // bits8.. intersection ordinal + 1 at the sample
+        const bool rec_fake = REC && (rec_meta & 1);
+        const int rec_st = (rec_meta >> 1) & 3;
+        const int rec_li = (rec_meta >> 3) & 31;
+        if (REC && found) intersect_i = (rec_meta >> 8) - 1 - (rec_fake ? 0 : 1);
 
         for (int li = 0; li < g.level_set_num; ++li) {
             const float lvf = g.level_set[li];
-            const bool lv_ok = found && !(lvf < v.smin || lvf > v.smax);
+            bool lv_ok = found && !(lvf < v.smin || lvf > v.smax);
+            if (REC) lv_ok = lv_ok && !rec_fake && (li == rec_li);
             if (!__any(lv_ok)) continue;
             double st[3] = {-1, -1, -1};
             double fs[4] = {0, 0, 0, 0};
@@ -881,6 +947,7 @@ k_backward(KGrid g, KOpt o, KLoss L, KGrads G, const float* __restrict__ origins
 #pragma unroll
             for (int st_id = 0; st_id < 3; ++st_id) {
                 bool cand = lv_ok && (st[st_id] > 0);
+                if (REC) cand = cand && (st_id == rec_st);
                 float pos[3] = {0.f, 0.f, 0.f};
                 if (cand) cand = root_position(r, v, st[st_id], pos);
                 if (cand) vox_has_sample = true;
@@ -997,6 +1064,7 @@ k_backward(KGrid g, KOpt o, KLoss L, KGrads G, const float* __restrict__ origins
             bool fk = found && o.surf_fake_sample && !vox_has_sample &&
                       (!o.limited_fake_sample || vox_has_surf) &&
                       ((v.t_far - v.t_close) > o.surf_fake_sample_min_vox_len);
+            if (REC) fk = found && rec_fake;  // the forward already decided
             float pos[3] = {0.f, 0.f, 0.f};
             float raw_alpha = 0.f;
             if (fk) {
@@ -1095,9 +1163,11 @@ k_backward(KGrid g, KOpt o, KLoss L, KGrads G, const float* __restrict__ origins
                 }
             }
         }
-        if (found && expf(log_transmit) < o.stop_thresh) {  // :2893-2895
+        // the reference tests this once per voxel, after all of its samples (:2893-2895)
+        if (found && (!REC || rec_last_of_voxel) && expf(log_transmit) < o.stop_thresh) {
             active = false;
             qn = 0;
+            n_rec = 0;
         }
       }
         qn = 0;

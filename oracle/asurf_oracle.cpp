@@ -486,7 +486,7 @@ inline void atomic_addf(float* p, float v) {
 }
 
 struct Counters {
-    int n_trav = 0, n_active = 0, n_samples = 0;
+    int n_trav = 0, n_active = 0, n_samples = 0, n_surf = 0;
 };
 
 struct Dump {
@@ -637,6 +637,7 @@ void trace_forward(const oracle_grid& g, const oracle_render_options& o, const R
         for (int li = 0; li < g.level_set_num; ++li) {
             const double lv = (double)g.level_set_data[li];
             if (lv < vc.smin || lv > vc.smax) continue;
+            if (!vox_has_surf) ++cnt.n_surf;
             vox_has_surf = true;
             double st[3] = {-1, -1, -1};
             solve_cubic_vieta(vc.fs[0] - lv, vc.fs[1], vc.fs[2], vc.fs[3], 1e-10, st);
@@ -1106,6 +1107,7 @@ void attach_stats(const oracle_stats* st, int64_t q, const Counters& c, const Du
     if (st->n_traversed) st->n_traversed[q] = c.n_trav;
     if (st->n_active) st->n_active[q] = c.n_active;
     if (st->n_samples) st->n_samples[q] = c.n_samples;
+    if (st->n_surf) st->n_surf[q] = c.n_surf;
 }
 
 Dump make_dump(const oracle_stats* st, int64_t q) {

@@ -120,6 +120,7 @@ typedef struct oracle_stats {
     float* dump_weight;   /* [n_rays,max_dump] */
     int32_t* dump_voxel;  /* [n_rays,max_dump,3] */
     int32_t* dump_flags;  /* [n_rays,max_dump] bit0 = fake sample */
+    int32_t* n_surf;      /* [n_rays] active voxels that hold a level set (cubic solved) */
 } oracle_stats;
 
 int oracle_num_threads(void);

@@ -83,7 +83,7 @@ class FusedParams(C.Structure):
 class Stats(C.Structure):
     _fields_ = [("n_traversed", c_i), ("n_active", c_i), ("n_samples", c_i),
                 ("max_dump", C.c_int32), ("dump_t", c_f), ("dump_alpha", c_f),
-                ("dump_weight", c_f), ("dump_voxel", c_i), ("dump_flags", c_i)]
+                ("dump_weight", c_f), ("dump_voxel", c_i), ("dump_flags", c_i), ("n_surf", c_i)]
 
 
 _lib = None
@@ -218,7 +218,9 @@ def _grads(gr):
 def _stats(q, max_dump=0):
     st = dict(n_traversed=np.zeros(q, np.int32), n_active=np.zeros(q, np.int32),
               n_samples=np.zeros(q, np.int32))
+    st["n_surf"] = np.zeros(q, np.int32)
     s = Stats(_i(st["n_traversed"]), _i(st["n_active"]), _i(st["n_samples"]), max_dump)
+    s.n_surf = _i(st["n_surf"])
     if max_dump:
         st["dump_t"] = np.zeros((q, max_dump), np.float32)
         st["dump_alpha"] = np.zeros((q, max_dump), np.float32)
