@@ -14,6 +14,7 @@
 #include <cstring>
 
 #include "asurf_kernels.h"
+#include "asurf_optim.h"
 
 namespace {
 
@@ -418,6 +419,44 @@ int asurf_volume_render_surf_trav_fused(const asurf_grid* grid, const asurf_rays
         ASURF_DISPATCH_B(grid->basis_dim, run_backward<B_>(L, rays, loss, G, fused->rgb_gt, rgb_out, M, true, 0));
     }
     return rc;
+}
+
+static int optim_launch(bool rms_mode, float* data, float* rms, float* grad, int64_t n_rows,
+                        int32_t n_cols, const uint8_t* mask, const int64_t* indices,
+                        int64_t n_indices, float beta, float lr, float epsilon, float minval,
+                        float lr_last, void* stream) {
+    if (!data || !grad || (rms_mode && !rms)) return fail(ASURF_E_INVALID, "optim step: NULL tensor");
+    if (n_rows < 0 || n_cols <= 0 || n_indices < 0) return fail(ASURF_E_INVALID, "optim step: bad shape");
+    if (lr_last < 0.f) lr_last = lr;  // optim_kernel.cu:169
+    const int mode = mask ? 1 : (indices ? 2 : 0);
+    if (mode == 2 && n_indices == 0) return 0;  // empty index list: nothing to do
+    const long long total = (mode == 2 ? n_indices : n_rows) * (long long)n_cols;
+    if (total == 0) return 0;
+    long long blocks = (total + 255) / 256;
+    if (blocks > 256 * 16) blocks = 256 * 16;  // grid-stride beyond 16 blocks per CU
+    auto* idx = reinterpret_cast<const long long*>(indices);
+    if (rms_mode)
+        hipLaunchKernelGGL((k_optim_step<true>), dim3((unsigned)blocks), dim3(256), 0,
+                           static_cast<hipStream_t>(stream), data, rms, grad, (long long)n_rows, n_cols,
+                           mode, mask, idx, (long long)n_indices, beta, lr, epsilon, minval, lr_last);
+    else
+        hipLaunchKernelGGL((k_optim_step<false>), dim3((unsigned)blocks), dim3(256), 0,
+                           static_cast<hipStream_t>(stream), data, rms, grad, (long long)n_rows, n_cols,
+                           mode, mask, idx, (long long)n_indices, beta, lr, epsilon, minval, lr_last);
+    return launch_error("k_optim_step");
+}
+
+int asurf_rmsprop_step(float* data, float* rms, float* grad, int64_t n_rows, int32_t n_cols,
+                       const uint8_t* mask, const int64_t* indices, int64_t n_indices, float beta,
+                       float lr, float epsilon, float minval, float lr_last, void* stream) {
+    return optim_launch(true, data, rms, grad, n_rows, n_cols, mask, indices, n_indices, beta, lr,
+                        epsilon, minval, lr_last, stream);
+}
+
+int asurf_sgd_step(float* data, float* grad, int64_t n_rows, int32_t n_cols, const uint8_t* mask,
+                   const int64_t* indices, int64_t n_indices, float lr, float lr_last, void* stream) {
+    return optim_launch(false, data, nullptr, grad, n_rows, n_cols, mask, indices, n_indices, 0.f, lr,
+                        0.f, 0.f, lr_last, stream);
 }
 
 int asurf_profile_enable(int on) {

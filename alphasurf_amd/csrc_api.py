@@ -19,7 +19,7 @@ __all__ = [
     "SparseGridSpec", "CameraSpec", "RaysSpec", "RayVoxIntersecSpec", "RenderOptions",
     "GridOutputGrads", "volume_render_surf_trav", "volume_render_surf_trav_backward",
     "volume_render_surf_trav_fused", "volume_render_surface", "volume_render_surface_backward",
-    "volume_render_surface_fused", "test_cubic_root_grad", "sample_grid",
+    "volume_render_surface_fused", "test_cubic_root_grad", "sample_grid", "rmsprop_step", "sgd_step",
 ]
 
 
@@ -404,6 +404,55 @@ def test_cubic_root_grad(T_fs, T_st_ids, T_grad_fs, T_st, use_vieta):
         _L.check(_L.lib().asurf_test_cubic_root_grad(_ptr(T_fs), _ptr(T_st_ids), _ptr(T_grad_fs),
                                                      _ptr(T_st), n, int(bool(use_vieta)), _stream(dev)))
     return T_grad_fs
+
+
+def _indexer_args(indexer, n_rows):
+    """The reference's polymorphic `indexer` tensor (optim_kernel.cu:171-214): 0-dim -> all rows,
+    bool [n_rows] -> row mask, int64 [k] -> row ids (k == 0: nothing to do)."""
+    if not torch.is_tensor(indexer):
+        raise RuntimeError("indexer must be a tensor")
+    if indexer.dim() == 0:
+        return C.c_void_p(0), C.c_void_p(0), 0, False
+    _check_input(indexer, "indexer")
+    if indexer.shape[0] == 0:
+        return C.c_void_p(0), C.c_void_p(0), 0, True
+    if indexer.dtype == torch.bool:
+        if indexer.shape[0] != n_rows:
+            raise RuntimeError("bool indexer must have one entry per row")
+        return _ptr(indexer), C.c_void_p(0), 0, False
+    if indexer.dtype != torch.int64:
+        raise RuntimeError("indexer must be bool or int64")
+    return C.c_void_p(0), _ptr(indexer), indexer.shape[0], False
+
+
+def rmsprop_step(data, rms, grad, indexer, beta, lr, epsilon, minval, lr_last):
+    """void rmsprop_step(data, rms, grad, indexer, beta, lr, epsilon, minval, lr_last)
+    (optim_kernel.cu:154-216): in-place RMSProp on [rows, cols] tensors; zeroes the gradient."""
+    for t, name in ((data, "data"), (rms, "rms"), (grad, "grad")):
+        _check_input(t, name, torch.float32)
+    if data.dim() != 2 or rms.shape != data.shape or grad.shape != data.shape:
+        raise RuntimeError("data, rms and grad must be 2-D tensors of the same shape")
+    mask, idx, n_idx, empty = _indexer_args(indexer, data.shape[0])
+    if empty:
+        return
+    with torch.cuda.device(data.device):
+        _L.check(_L.lib().asurf_rmsprop_step(_ptr(data), _ptr(rms), _ptr(grad), data.shape[0], data.shape[1],
+                                             mask, idx, n_idx, float(beta), float(lr), float(epsilon),
+                                             float(minval), float(lr_last), _stream(data.device)))
+
+
+def sgd_step(data, grad, indexer, lr, lr_last):
+    """void sgd_step(data, grad, indexer, lr, lr_last) (optim_kernel.cu:220-265)."""
+    for t, name in ((data, "data"), (grad, "grad")):
+        _check_input(t, name, torch.float32)
+    if data.dim() != 2 or grad.shape != data.shape:
+        raise RuntimeError("data and grad must be 2-D tensors of the same shape")
+    mask, idx, n_idx, empty = _indexer_args(indexer, data.shape[0])
+    if empty:
+        return
+    with torch.cuda.device(data.device):
+        _L.check(_L.lib().asurf_sgd_step(_ptr(data), _ptr(grad), data.shape[0], data.shape[1], mask, idx,
+                                         n_idx, float(lr), float(lr_last), _stream(data.device)))
 
 
 def sample_grid(*args, **kwargs):

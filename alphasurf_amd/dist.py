@@ -1,0 +1,126 @@
+"""Data-parallel exchange for ray-sharded rendering.
+
+The reference is single-GPU; this is new functionality.  Rays shard
+across ranks, the grid is replicated, every rank calls the fused renderer with the GLOBAL
+ray count in the loss normaliser, and the per-rank gradient buffers are then summed here.
+After the exchange every rank holds the gradient of the whole batch and the union of the
+touched-row masks, exactly what a single GPU would have produced on the concatenated rays
+(up to float summation order).
+
+Backend: torch.distributed -- "nccl" is RCCL over xGMI on ROCm; "gloo" for the CPU tests.
+"""
+import torch
+import torch.distributed as dist
+
+
+def _world(group):
+    return dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
+
+
+def all_reduce_dense(tensors, mask=None, group=None):
+    """Plain sum all-reduce of every gradient buffer + OR of the mask."""
+    if _world(group) == 1:
+        return
+    for t in tensors:
+        if t is not None:
+            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+    if mask is not None:
+        m8 = mask.view(torch.uint8) if mask.dtype == torch.bool else mask
+        dist.all_reduce(m8, op=dist.ReduceOp.MAX, group=group)
+
+
+def all_reduce_sparse(tensors, mask, group=None):
+    """Sparse sum keyed by the touched-row mask (`mask_out`, render_util.cuh:138-142).
+
+    Row ownership is a contiguous range per rank.  Step 1 (all-to-all): every rank sends the
+    touched rows of each range to its owner, which sums them.  Step 2 (all-gather): owners
+    publish their summed rows; every rank writes them back.  Per-rank volume is about
+    2 * touched_rows * row_bytes instead of 2 * all_rows * row_bytes for the dense ring, and
+    the all-to-all uses all xGMI links at once rather than one ring direction.
+    """
+    world = _world(group)
+    if world == 1:
+        return
+    rank = dist.get_rank(group)
+    tensors = [t for t in tensors if t is not None]
+    n = mask.shape[0]
+    dev = mask.device
+    widths = [t.reshape(n, -1).shape[1] for t in tensors]
+    W = sum(widths)
+    # contiguous ownership ranges
+    bounds = torch.linspace(0, n, world + 1, device="cpu").long().tolist()
+    idx = torch.nonzero(mask.view(-1), as_tuple=False).view(-1)
+    rows = torch.cat([t.reshape(n, -1)[idx] for t in tensors], dim=1) if idx.numel() else \
+        torch.zeros((0, W), dtype=tensors[0].dtype, device=dev)
+    owner_cuts = torch.searchsorted(idx, torch.tensor(bounds, device=dev))
+    send_counts = (owner_cuts[1:] - owner_cuts[:-1]).to(torch.int64)
+    recv_counts = torch.empty_like(send_counts)
+    dist.all_to_all_single(recv_counts, send_counts, group=group)
+    sc, rc = send_counts.tolist(), recv_counts.tolist()
+    recv_idx = torch.empty(sum(rc), dtype=idx.dtype, device=dev)
+    recv_rows = torch.empty((sum(rc), W), dtype=rows.dtype, device=dev)
+    dist.all_to_all_single(recv_idx, idx, output_split_sizes=rc, input_split_sizes=sc, group=group)
+    dist.all_to_all_single(recv_rows, rows, output_split_sizes=rc, input_split_sizes=sc, group=group)
+    # owner-side reduction over its range
+    lo, hi = bounds[rank], bounds[rank + 1]
+    acc = torch.zeros((hi - lo, W), dtype=rows.dtype, device=dev)
+    acc.index_add_(0, recv_idx - lo, recv_rows)
+    touched = torch.zeros(hi - lo, dtype=torch.bool, device=dev)
+    touched[recv_idx - lo] = True
+    own_idx = torch.nonzero(touched, as_tuple=False).view(-1)
+    own_rows = acc[own_idx]
+    own_idx = own_idx + lo
+    # publish the summed rows
+    cnt = torch.tensor([own_idx.numel()], dtype=torch.int64, device=dev)
+    cnts = [torch.zeros_like(cnt) for _ in range(world)]
+    dist.all_gather(cnts, cnt, group=group)
+    cnts = [int(c.item()) for c in cnts]
+    mx = max(max(cnts), 1)
+    pad_idx = torch.zeros(mx, dtype=own_idx.dtype, device=dev)
+    pad_rows = torch.zeros((mx, W), dtype=rows.dtype, device=dev)
+    pad_idx[: own_idx.numel()] = own_idx
+    pad_rows[: own_idx.numel()] = own_rows
+    all_idx = [torch.empty_like(pad_idx) for _ in range(world)]
+    all_rows = [torch.empty_like(pad_rows) for _ in range(world)]
+    dist.all_gather(all_idx, pad_idx, group=group)
+    dist.all_gather(all_rows, pad_rows, group=group)
+    for r in range(world):
+        k = cnts[r]
+        if k == 0:
+            continue
+        ids, vals = all_idx[r][:k], all_rows[r][:k]
+        c0 = 0
+        for t, w in zip(tensors, widths):
+            t.reshape(n, -1)[ids] = vals[:, c0:c0 + w]
+            c0 += w
+        mask.view(-1)[ids] = True
+
+
+def all_reduce_grads(grad_sh, grad_density, grad_surface, mask, grad_fake_sample_std=None,
+                     group=None, dense_threshold=0.125, mode="auto"):
+    """Sum the sparse gradient buffers of a fused render across ranks.
+
+    mode: "dense", "sparse" or "auto" (sparse when the fraction of touched rows on every rank
+    is below `dense_threshold`, mirroring the reference's own switch between mask and index
+    lists at svox2/svox2.py:6326-6332)."""
+    if _world(group) == 1:
+        return "single"
+    if grad_fake_sample_std is not None:
+        dist.all_reduce(grad_fake_sample_std, group=group)
+    tensors = [grad_sh, grad_density, grad_surface]
+    if mode == "auto":
+        frac = mask.float().mean().reshape(1)
+        dist.all_reduce(frac, op=dist.ReduceOp.MAX, group=group)
+        mode = "sparse" if float(frac.item()) < dense_threshold else "dense"
+    if mode == "sparse":
+        all_reduce_sparse(tensors, mask, group=group)
+    else:
+        all_reduce_dense(tensors, mask, group=group)
+    return mode
+
+
+def shard_rays(n_rays, rank, world):
+    """Contiguous ray range of this rank (contiguous image tiles keep touched-voxel sets compact)."""
+    per = (n_rays + world - 1) // world
+    lo = min(rank * per, n_rays)
+    return lo, min(lo + per, n_rays)

@@ -1,0 +1,550 @@
+"""Host-side mirror of the slice of the reference's `svox2` Python API that sits on the hot path
+(tier P0 + the cheap P1 pieces): `SparseGrid`, `Rays`, `Camera`,
+`RenderOptions`, the autograd bridge and the fused training call, with the reference's names,
+keyword arguments and side effects, so that `opt/opt.py` can import this package as `svox2`.
+
+Own code; reference locations are cited for parity checking (paths relative to the reference
+checkout, `svox2/svox2.py` unless stated).  Everything that leaves the hot path raises
+NotImplementedError naming the SURVEY.md section 8(f) row it belongs to.
+"""
+from dataclasses import dataclass
+from functools import reduce
+from typing import List, Optional, Tuple, Union
+
+import numpy as np
+import torch
+from torch import autograd, nn
+
+from . import csrc_api as _C
+from . import gridinit, shutils
+
+# enums of data_spec.hpp:8-36 / svox2/defs.py
+CONSTANTS = dict(
+    BASIS_TYPE_SH=1, BASIS_TYPE_3D_TEXTURE=4, BASIS_TYPE_MLP=255,
+    SURFACE_TYPE_NONE=100, SURFACE_TYPE_PLANE=101, SURFACE_TYPE_SDF=102, SURFACE_TYPE_UDF=103,
+    SURFACE_TYPE_UDF_ALPHA=104, SURFACE_TYPE_UDF_FAKE_SAMPLE=105, SURFACE_TYPE_VOXEL_FACE=106,
+    SIGMOID_FN=0, EXP_FN=1,
+)
+globals().update(CONSTANTS)
+
+
+def _next_row(row, what):
+    raise NotImplementedError(f"{what} is outside the hot-path scope of this build (SURVEY.md section 8f, {row})")
+
+
+@dataclass
+class RenderOptions:
+    """Rendering options (:21-105); `backend` is consumed in Python only."""
+    backend: str = "cuvol"
+    background_brightness: float = 1.0
+    step_size: float = 0.5
+    sigma_thresh: float = 1e-10
+    stop_thresh: float = 1e-7
+    last_sample_opaque: bool = False
+    near_clip: float = 0.0
+    use_spheric_clip: bool = False
+    random_sigma_std: float = 1.0
+    random_sigma_std_background: float = 1.0
+    surf_fake_sample: bool = False
+    surf_fake_sample_min_vox_len: float = 0.1
+    limited_fake_sample: bool = False
+    no_surf_grad_from_sh: bool = False
+    alpha_activation_type: int = CONSTANTS["EXP_FN"]
+    fake_sample_l_dist: bool = True
+    fake_sample_normalize_surf: bool = True
+    only_outward_intersect: bool = False
+    truncated_vol_render: bool = False
+    trunc_vol_weight_min: float = 0.0
+
+    def _to_cpp(self, randomize: bool = False):
+        opt = _C.RenderOptions()
+        for name in ("background_brightness", "step_size", "sigma_thresh", "stop_thresh", "near_clip",
+                     "use_spheric_clip", "last_sample_opaque", "surf_fake_sample",
+                     "surf_fake_sample_min_vox_len", "limited_fake_sample", "no_surf_grad_from_sh",
+                     "alpha_activation_type", "fake_sample_l_dist", "fake_sample_normalize_surf",
+                     "only_outward_intersect", "truncated_vol_render", "trunc_vol_weight_min"):
+            setattr(opt, name, getattr(self, name))
+        return opt
+
+
+@dataclass
+class Rays:
+    """:108-133"""
+    origins: torch.Tensor
+    dirs: torch.Tensor
+    masks: Optional[torch.Tensor] = None
+
+    def __post_init__(self):
+        if self.masks is None:
+            self.masks = torch.ones_like(self.origins[..., 0]).bool()
+
+    def _to_cpp(self):
+        spec = _C.RaysSpec()
+        spec.origins, spec.dirs, spec.masks = self.origins, self.dirs, self.masks
+        return spec
+
+    def __getitem__(self, key):
+        return Rays(self.origins[key], self.dirs[key], self.masks[key])
+
+    @property
+    def is_cuda(self) -> bool:
+        return self.origins.is_cuda and self.dirs.is_cuda and self.masks.is_cuda
+
+
+@dataclass
+class RayVoxIntersecs:
+    """:135-156 (legacy `surface` backend)"""
+    voxel_ls: torch.Tensor
+    vox_start_i: torch.Tensor
+    vox_num: torch.Tensor
+
+    def _to_cpp(self):
+        spec = _C.RayVoxIntersecSpec()
+        spec.voxel_ls, spec.vox_start_i, spec.vox_num = self.voxel_ls, self.vox_start_i, self.vox_num
+        return spec
+
+    def __getitem__(self, key):
+        return RayVoxIntersecs(self.voxel_ls[key], self.vox_start_i[key], self.vox_num[key])
+
+    @property
+    def is_cuda(self) -> bool:
+        return self.voxel_ls.is_cuda and self.vox_start_i.is_cuda and self.vox_num.is_cuda
+
+
+@dataclass
+class Camera:
+    """Pinhole camera, OpenCV convention (:159-237)."""
+    c2w: torch.Tensor
+    fx: float = 1111.11
+    fy: Optional[float] = None
+    cx: Optional[float] = None
+    cy: Optional[float] = None
+    width: int = 800
+    height: int = 800
+    ndc_coeffs: Union[Tuple[float, float], List[float]] = (-1.0, -1.0)
+
+    @property
+    def fx_val(self):
+        return self.fx
+
+    @property
+    def fy_val(self):
+        return self.fx if self.fy is None else self.fy
+
+    @property
+    def cx_val(self):
+        return self.width * 0.5 if self.cx is None else self.cx
+
+    @property
+    def cy_val(self):
+        return self.height * 0.5 if self.cy is None else self.cy
+
+    @property
+    def using_ndc(self):
+        return self.ndc_coeffs[0] > 0.0
+
+    @property
+    def is_cuda(self) -> bool:
+        return self.c2w.is_cuda
+
+    def _to_cpp(self):
+        spec = _C.CameraSpec()
+        spec.c2w = self.c2w
+        spec.fx, spec.fy, spec.cx, spec.cy = self.fx_val, self.fy_val, self.cx_val, self.cy_val
+        spec.width, spec.height = self.width, self.height
+        spec.ndc_coeffx, spec.ndc_coeffy = self.ndc_coeffs[0], self.ndc_coeffs[1]
+        return spec
+
+    def gen_rays(self) -> Rays:
+        """Rays through the pixel centres in row-major order; directions are formed in float64
+        and normalised before the rotation, like the reference (:211-237)."""
+        if self.using_ndc:
+            _next_row("N4", "NDC cameras")
+        dev = self.c2w.device
+        ys = torch.arange(self.height, dtype=torch.float64, device=dev) + 0.5
+        xs = torch.arange(self.width, dtype=torch.float64, device=dev) + 0.5
+        yy, xx = torch.meshgrid(ys, xs, indexing="ij")
+        d = torch.stack(((xx - self.cx_val) / self.fx_val, (yy - self.cy_val) / self.fy_val,
+                         torch.ones_like(xx)), dim=-1).reshape(-1, 3)
+        d = d / d.norm(dim=-1, keepdim=True)
+        d = (d @ self.c2w[:3, :3].double().T).float()
+        o = self.c2w[None, :3, 3].expand(d.shape[0], -1).contiguous()
+        return Rays(o, d.contiguous())
+
+
+class _SurfTravRenderFunction(autograd.Function):
+    """Autograd bridge of the non-fused path (:349-430): forward = volume_render_<backend>,
+    backward = volume_render_<backend>_backward into freshly zeroed dense gradients."""
+
+    @staticmethod
+    def forward(ctx, data_density, data_surface, data_sh, data_basis, data_background,
+                data_fake_sample_std, grid, rays, opt, backend):
+        color = getattr(_C, f"volume_render_{backend}")(grid, rays, opt)
+        ctx.save_for_backward(color)
+        ctx.grid, ctx.rays, ctx.opt, ctx.backend = grid, rays, opt, backend
+        return color
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        (color_cache,) = ctx.saved_tensors
+        g = ctx.grid
+        holder = _C.GridOutputGrads()
+        holder.grad_density_out = torch.zeros_like(g.density_data.data)
+        holder.grad_surface_out = torch.zeros_like(g.surface_data.data)
+        holder.grad_sh_out = torch.zeros_like(g.sh_data.data)
+        holder.grad_fake_sample_std_out = torch.zeros_like(g.density_data.data[:1])
+        getattr(_C, f"volume_render_{ctx.backend}_backward")(
+            g, ctx.rays, ctx.opt, grad_out.contiguous(), color_cache, holder)
+        ctx.grid = ctx.rays = ctx.opt = None
+        need = ctx.needs_input_grad
+        return (holder.grad_density_out if need[0] else None,
+                holder.grad_surface_out if need[1] else None,
+                holder.grad_sh_out if need[2] else None, None, None,
+                holder.grad_fake_sample_std_out if need[5] else None, None, None, None, None)
+
+
+class SparseGrid(nn.Module):
+    """Sparse voxel grid with a per-vertex surface scalar (:560-990).  Only what the surf_trav
+    hot path needs is built: SH basis, SDF/UDF surface types, no MSI background."""
+
+    def __init__(self, reso: Union[int, List[int], Tuple[int, int, int]] = 128,
+                 radius: Union[float, List[float]] = 1.0,
+                 center: Union[float, List[float]] = [0.0, 0.0, 0.0],
+                 basis_type: int = CONSTANTS["BASIS_TYPE_SH"], basis_dim: int = 9, basis_reso: int = 16,
+                 use_z_order: bool = False, use_sphere_bound: bool = False, mlp_posenc_size: int = 0,
+                 mlp_width: int = 16, background_nlayers: int = 0, background_reso: int = 256,
+                 device: Union[torch.device, str] = "cpu",
+                 surface_type: int = CONSTANTS["SURFACE_TYPE_NONE"], surface_init: str = None,
+                 use_octree: bool = True, trainable_fake_sample_std: bool = False,
+                 force_alpha: bool = False):
+        super().__init__()
+        if basis_type != CONSTANTS["BASIS_TYPE_SH"]:
+            _next_row("N4", "learned bases (3D texture / MLP)")
+        if background_nlayers != 0:
+            _next_row("N4", "MSI background layers")
+        assert shutils.isqrt(basis_dim) is not None, "basis_dim (SH) must be a square number"
+        assert 1 <= basis_dim <= shutils.MAX_SH_BASIS, f"basis_dim 1-{shutils.MAX_SH_BASIS} supported"
+        self.basis_type, self.surface_type = basis_type, surface_type
+        self.basis_dim = basis_dim
+        self.step_id = 0
+        self.force_alpha = force_alpha
+        self.mlp_posenc_size, self.mlp_width = mlp_posenc_size, mlp_width
+        self.background_nlayers, self.background_reso = 0, background_reso
+        reso = [reso] * 3 if isinstance(reso, int) else list(reso)
+        assert len(reso) == 3, "reso must be an integer or indexable object of 3 ints"
+        if isinstance(radius, (float, int)):
+            radius = [radius] * 3
+        self.radius = torch.as_tensor(radius, dtype=torch.float32, device="cpu")
+        self.center = torch.as_tensor(center, dtype=torch.float32, device="cpu")
+        self._offset = 0.5 * (1.0 - self.center / self.radius)   # :644-645
+        self._scaling = 0.5 / self.radius
+
+        links = gridinit.init_links(reso, use_z_order=use_z_order)
+        if use_sphere_bound:
+            links = gridinit.sphere_bound_links(links)
+        self.capacity = int(links.max()) + 1
+        n = self.capacity
+        self.density_data = nn.Parameter(torch.zeros(n, 1, dtype=torch.float32, device=device))
+        self.sh_data = nn.Parameter(torch.zeros(n, basis_dim * 3, dtype=torch.float32, device=device))
+        empty = dict(dtype=torch.float32, device=device)
+        self.basis_data = nn.Parameter(torch.empty(0, 0, 0, 0, **empty), requires_grad=False)
+        self.background_data = nn.Parameter(torch.empty(0, 0, 0, **empty), requires_grad=False)
+        self.register_buffer("links", torch.from_numpy(links).to(device))
+        self.trainable_data = ["density_data", "sh_data", "basis_data", "background_data"]
+
+        self.surface_data = None
+        self.fake_sample_std = None
+        self.truncated_vol_render_a = 1
+        if trainable_fake_sample_std:
+            self.fake_sample_std = nn.Parameter(torch.tensor([[1.0]], dtype=torch.float32, device=device))
+            self.trainable_data.append("fake_sample_std")
+        self.level_set_data = None
+        if surface_type == CONSTANTS["SURFACE_TYPE_SDF"]:
+            self.level_set_data = torch.tensor([0.0], device=device)
+            if surface_init is None:
+                surf = np.zeros((n, 1), np.float32)
+            elif surface_init == "sphere":
+                surf = gridinit.sphere_surface_init(links)
+            else:
+                _next_row("N4", f"surface_init={surface_init!r}")
+            self.surface_data = nn.Parameter(torch.from_numpy(surf).to(device))
+            self.trainable_data.append("surface_data")
+        elif surface_type == CONSTANTS["SURFACE_TYPE_UDF"]:
+            if surface_init is not None:
+                _next_row("N4", f"UDF surface_init={surface_init!r}")
+            self.level_set_data = torch.tensor([64.0], device=device)
+            self.surface_data = nn.Parameter(torch.zeros(n, 1, dtype=torch.float32, device=device))
+            self.trainable_data.append("surface_data")
+        elif surface_type != CONSTANTS["SURFACE_TYPE_NONE"]:
+            _next_row("N4", f"surface_type={surface_type}")
+
+        self.opt = RenderOptions()
+        self.sparse_grad_indexer: Optional[torch.Tensor] = None
+        self.sparse_sh_grad_indexer: Optional[torch.Tensor] = None
+        self.sparse_background_indexer = None
+        self.density_rms = self.surface_rms = self.fake_sample_std_rms = self.sh_rms = None
+        self.background_rms = self.basis_rms = None
+        self.use_octree = use_octree
+        self._C = _C
+
+    # ---- small properties (:992-1014) ----
+    @property
+    def data_dim(self):
+        return self.sh_data.size(1) + 1
+
+    @property
+    def use_background(self):
+        return False
+
+    @property
+    def shape(self):
+        return list(self.links.shape) + [self.data_dim]
+
+    def _grid_size(self):
+        return torch.tensor(self.links.shape, device="cpu", dtype=torch.float32)
+
+    def world2grid(self, points):
+        """:4492-4506 (this fork has no -0.5 voxel-centre shift)"""
+        gsz = self._grid_size()
+        return torch.addcmul((self._offset * gsz).to(points.device), points,
+                             (self._scaling * gsz).to(points.device))
+
+    def grid2world(self, points):
+        gsz = self._grid_size()
+        roffset = self.radius * (-1.0) + self.center   # :4517-4519
+        rscaling = 2.0 * self.radius / gsz
+        return torch.addcmul(roffset.to(points.device), points, rscaling.to(points.device))
+
+    def trunc_vol_render_rw(self, intersect_ids):
+        """Truncated-hann re-weighting of the i-th intersection (:4740-4746)."""
+        u = torch.clamp(self.truncated_vol_render_a - intersect_ids, 0.0, 1.0)
+        return torch.clamp_min(0.5 * (1.0 - torch.cos(torch.pi * u)), self.opt.trunc_vol_weight_min)
+
+    # ---- spec packing (:6234-6293) ----
+    def _to_cpp(self, grid_coords: bool = False, replace_basis_data=None):
+        g = _C.SparseGridSpec()
+        g.density_data = self.density_data
+        g.surface_type = self.surface_type
+        if self.surface_type != CONSTANTS["SURFACE_TYPE_NONE"]:
+            g.surface_data = self.surface_data
+            g.level_set_data = self.level_set_data
+        g.sh_data = self.sh_data
+        g.links = self.links
+        if grid_coords:
+            g._offset = torch.zeros_like(self._offset)
+            g._scaling = torch.ones_like(self._offset)
+        else:
+            gsz = self._grid_size()
+            g._offset = self._offset * gsz
+            g._scaling = self._scaling * gsz
+        g.basis_dim = self.basis_dim
+        g.basis_type = self.basis_type
+        if self.fake_sample_std is not None:
+            g.fake_sample_std = float(self.fake_sample_std.item()) if torch.is_tensor(self.fake_sample_std) \
+                else float(self.fake_sample_std)
+        g.truncated_vol_render_a = self.truncated_vol_render_a
+        return g
+
+    def _get_data_grads(self):
+        ret = {}
+        for name in self.trainable_data:
+            p = getattr(self, name)
+            if not p.requires_grad:
+                ret[name] = torch.zeros_like(p.data)
+                continue
+            if p.grad is None or p.grad.shape != p.data.shape:
+                p.grad = torch.zeros_like(p.data)
+            ret[name] = p.grad
+        return ret
+
+    # ---- rendering (:3390-3638) ----
+    def _check_backend(self):
+        if self.opt.backend not in ("surf_trav", "surface"):
+            _next_row("N4", f"renderer backend {self.opt.backend!r}")
+        if self.surface_data is None:
+            raise RuntimeError("the surf_trav backend needs a surface grid (surface_type SDF/UDF)")
+
+    def volume_render(self, rays: Rays, use_kernel: bool = True, randomize: bool = False,
+                      return_raylen: bool = False, **kwargs):
+        """Differentiable render of a ray batch; returns {'rgb': [Q,3]} (:3390-3474)."""
+        if not use_kernel or return_raylen:
+            raise NotImplementedError("the pure-PyTorch debugging renderer is not part of this build; "
+                                      "the HIP path is the only implementation (no CPU fallback)")
+        self._check_backend()
+        assert rays.is_cuda and self.links.is_cuda
+        if self.opt.backend == "surface":
+            _next_row("8a-14", "the legacy `surface` backend's Python caller (needs kaolin in the reference too)")
+        rgb = _SurfTravRenderFunction.apply(
+            self.density_data, self.surface_data, self.sh_data, None, None, self.fake_sample_std,
+            self._to_cpp(), rays._to_cpp(), self.opt._to_cpp(randomize=randomize), self.opt.backend)
+        return {"rgb": rgb}
+
+    def volume_render_fused(self, rays: Rays, rgb_gt: torch.Tensor, randomize: bool = False,
+                            beta_loss: float = 0.0, sparsity_loss: float = 0.0,
+                            fused_surf_norm_reg_scale: float = 0.0,
+                            fused_surf_norm_reg_con_check: bool = True,
+                            fused_surf_norm_reg_ignore_empty: bool = False,
+                            lambda_l2: float = 1.0, lambda_l1: float = 0.0, lambda_l_dist: float = 0.0,
+                            lambda_l_entropy: float = 0.0, no_norm_weight_l_entropy: bool = False,
+                            lambda_l_dist_a: float = 0.0, lambda_l_entropy_a: float = 0.0,
+                            lambda_l_samp_dist: float = 0.0, lambda_l_di: float = 0.0,
+                            l_di_alpha_thresh: float = 0.0, surf_sparse_alpha_thresh: float = 0.0,
+                            lambda_inplace_surf_sparse: float = 0.0, lambda_inwards_norm_loss: float = 0.0,
+                            lambda_conv_mode_samp: float = 0.0, l_dist_max_sample: int = 64,
+                            no_surface: bool = False, global_n_rays: int = 0):
+        """Render + fused loss gradients accumulated into the parameters' .grad (:3477-3638).
+        `global_n_rays` (extension) = ray count of the whole data-parallel batch."""
+        assert self.sh_data.is_cuda and rays.is_cuda, "the HIP extension is required for fused"
+        if no_surface:
+            _next_row("N4", "no_surface warm-up (cuvol renderer)")
+        self._check_backend()
+        if self.opt.backend == "surface":
+            _next_row("8a-14", "the legacy `surface` backend's Python caller")
+        grad = self._get_data_grads()
+        rgb_out = torch.zeros_like(rgb_gt)
+        self.sparse_grad_indexer = torch.zeros((self.density_data.size(0),), dtype=torch.bool,
+                                               device=self.density_data.device)
+        holder = _C.GridOutputGrads()
+        holder.grad_density_out = grad["density_data"]
+        holder.grad_surface_out = grad["surface_data"]
+        holder.grad_sh_out = grad["sh_data"]
+        holder.mask_out = self.sparse_grad_indexer
+        if "fake_sample_std" in grad:
+            holder.grad_fake_sample_std_out = grad["fake_sample_std"]
+        _C.volume_render_surf_trav_fused(
+            self._to_cpp(), rays._to_cpp(), self.opt._to_cpp(randomize=randomize), rgb_gt, beta_loss,
+            sparsity_loss, fused_surf_norm_reg_scale, fused_surf_norm_reg_con_check,
+            fused_surf_norm_reg_ignore_empty, lambda_l2, lambda_l1, lambda_l_dist, lambda_l_entropy,
+            no_norm_weight_l_entropy, lambda_l_dist_a, lambda_l_entropy_a, lambda_l_samp_dist,
+            lambda_l_di, l_di_alpha_thresh, surf_sparse_alpha_thresh, lambda_inplace_surf_sparse,
+            lambda_inwards_norm_loss, lambda_conv_mode_samp, l_dist_max_sample, rgb_out, holder,
+            global_n_rays=global_n_rays)
+        self.sparse_sh_grad_indexer = self.sparse_grad_indexer.clone()
+        return {"rgb": rgb_out}
+
+    def volume_render_image(self, camera: Camera, use_kernel: bool = True, randomize: bool = False,
+                            batch_size: int = 5000, return_raylen: bool = False, debug_pixels=None,
+                            **kwargs):
+        """Whole-image render in ray batches (:3641-3691): no image kernel is registered for
+        surf_trav in the reference either (svox2.cpp:153)."""
+        rays = camera.gen_rays()
+        if debug_pixels is not None:
+            ids = debug_pixels[:, 0] + debug_pixels[:, 1] * camera.width
+            return self.volume_render(rays[ids], use_kernel=use_kernel, randomize=randomize)["rgb"]
+        parts = [self.volume_render(rays[s:s + batch_size], use_kernel=use_kernel, randomize=randomize)["rgb"]
+                 for s in range(0, camera.height * camera.width, batch_size)]
+        return torch.cat(parts, dim=0).view(camera.height, camera.width, -1)
+
+    # ---- optimizers (:5972-6140 -> optim_kernel.cu:14-265) ----
+    def _maybe_convert_sparse_grad_indexer(self, sh=False, bg=False):
+        """Mask -> index list when under 1/8 of the rows were touched (:6314-6333)."""
+        indexer = self.sparse_sh_grad_indexer if sh else self.sparse_grad_indexer
+        if indexer is None:
+            return torch.empty((), device=self.density_data.device)
+        if indexer.dtype == torch.bool and torch.count_nonzero(indexer).item() < indexer.size(0) // 8:
+            indexer = torch.nonzero(indexer.flatten(), as_tuple=False).flatten()
+        return indexer
+
+    def _optim_step(self, name, rms_name, indexer, lr, beta, epsilon, optim):
+        p = getattr(self, name)
+        if optim == "rmsprop":
+            rms = getattr(self, rms_name)
+            if rms is None or rms.shape != p.shape:
+                rms = torch.zeros_like(p.data)
+                setattr(self, rms_name, rms)
+            _C.rmsprop_step(p.data, rms, p.grad, indexer, beta, lr, epsilon, -1e9, lr)
+        elif optim == "sgd":
+            _C.sgd_step(p.data, p.grad, indexer, lr, lr)
+        else:
+            raise NotImplementedError(f"Unsupported optimizer {optim}")
+
+    def optim_density_step(self, lr: float, beta: float = 0.9, epsilon: float = 1e-8, optim: str = "rmsprop"):
+        self._optim_step("density_data", "density_rms", self._maybe_convert_sparse_grad_indexer(),
+                         lr, beta, epsilon, optim)
+
+    def optim_surface_step(self, lr: float, beta: float = 0.9, epsilon: float = 1e-8, optim: str = "rmsprop"):
+        if self.surface_data is None:
+            return
+        self._optim_step("surface_data", "surface_rms", self._maybe_convert_sparse_grad_indexer(),
+                         lr, beta, epsilon, optim)
+
+    def optim_sh_step(self, lr: float, beta: float = 0.9, epsilon: float = 1e-8, optim: str = "rmsprop"):
+        self._optim_step("sh_data", "sh_rms", self._maybe_convert_sparse_grad_indexer(sh=True),
+                         lr, beta, epsilon, optim)
+
+    def optim_fake_sample_std_step(self, lr: float, beta: float = 0.9, epsilon: float = 1e-8,
+                                   optim: str = "rmsprop", lambda_l2: float = 0.0, lambda_l1: float = 0.0):
+        """:6058-6107.  The reference passes `self.surface_rms` as the RMS state here (a slip: it
+        reads and overwrites surface_rms[0]); this mirror keeps a dedicated state tensor."""
+        if self.fake_sample_std is None:
+            return
+        p = self.fake_sample_std
+        p.grad += 2 * lambda_l2 * p.data + lambda_l1 * torch.sign(p.data)
+        self._optim_step("fake_sample_std", "fake_sample_std_rms",
+                         torch.empty((), device=p.device), lr, beta, epsilon, optim)
+
+    # ---- checkpointing (:4693-4838): same .npz keys ----
+    def save(self, path: str, compress: bool = False, step_id: int = 0):
+        data = dict(radius=self.radius.numpy(), center=self.center.numpy(),
+                    links=self.links.cpu().numpy(), density_data=self.density_data.data.cpu().numpy(),
+                    sh_data=self.sh_data.data.cpu().numpy().astype(np.float16),
+                    basis_type=self.basis_type, surface_type=self.surface_type, step_id=step_id)
+        if self.surface_data is not None:
+            data["surface_data"] = self.surface_data.data.cpu().numpy()
+            data["level_set_data"] = self.level_set_data.cpu().numpy()
+        if self.fake_sample_std is not None:
+            data["fake_sample_std"] = self.fake_sample_std.data.cpu().numpy() \
+                if torch.is_tensor(self.fake_sample_std) else self.fake_sample_std
+        (np.savez_compressed if compress else np.savez)(path, **data)
+
+    @classmethod
+    def load(cls, path: str, device: Union[torch.device, str] = "cpu"):
+        z = np.load(path)
+        links = z["links"]
+        surface_type = int(z["surface_type"]) if "surface_type" in z else CONSTANTS["SURFACE_TYPE_NONE"]
+        grid = cls(1, radius=z["radius"].tolist(), center=z["center"].tolist(),
+                   basis_dim=z["sh_data"].shape[1] // 3, device="cpu", surface_type=surface_type,
+                   trainable_fake_sample_std="fake_sample_std" in z and np.ndim(z["fake_sample_std"]) > 0)
+        grid.capacity = z["density_data"].shape[0]
+        grid.density_data = nn.Parameter(torch.from_numpy(z["density_data"].astype(np.float32)).to(device))
+        grid.sh_data = nn.Parameter(torch.from_numpy(z["sh_data"].astype(np.float32)).to(device))
+        grid.links = torch.from_numpy(links).to(device)
+        if "surface_data" in z:
+            grid.surface_data = nn.Parameter(torch.from_numpy(z["surface_data"].astype(np.float32)).to(device))
+            grid.level_set_data = torch.from_numpy(z["level_set_data"].astype(np.float32)).to(device)
+        if grid.fake_sample_std is not None:
+            grid.fake_sample_std = nn.Parameter(torch.from_numpy(
+                np.asarray(z["fake_sample_std"], np.float32).reshape(1, 1)).to(device))
+        grid.step_id = int(z["step_id"]) if "step_id" in z else 0
+        return grid
+
+    def __repr__(self):
+        return (f"alphasurf_amd.SparseGrid(basis_dim={self.basis_dim}, reso={list(self.links.shape)}, "
+                f"capacity={self.sh_data.size(0)})")
+
+
+def _add_next_rows():
+    rows = {
+        "N2": ["inplace_tv_grad", "inplace_tv_surface_grad", "inplace_surface_normal_grad",
+               "inplace_alpha_surf_sparsify_grad", "inplace_surface_eikonal_grad", "inplace_tv_color_grad",
+               "inplace_surface_sign_change_grad", "inplace_tv_lumisphere_grad", "inplace_tv_background_grad",
+               "inplace_l2_color_grad", "inplace_alpha_lap_grad", "_get_rand_cells_non_empty", "tv_basis"],
+        "N3": ["volume_render_depth", "volume_render_depth_image", "volume_render_normal_image",
+               "volume_render_alpha_image", "extract_pts"],
+        "N4": ["init_surface_from_density", "accelerate", "resample", "resample_surface", "prune_grid",
+               "sparsify_background", "extract_mesh", "reinit_learned_bases", "optim_basis_step",
+               "optim_background_step", "sample", "_surface_render_gradcheck_lerp",
+               "_surface_norm_match_loss_grad_check", "_surface_viscosity_loss_grad_check",
+               "_eval_learned_bases", "_eval_basis_mlp"],
+    }
+    for row, names in rows.items():
+        for name in names:
+            def stub(self, *a, _n=name, _r=row, **k):
+                _next_row(_r, f"SparseGrid.{_n}")
+            stub.__name__ = name
+            setattr(SparseGrid, name, stub)
+
+
+_add_next_rows()
+
+__all__ = ["SparseGrid", "Rays", "RayVoxIntersecs", "Camera", "RenderOptions"] + list(CONSTANTS)

@@ -47,3 +47,23 @@ def sphere_surface_init(links):
     out = np.zeros((int(links.max()) + 1, 1), np.float32)
     out[links.reshape(-1).astype(np.int64), 0] = dists[np.arange(dists.shape[0]), pick]
     return out
+
+
+def sphere_bound_links(links):
+    """use_sphere_bound (svox2.py:653-679): keep only vertices inside the unit sphere (plus a
+    sqrt(3)/reso margin) and renumber the kept rows in the order of their original row ids."""
+    reso = links.shape
+    gsz = np.asarray(reso, np.float32)
+    axes = [(np.arange(r, dtype=np.float32) - 0.5) for r in reso]
+    X, Y, Z = np.meshgrid(*axes, indexing="ij")
+    pts = np.stack([X, Y, Z], -1).reshape(-1, 3)
+    pts = (1.0 / gsz - 1.0) + pts * (2.0 / gsz)
+    keep = np.linalg.norm(pts, axis=-1) <= 1.0 + (3 ** 0.5) / gsz.max()
+    flat = links.reshape(-1).astype(np.int64)
+    n3 = flat.shape[0]
+    data_mask = np.zeros(n3, np.int32)
+    data_mask[flat[keep]] = 1
+    rank = np.cumsum(data_mask) - 1
+    out = np.full(n3, -1, np.int32)
+    out[keep] = rank[flat[keep]].astype(np.int32)
+    return out.reshape(reso)

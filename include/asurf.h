@@ -222,6 +222,20 @@ int asurf_volume_render_surface_fused(const asurf_grid* grid, const asurf_rays* 
 int asurf_test_cubic_root_grad(const double* fs, const int32_t* st_ids, float* grad_fs,
                                float* st, int64_t n, int32_t use_vieta, void* stream);
 
+/* void rmsprop_step(data, rms, grad, indexer, beta, lr, epsilon, minval, lr_last)
+ * void sgd_step(data, grad, indexer, lr, lr_last)
+ *   svox2.cpp (REG rmsprop_step / sgd_step), optim_kernel.cu:154-265.  data/rms/grad are
+ *   [n_rows, n_cols] f32.  The reference's `indexer` tensor becomes: mask != NULL -> bool row
+ *   mask [n_rows]; else indices != NULL -> int64 row ids [n_indices] (n_indices == 0 is a no-op,
+ *   as in the reference); both NULL -> every row.  rms: rms==0 ? g^2 :
+ *   lerp(g^2, rms, beta); data = max(data - lr*g/(sqrt(rms)+eps), minval); grad = 0.  The last
+ *   column uses lr_last (lr_last < 0 means lr). */
+int asurf_rmsprop_step(float* data, float* rms, float* grad, int64_t n_rows, int32_t n_cols,
+                       const uint8_t* mask, const int64_t* indices, int64_t n_indices, float beta,
+                       float lr, float epsilon, float minval, float lr_last, void* stream);
+int asurf_sgd_step(float* data, float* grad, int64_t n_rows, int32_t n_cols, const uint8_t* mask,
+                   const int64_t* indices, int64_t n_indices, float lr, float lr_last, void* stream);
+
 /* Measurement hooks (no reference counterpart; used by bench.py).  When enabled, the
  * surf_trav launchers bracket each kernel of a call with hipEvents on the call's stream.
  * asurf_profile_read() waits for the last call and returns, in milliseconds,
