@@ -15,6 +15,7 @@
 
 #include "asurf_kernels.h"
 #include "asurf_optim.h"
+#include "asurf_pipeline.h"
 
 namespace {
 
@@ -38,8 +39,13 @@ struct MaskLayout {
     size_t off_fine_work, off_fine_live, off_coarse_work, off_coarse_live;
     size_t off_cache_a, off_cache_w, off_cache_t, off_cache_n;
     size_t off_rec_v, off_rec_m, off_rec_n;
+    size_t off_p_items, off_p_citem, off_p_nitems, off_p_cut, off_p_counters, off_p_pool;
+    int pool_shard_cap;
     size_t total;
 };
+
+// work voxels per ray the three-kernel forward keeps; longer rays go to the one-kernel path
+constexpr int kPipeC1 = 32;
 
 // per-ray capacity of the sample records the fused forward leaves for the replaying
 // backward; rays with more samples fall back to the walking backward kernel
@@ -80,6 +86,22 @@ MaskLayout layout_for(const int32_t size[3], int64_t n_rays, int32_t M) {
     off = align_up(off + rplane, 256);
     L.off_rec_n = off;
     off = align_up(off + (size_t)(n_rays > 0 ? n_rays : 0) * 4, 256);
+    // three-kernel forward pipeline (asurf_pipeline.h)
+    const size_t nr = (size_t)(n_rays > 0 ? n_rays : 0);
+    const size_t iplane = (size_t)kPipeC1 * nr * 4;
+    L.off_p_items = off;
+    off = align_up(off + iplane, 256);
+    L.off_p_citem = off;
+    off = align_up(off + iplane, 256);
+    L.off_p_nitems = off;
+    off = align_up(off + nr * 4, 256);
+    L.off_p_cut = off;
+    off = align_up(off + nr * 4, 256);
+    L.off_p_counters = off;  // n_flagged + kPoolShards cursors
+    off = align_up(off + (1 + kPoolShards) * 4, 256);
+    L.pool_shard_cap = (int)((8 * nr + kPoolShards - 1) / kPoolShards) + 64;
+    L.off_p_pool = off;
+    off = align_up(off + (size_t)L.pool_shard_cap * kPoolShards * sizeof(CandRec), 256);
     L.total = off;
     return L;
 }
@@ -100,7 +122,9 @@ int check_grid(const asurf_grid* g) {
     if (g->background_nlayers != 0)
         return fail(ASURF_E_UNSUPPORTED, "MSI background layers are outside this build's scope");
     for (int i = 0; i < 3; ++i)
-        if (g->size[i] < 2) return fail(ASURF_E_INVALID, "links.shape[%d] = %d < 2", i, g->size[i]);
+        if (g->size[i] < 2 || g->size[i] > 1024)
+            return fail(ASURF_E_INVALID, "links.shape[%d] = %d outside [2, 1024] (voxel coordinates are "
+                        "packed 10 bits per axis)", i, g->size[i]);
     if ((int64_t)g->size[0] * g->size[1] * g->size[2] >= (1ll << 31))
         return fail(ASURF_E_INVALID, "links has >= 2^31 elements");
     if (g->capacity <= 0) return fail(ASURF_E_INVALID, "capacity must be > 0");
@@ -238,9 +262,22 @@ int prepare(const asurf_grid* grid, const asurf_rays* rays, const asurf_render_o
     return launch_error("k_build_masks");
 }
 
+// The three-kernel forward is used unless the call needs what only the one-kernel path keeps:
+// exact V_t/V_a/S counters (a ray stopped by stop_thresh must not be walked further),
+// stop_thresh > 1 (the reference then stops at the first voxel that passes the gates even if
+// it holds no sample), or more level sets than a record encodes.
+bool use_pipeline(const asurf_grid* grid, const asurf_render_options* opt, const uint64_t* counters) {
+    const char* off = getenv("ASURF_NO_PIPELINE");
+    if (off && atoi(off)) return false;
+    return counters == nullptr && !(opt->stop_thresh > 1.f) && grid->level_set_num <= 32 &&
+           grid->size[0] <= 1024 && grid->size[1] <= 1024 && grid->size[2] <= 1024;
+}
+
+// The one-kernel forward.  `pipeline` = the three-kernel pipeline runs first and this kernel
+// only renders the rays it handed back (k_forward's ray_filter).
 template <int B>
 int run_forward(const Launch& L, const asurf_rays* rays, float* rgb_out, int M, bool cache,
-                bool record, uint64_t* counters) {
+                bool record, uint64_t* counters, bool pipeline) {
     float* ca = reinterpret_cast<float*>(L.ws + L.ML.off_cache_a);
     float* cw = reinterpret_cast<float*>(L.ws + L.ML.off_cache_w);
     float* ct = reinterpret_cast<float*>(L.ws + L.ML.off_cache_t);
@@ -249,10 +286,42 @@ int run_forward(const Launch& L, const asurf_rays* rays, float* rgb_out, int M, 
     int* rm = record ? reinterpret_cast<int*>(L.ws + L.ML.off_rec_m) : nullptr;
     int* rn = record ? reinterpret_cast<int*>(L.ws + L.ML.off_rec_n) : nullptr;
     auto* cnt = reinterpret_cast<unsigned long long*>(counters);
+    const long long Q = rays->n_rays;
+    const int* filter = nullptr;
+    if (pipeline) {
+        PipeBuf P;
+        P.items = reinterpret_cast<int*>(L.ws + L.ML.off_p_items);
+        P.citem = reinterpret_cast<int*>(L.ws + L.ML.off_p_citem);
+        P.n_items = reinterpret_cast<int*>(L.ws + L.ML.off_p_nitems);
+        P.cut = reinterpret_cast<int*>(L.ws + L.ML.off_p_cut);
+        P.n_flagged = reinterpret_cast<int*>(L.ws + L.ML.off_p_counters);
+        P.pool_count = P.n_flagged + 1;
+        P.pool = reinterpret_cast<CandRec*>(L.ws + L.ML.off_p_pool);
+        P.shard_cap = L.ML.pool_shard_cap;
+        P.C1 = kPipeC1;
+        if (hipMemsetAsync(P.n_flagged, 0, (1 + kPoolShards) * sizeof(int), L.stream) != hipSuccess)
+            return fail(ASURF_E_LAUNCH, "hipMemsetAsync failed");
+        if (L.coarse_in_lds)
+            hipLaunchKernelGGL((k_walk<true>), L.ray_grid, dim3(kBlock), L.dyn_lds, L.stream, L.g, L.o,
+                               rays->origins, rays->dirs, Q, P, record ? 1 : 0);
+        else
+            hipLaunchKernelGGL((k_walk<false>), L.ray_grid, dim3(kBlock), 0, L.stream, L.g, L.o,
+                               rays->origins, rays->dirs, Q, P, record ? 1 : 0);
+        hipLaunchKernelGGL(k_geom, dim3(L.ray_grid.x, kPipeC1), dim3(kBlock), 0, L.stream, L.g, L.o,
+                           rays->origins, rays->dirs, Q, P);
+        if (cache)
+            hipLaunchKernelGGL((k_comp<B, true>), L.ray_grid, dim3(kBlock), 0, L.stream, L.g, L.o,
+                               rays->dirs, Q, P, rgb_out, M, ca, cw, ct, cn, rv, rm, rn, kRecDepth);
+        else
+            hipLaunchKernelGGL((k_comp<B, false>), L.ray_grid, dim3(kBlock), 0, L.stream, L.g, L.o,
+                               rays->dirs, Q, P, rgb_out, M, ca, cw, ct, cn, rv, rm, rn, kRecDepth);
+        if (int e = launch_error("forward pipeline")) return e;
+        filter = P.n_items;
+    }
 #define ASURF_FWD(CACHE, COUNT, CLDS)                                                            \
     hipLaunchKernelGGL((k_forward<B, CACHE, COUNT, CLDS>), L.ray_grid, dim3(kBlock), L.dyn_lds,  \
                        L.stream, L.g, L.o, rays->origins, rays->dirs, (long long)rays->n_rays,   \
-                       rgb_out, M, ca, cw, ct, cn, rv, rm, rn, kRecDepth, cnt)
+                       rgb_out, M, ca, cw, ct, cn, rv, rm, rn, kRecDepth, filter, cnt)
 #define ASURF_FWD2(CACHE, COUNT)             \
     do {                                     \
         if (L.coarse_in_lds) ASURF_FWD(CACHE, COUNT, true); \
@@ -342,7 +411,8 @@ int asurf_volume_render_surf_trav(const asurf_grid* grid, const asurf_rays* rays
     if (rays->n_rays == 0) return 0;
     if (!rgb_out) return fail(ASURF_E_INVALID, "rgb_out is NULL");
     int rc = 0;
-    ASURF_DISPATCH_B(grid->basis_dim, run_forward<B_>(L, rays, rgb_out, 0, false, false, counters));
+    const bool pipe = use_pipeline(grid, opt, counters);
+    ASURF_DISPATCH_B(grid->basis_dim, run_forward<B_>(L, rays, rgb_out, 0, false, false, counters, pipe));
     return rc;
 }
 
@@ -409,7 +479,8 @@ int asurf_volume_render_surf_trav_fused(const asurf_grid* grid, const asurf_rays
     const char* norec = getenv("ASURF_NO_REPLAY");
     const bool replay = !(norec && atoi(norec)) && grid->level_set_num <= 32 &&
                         (opt->stop_thresh <= 0.f || opt->stop_thresh >= 2e-8f);
-    ASURF_DISPATCH_B(grid->basis_dim, run_forward<B_>(L, rays, rgb_out, M, true, replay, counters));
+    const bool pipe = use_pipeline(grid, opt, counters);
+    ASURF_DISPATCH_B(grid->basis_dim, run_forward<B_>(L, rays, rgb_out, M, true, replay, counters, pipe));
     if (rc) return rc;
     if (replay) {
         ASURF_DISPATCH_B(grid->basis_dim, run_backward<B_>(L, rays, loss, G, fused->rgb_gt, rgb_out, M, true, 1));

@@ -17,6 +17,12 @@
 #pragma once
 #include "asurf_device.h"
 
+// minimum waves per SIMD the ray kernels are compiled for (__launch_bounds__ 2nd argument):
+// caps the VGPR allocation at 512 / ASURF_MIN_WAVES
+#ifndef ASURF_MIN_WAVES
+#define ASURF_MIN_WAVES 1
+#endif
+
 namespace asurf {
 
 // ------------------------------------------------------------------------------------
@@ -490,12 +496,12 @@ __device__ __forceinline__ void scatter8(float* out, uint8_t* mask, const int* l
 // are valid, the rest are implicit zeros.
 // ------------------------------------------------------------------------------------
 template <int B, bool CACHE, bool COUNT, bool CLDS>
-__global__ void __launch_bounds__(kBlock)
+__global__ void __launch_bounds__(kBlock, ASURF_MIN_WAVES)
 k_forward(KGrid g, KOpt o, const float* __restrict__ origins, const float* __restrict__ dirs,
           long long Q, float* __restrict__ rgb_out, int M, float* __restrict__ cache_a,
           float* __restrict__ cache_w, float* __restrict__ cache_t, int* __restrict__ cache_n,
           int* __restrict__ rec_v, int* __restrict__ rec_m, int* __restrict__ rec_n, int R,
-          unsigned long long* counters) {
+          const int* __restrict__ ray_filter, unsigned long long* counters) {
     extern __shared__ unsigned int s_coarse[];
     __shared__ float s_sph[kBlock * kSphPad];
     __shared__ LaneRec s_rec[kBlock];
@@ -516,7 +522,9 @@ k_forward(KGrid g, KOpt o, const float* __restrict__ origins, const float* __res
     const LaneRec* rec_wave = s_rec + (tid & ~63);
 
     const long long q = (long long)blockIdx.x * kBlock + tid;
-    const bool valid = q < Q;
+    // ray_filter: render only the rays the three-kernel pipeline handed back (entry < 0)
+    const bool valid = (q < Q) && (ray_filter == nullptr || ray_filter[q] < 0);
+    if (!__any(valid)) return;
     Ray r;
     r.tmin = 1.f;
     r.tmax = 0.f;
@@ -738,7 +746,7 @@ k_forward(KGrid g, KOpt o, const float* __restrict__ origins, const float* __res
 //          rays whose record overflowed (rec_n < 0) are left to a second, walking launch that
 //          is restricted to them through `ray_filter`.
 template <int B, bool FUSED, bool CLDS, bool REC>
-__global__ void __launch_bounds__(kBlock)
+__global__ void __launch_bounds__(kBlock, ASURF_MIN_WAVES)
 k_backward(KGrid g, KOpt o, KLoss L, KGrads G, const float* __restrict__ origins,
            const float* __restrict__ dirs, long long Q, const float* __restrict__ grad_in,
            const float* __restrict__ color_cache, int M, const float* __restrict__ cache_a,

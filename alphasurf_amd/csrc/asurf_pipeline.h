@@ -1,0 +1,330 @@
+// asurf_pipeline.h -- the forward pass as three dense kernels (gfx950, wave64).
+//
+//   k_walk : one ray per lane, nothing but the DDA + occupancy-bit tests (few registers, many
+//            waves per SIMD).  Work voxels go to a per-ray list [C1][Q] (lane-coalesced).
+//   k_geom : one WORK VOXEL per lane -- every lane of a wave is busy no matter how the work
+//            voxels are spread over rays.  Gathers the 8 corners, forms and solves the cubic
+//            (f64), validates the roots and leaves up to 3 sample candidates per voxel in a
+//            compact pool.
+//   k_comp : one ray per lane again, for what is inherently sequential along a ray: the
+//            sigma gate, truncation window, compositing, the sample cache of the fused losses
+//            and the records the replaying backward kernel consumes.  Shading stays
+//            wave-cooperative (coop_shade_fwd).
+//
+// Rays with more than C1 work voxels or a voxel with more than 3 candidates are flagged and
+// rendered by the single-kernel path (k_forward with ray_filter); results are identical.
+#pragma once
+#include "asurf_kernels.h"
+
+namespace asurf {
+
+struct CandRec {  // 32 bytes
+    float px, py, pz;  // position inside the voxel
+    float ts;          // ray parameter of the sample (cache of the fused losses)
+    float raw;         // trilinear raw opacity
+    float ext;         // fake samples: signed distance to the nearest level set (std-normalised)
+    int meta;          // bit0 fake, bits1-2 root index, bits3-7 level-set index
+    int pad;
+};
+
+struct PipeBuf {
+    int* items;      // [C1][Q] packed work voxels
+    int* citem;      // [C1][Q] (pool base << 2) | candidate count
+    int* n_items;    // [Q]; < 0: ray left to the single-kernel path
+    int* cut;        // [Q] ordinal of the first work voxel the reference's BACKWARD would skip
+    int* n_flagged;  // [1]
+    int* pool_count; // [kPoolShards] one allocation cursor per shard of the candidate pool
+    CandRec* pool;
+    int shard_cap;   // records per shard
+    int C1;
+};
+
+// The candidate pool is cut into shards with their own cursors so that the allocating
+// atomics of k_geom do not serialise on one address.
+constexpr int kPoolShards = 256;
+
+// ------------------------------------------------------------------------------------
+template <bool CLDS>
+__global__ void __launch_bounds__(kBlock)
+k_walk(KGrid g, KOpt o, const float* __restrict__ origins, const float* __restrict__ dirs,
+       long long Q, PipeBuf P, int want_cut) {
+    extern __shared__ unsigned int s_coarse[];
+    const int tid = threadIdx.x;
+    if constexpr (CLDS) {
+        for (int i = tid; i < g.coarse_words; i += kBlock) s_coarse[i] = g.coarse[i];
+        __syncthreads();
+    }
+    const long long q = (long long)blockIdx.x * kBlock + tid;
+    if (q >= Q) return;
+    Ray r;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        r.o[k] = origins[3 * q + k];
+        r.d[k] = dirs[3 * q + k];
+    }
+    setup_ray(g, o, r);
+    bool active = !(r.tmin > r.tmax);
+    int cnt = 0;
+    int cutv = 0x7fffffff;
+    if (active) {
+        Walk w;
+        walk_init(g, r, w);
+        while (active) {
+            walk_step(g, r, w);
+            const bool hit = walk_test<CLDS>(g, s_coarse, w);
+            active = (w.t <= r.tmax);
+            if (hit) {
+                if (cnt < P.C1) P.items[(size_t)cnt * Q + q] = pack_voxel(w.vx, w.vy, w.vz);
+                ++cnt;
+            } else if (want_cut && active && (w.t + o.step_size > r.tmax) && cutv == 0x7fffffff) {
+                if (!links_present(g, w)) cutv = cnt;  // surf_trav.cu:1935-1936
+            }
+        }
+    }
+    if (cnt > P.C1) {
+        cnt = -1;
+        atomicAdd(P.n_flagged, 1);
+    }
+    P.n_items[q] = cnt;
+    P.cut[q] = cutv;
+}
+
+// ------------------------------------------------------------------------------------
+// grid = (ceil(Q / 256), C1): block row s handles work voxel s of 256 consecutive rays
+__global__ void __launch_bounds__(kBlock)
+k_geom(KGrid g, KOpt o, const float* __restrict__ origins, const float* __restrict__ dirs,
+       long long Q, PipeBuf P) {
+    const int s = blockIdx.y;
+    const long long q = (long long)blockIdx.x * kBlock + threadIdx.x;
+    const bool mine = (q < Q) && (s < P.n_items[q]);  // also skips flagged rays (n_items < 0)
+    if (!__any(mine)) return;
+    CandRec c[3];
+    int nc = 0;
+    bool overflow = false;
+  if (mine) {
+    Ray r;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        r.o[k] = origins[3 * q + k];
+        r.d[k] = dirs[3 * q + k];
+    }
+    setup_ray(g, o, r);
+    Vox v;
+    load_voxel(g, r, P.items[(size_t)s * Q + q], v);
+    bool vox_has_sample = false, vox_has_surf = false;
+    for (int li = 0; li < g.level_set_num; ++li) {  // surf_trav.cu:273-419 up to the sigma gate
+        const float lvf = g.level_set[li];
+        if (lvf < v.smin || lvf > v.smax) continue;
+        vox_has_surf = true;
+        double st[3] = {-1, -1, -1};
+        solve_cubic_vieta(v.fs[0] - (double)lvf, v.fs[1], v.fs[2], v.fs[3], st);
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            if (!(st[j] > 0)) continue;
+            float pos[3];
+            if (!root_position(r, v, st[j], pos)) continue;
+            vox_has_sample = true;
+            if (o.only_outward_intersect) {
+                float sg[3];
+                field_grad(v.surf, pos, sg);
+                const float ndd = -(sg[0] * r.d[0] + sg[1] * r.d[1] + sg[2] * r.d[2]);
+                if (ndd >= 0.f) continue;
+            }
+            if (nc < 3) {
+                CandRec& cr = (nc == 0) ? c[0] : (nc == 1) ? c[1] : c[2];
+                cr.px = pos[0];
+                cr.py = pos[1];
+                cr.pz = pos[2];
+                cr.ts = (float)((double)v.t_close + st[j]);
+                cr.raw = trilerp8(v.dens, pos);
+                cr.ext = 0.f;
+                cr.meta = (li << 3) | (j << 1);
+                cr.pad = 0;
+                ++nc;
+            } else {
+                overflow = true;
+            }
+        }
+    }
+    // fake sample (surf_trav.cu:423-503): everything that does not depend on earlier samples
+    if (o.surf_fake_sample && !vox_has_sample && (!o.limited_fake_sample || vox_has_surf) &&
+        ((v.t_far - v.t_close) > o.surf_fake_sample_min_vox_len)) {
+        float pos[3];
+        fake_position(r, v, pos);
+        const float raw = trilerp8(v.dens, pos);
+        if (raw > o.sigma_thresh) {
+            double miu, sd;
+            c[0].px = pos[0];
+            c[0].py = pos[1];
+            c[0].pz = pos[2];
+            c[0].ts = (v.t_far + v.t_close) / 2.f;
+            c[0].raw = raw;
+            c[0].ext = fake_distance(g, o, v, pos, &miu, &sd);
+            c[0].meta = 1;
+            c[0].pad = 0;
+            nc = 1;
+        }
+    }
+    if (overflow) nc = 0;
+  }
+    // one pool allocation per wave: exclusive prefix of the lanes' counts + a single atomic
+    const int lane = threadIdx.x & 63;
+    int incl = nc;
+#pragma unroll
+    for (int dlt = 1; dlt < 64; dlt <<= 1) {
+        const int t = __shfl_up(incl, dlt);
+        if (lane >= dlt) incl += t;
+    }
+    const int total = __shfl(incl, 63);
+    const int shard = (int)((blockIdx.x + blockIdx.y * 37u + (threadIdx.x >> 6) * 11u) % kPoolShards);
+    int base0 = 0;
+    if (total > 0) {
+        if (lane == 0) base0 = atomicAdd(&P.pool_count[shard], total);
+        base0 = __shfl(base0, 0);
+    }
+    if (!mine) return;
+    int packed = 0;
+    const int rel = base0 + incl - nc;
+    if (overflow || (nc > 0 && rel + nc > P.shard_cap)) {
+        P.n_items[q] = -1;  // later slots of this ray may still run; k_comp ignores the ray
+        atomicAdd(P.n_flagged, 1);
+    } else if (nc > 0) {
+        const int base = shard * P.shard_cap + rel;
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+            if (i < nc) P.pool[base + i] = c[i];
+        packed = (base << 2) | nc;
+    }
+    P.citem[(size_t)s * Q + q] = packed;
+}
+
+// ------------------------------------------------------------------------------------
+template <int B, bool CACHE>
+__global__ void __launch_bounds__(kBlock)
+k_comp(KGrid g, KOpt o, const float* __restrict__ dirs, long long Q, PipeBuf P,
+       float* __restrict__ rgb_out, int M, float* __restrict__ cache_a, float* __restrict__ cache_w,
+       float* __restrict__ cache_t, int* __restrict__ cache_n, int* __restrict__ rec_v,
+       int* __restrict__ rec_m, int* __restrict__ rec_n, int R) {
+    __shared__ float s_sph[kBlock * kSphPad];
+    __shared__ LaneRec s_rec[kBlock];
+    const int tid = threadIdx.x;
+    const float* sph_wave = s_sph + (tid & ~63) * kSphPad;
+    const LaneRec* rec_wave = s_rec + (tid & ~63);
+    const long long q = (long long)blockIdx.x * kBlock + tid;
+    const bool in_range = q < Q;
+    const int n = in_range ? P.n_items[q] : 0;
+    const bool valid = in_range && n >= 0;  // flagged rays belong to the single-kernel path
+    if (valid) {
+        float d[3] = {dirs[3 * q], dirs[3 * q + 1], dirs[3 * q + 2]};
+        float sph[B];
+        eval_sh<B>(d, sph);
+#pragma unroll
+        for (int k = 0; k < B; ++k) s_sph[tid * kSphPad + k] = sph[k];
+    }
+    const bool do_rec = CACHE && (rec_v != nullptr);
+    const int cutv = (valid && do_rec) ? P.cut[q] : 0x7fffffff;
+    float outv[3] = {0.f, 0.f, 0.f};
+    float log_transmit = 0.f;
+    int sample_i = 0, intersect_i = -1, rec_cnt = 0;
+    bool rec_over = false;
+    int n_left = valid ? n : 0;  // becomes 0 when stop_thresh ends the ray
+
+    for (int s = 0; __any(s < n_left); ++s) {
+        const bool have = s < n_left;
+        const int ci = have ? P.citem[(size_t)s * Q + q] : 0;
+        const int nc = ci & 3;
+        if (!__any(nc > 0)) continue;
+        const int base = ci >> 2;
+        int pv = 0;
+        bool links_loaded = false;
+        bool composited = false;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const bool hc = c < nc;
+            if (!__any(hc)) break;
+            CandRec cr;
+            cr.meta = 0;
+            cr.px = cr.py = cr.pz = cr.ts = cr.raw = cr.ext = 0.f;
+            if (hc) cr = P.pool[base + c];
+            const bool fake = hc && (cr.meta & 1);
+            bool shade = false;
+            float a = 0.f;  // re-weighted alpha
+            if (hc && !fake) {  // surf_trav.cu:369-385
+                ++intersect_i;
+                if (cr.raw > o.sigma_thresh) {
+                    const float alpha = alpha_act(cr.raw, o.alpha_activation_type);
+                    const float rw = o.truncated_vol_render
+                                         ? trunc_rw((float)intersect_i, g.trunc_a, o.trunc_vol_weight_min)
+                                         : 1.f;
+                    a = alpha * rw;
+                    shade = true;
+                }
+            } else if (fake) {  // :455-507 (the sigma gate was applied by k_geom)
+                float alpha = alpha_act(cr.raw, o.alpha_activation_type);
+                alpha = alpha * expf((float)(-.5 * (double)sqrf(cr.ext / g.fake_sample_std)));
+                const float rw = o.truncated_vol_render
+                                     ? trunc_rw((float)intersect_i, g.trunc_a, o.trunc_vol_weight_min)
+                                     : 1.f;
+                a = alpha * rw;
+                shade = true;
+            }
+            if (shade && !links_loaded) {
+                pv = P.items[(size_t)s * Q + q];
+                const int vx = pv >> 20, vy = (pv >> 10) & 1023, vz = pv & 1023;
+                const int32_t* p = g.links + ((size_t)vx * g.offx + (size_t)vy * g.offy + vz);
+                s_rec[tid].link[0] = p[0];
+                s_rec[tid].link[1] = p[1];
+                s_rec[tid].link[2] = p[g.offy];
+                s_rec[tid].link[3] = p[g.offy + 1];
+                s_rec[tid].link[4] = p[g.offx];
+                s_rec[tid].link[5] = p[g.offx + 1];
+                s_rec[tid].link[6] = p[g.offx + g.offy];
+                s_rec[tid].link[7] = p[g.offx + g.offy + 1];
+                links_loaded = true;
+            }
+            const unsigned long long need = __ballot(shade);
+            if (!need) continue;
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            float color[3] = {0.f, 0.f, 0.f};
+            const float pos[3] = {cr.px, cr.py, cr.pz};
+            coop_shade_fwd<B>(g, need, rec_wave, sph_wave, pos, color);
+            if (!shade) continue;
+            const float pcnt = -1 * logf(1 - a);  // :397-404
+            const float weight = expf(log_transmit) * (1.f - expf(-pcnt));
+            log_transmit -= pcnt;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) outv[k] += weight * fmaxf(color[k] + 0.5f, 0.f);
+            composited = true;
+            if (CACHE && sample_i < M && (!fake || o.fake_sample_l_dist)) {
+                const size_t idx = (size_t)sample_i * Q + q;
+                cache_a[idx] = a;
+                cache_w[idx] = weight;
+                cache_t[idx] = cr.ts;
+                sample_i += 1;
+            }
+            if (do_rec && s < cutv) {
+                if (rec_cnt < R) {
+                    rec_v[(size_t)rec_cnt * Q + q] = pv;
+                    rec_m[(size_t)rec_cnt * Q + q] = ((intersect_i + 1) << 8) | (cr.meta & 0xff);
+                    ++rec_cnt;
+                } else {
+                    rec_over = true;
+                }
+            }
+        }
+        // once per voxel (:544-547); log_transmit only changes where something was composited
+        if (composited && expf(log_transmit) < o.stop_thresh) {
+            log_transmit = -1e3f;
+            n_left = 0;
+        }
+    }
+    if (valid) {
+        const float bg = expf(log_transmit) * o.background_brightness;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) rgb_out[3 * q + k] = outv[k] + bg;
+        if (CACHE) cache_n[q] = sample_i;
+        if (do_rec) rec_n[q] = rec_over ? -1 : rec_cnt;
+    }
+}
+
+}  // namespace asurf

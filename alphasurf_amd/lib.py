@@ -9,7 +9,8 @@ import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
-LIB_PATH = os.path.join(CSRC, "libasurf_hip.so")
+# ASURF_LIB: development override to A/B another build of the same sources
+LIB_PATH = os.environ.get("ASURF_LIB") or os.path.join(CSRC, "libasurf_hip.so")
 
 c_f = C.POINTER(C.c_float)
 c_i = C.POINTER(C.c_int32)

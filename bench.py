@@ -35,6 +35,8 @@ def parse():
     ap.add_argument("--shuffle", action="store_true", help="training-order (shuffled) rays")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-rays", type=int, default=40000)
+    ap.add_argument("--exchange", default="dense", choices=["dense", "sparse", "auto"],
+                    help="gradient exchange for --gpus > 1 (alphasurf_amd/dist.py)")
     return ap.parse_args()
 
 
@@ -63,7 +65,7 @@ def main():
     dev = torch.device("cuda", local_rank if world > 1 else 0)
     torch.cuda.set_device(dev)
 
-    from alphasurf_amd import csrc_api as _C, lib as _lib, synth
+    from alphasurf_amd import csrc_api as _C, dist as adist, lib as _lib, synth
 
     # ---- synthetic workload (seeded; identical grid on every rank) ----
     R, B = args.reso, args.basis_dim
@@ -105,18 +107,23 @@ def main():
 
     def step(counters=None):
         gr.mask_out.zero_()  # the reference allocates a fresh sparse_grad_indexer per call (svox2.py:3535)
+        if world > 1:
+            # the exchange sums whatever the buffers hold, so they must hold this step only
+            # (in training the optimizer kernels zero them, optim_kernel.cu:24)
+            gr.grad_sh_out.zero_()
+            gr.grad_density_out.zero_()
+            gr.grad_surface_out.zero_()
         _C.volume_render_surf_trav_fused(
             g, r, opt, gt, 0.0, 0.0, 0.0, True, False, F["lambda_l2"], F["lambda_l1"], 0.0,
             F["lambda_l_entropy"], False, 0.0, 0.0, 0.0, 0.0, F["l_di_alpha_thresh"],
             F["surf_sparse_alpha_thresh"], 0.0, 0.0, F["lambda_conv_mode_samp"], M, rgb, gr,
             global_n_rays=Q_global, counters=counters)
         if world > 1:
-            # data-parallel exchange: sum of per-shard gradients == gradient of the global batch
-            dist.all_reduce(gr.grad_sh_out)
-            dist.all_reduce(gr.grad_density_out)
-            dist.all_reduce(gr.grad_surface_out)
-            m8 = gr.mask_out.view(torch.uint8)
-            dist.all_reduce(m8, op=dist.ReduceOp.MAX)
+            # data-parallel exchange: sum of per-shard gradients == gradient of the global batch.
+            # A view touches ~20 % of the rows here, so the dense ring all-reduce is chosen
+            # (alphasurf_amd/dist.py switches to the sparse all-to-all below 1/8).
+            adist.all_reduce_grads(gr.grad_sh_out, gr.grad_density_out, gr.grad_surface_out, gr.mask_out,
+                                   mode=args.exchange)
 
     def barrier():
         if world > 1:
@@ -216,7 +223,7 @@ def main():
                                    "volume_render_surf_trav_fused fwd+bwd, surface_cuda_syn.yaml options",
                        "rays_per_step_per_gpu": Q, "active_voxels": int(g.density_data.shape[0]),
                        "avg_per_ray": {"V_t": round(v_t / Q, 2), "V_a": round(v_a / Q, 2), "S": round(s_cnt / Q, 3)},
-                       "parallelism": f"ray-sharded dp{world}, dense RCCL all-reduce of grads" if world > 1 else "single GPU"},
+                       "parallelism": f"ray-sharded dp{world}, {args.exchange} RCCL exchange of grads" if world > 1 else "single GPU"},
             "roofline": roofline, "cpu_baseline": cpu,
         }
     if world > 1:
