@@ -39,8 +39,9 @@ struct MaskLayout {
     size_t off_fine_work, off_fine_live, off_coarse_work, off_coarse_live;
     size_t off_cache_a, off_cache_w, off_cache_t, off_cache_n;
     size_t off_rec_v, off_rec_m, off_rec_n;
-    size_t off_p_items, off_p_citem, off_p_nitems, off_p_cut, off_p_counters, off_p_pool;
-    int pool_shard_cap;
+    size_t off_p_items, off_p_citem, off_p_nitems, off_p_cut, off_p_flagged, off_p_counters, off_p_pool;
+    size_t off_p_spbase, off_p_spill;
+    int pool_shard_cap, sp_cap;
     size_t total;
 };
 
@@ -97,8 +98,15 @@ MaskLayout layout_for(const int32_t size[3], int64_t n_rays, int32_t M) {
     off = align_up(off + nr * 4, 256);
     L.off_p_cut = off;
     off = align_up(off + nr * 4, 256);
-    L.off_p_counters = off;  // n_flagged + kPoolShards cursors
-    off = align_up(off + (1 + kPoolShards) * 4, 256);
+    L.off_p_flagged = off;
+    off = align_up(off + nr * 4, 256);
+    L.off_p_spbase = off;
+    off = align_up(off + nr * 4, 256);
+    L.sp_cap = (int)(4 * nr) + 256;  // spilled work voxels (beyond kPipeC1 per ray), all rays together
+    L.off_p_spill = off;             // sp_items | sp_citem | sp_ray
+    off = align_up(off + (size_t)L.sp_cap * 3 * 4, 256);
+    L.off_p_counters = off;  // n_flagged, spill cursor, kPoolShards pool cursors
+    off = align_up(off + (2 + kPoolShards) * 4, 256);
     L.pool_shard_cap = (int)((8 * nr + kPoolShards - 1) / kPoolShards) + 64;
     L.off_p_pool = off;
     off = align_up(off + (size_t)L.pool_shard_cap * kPoolShards * sizeof(CandRec), 256);
@@ -287,19 +295,25 @@ int run_forward(const Launch& L, const asurf_rays* rays, float* rgb_out, int M, 
     int* rn = record ? reinterpret_cast<int*>(L.ws + L.ML.off_rec_n) : nullptr;
     auto* cnt = reinterpret_cast<unsigned long long*>(counters);
     const long long Q = rays->n_rays;
-    const int* filter = nullptr;
+    const int* ray_list = nullptr;
+    const int* n_list = nullptr;
     if (pipeline) {
         PipeBuf P;
         P.items = reinterpret_cast<int*>(L.ws + L.ML.off_p_items);
         P.citem = reinterpret_cast<int*>(L.ws + L.ML.off_p_citem);
         P.n_items = reinterpret_cast<int*>(L.ws + L.ML.off_p_nitems);
         P.cut = reinterpret_cast<int*>(L.ws + L.ML.off_p_cut);
-        P.n_flagged = reinterpret_cast<int*>(L.ws + L.ML.off_p_counters);
-        P.pool_count = P.n_flagged + 1;
+        P.flagged = reinterpret_cast<int*>(L.ws + L.ML.off_p_flagged);
+        P.counters = reinterpret_cast<int*>(L.ws + L.ML.off_p_counters);
+        P.sp_base = reinterpret_cast<int*>(L.ws + L.ML.off_p_spbase);
+        P.sp_items = reinterpret_cast<int*>(L.ws + L.ML.off_p_spill);
+        P.sp_citem = P.sp_items + L.ML.sp_cap;
+        P.sp_ray = P.sp_citem + L.ML.sp_cap;
+        P.sp_cap = L.ML.sp_cap;
         P.pool = reinterpret_cast<CandRec*>(L.ws + L.ML.off_p_pool);
         P.shard_cap = L.ML.pool_shard_cap;
         P.C1 = kPipeC1;
-        if (hipMemsetAsync(P.n_flagged, 0, (1 + kPoolShards) * sizeof(int), L.stream) != hipSuccess)
+        if (hipMemsetAsync(P.counters, 0, (2 + kPoolShards) * sizeof(int), L.stream) != hipSuccess)
             return fail(ASURF_E_LAUNCH, "hipMemsetAsync failed");
         if (L.coarse_in_lds)
             hipLaunchKernelGGL((k_walk<true>), L.ray_grid, dim3(kBlock), L.dyn_lds, L.stream, L.g, L.o,
@@ -307,8 +321,10 @@ int run_forward(const Launch& L, const asurf_rays* rays, float* rgb_out, int M, 
         else
             hipLaunchKernelGGL((k_walk<false>), L.ray_grid, dim3(kBlock), 0, L.stream, L.g, L.o,
                                rays->origins, rays->dirs, Q, P, record ? 1 : 0);
-        hipLaunchKernelGGL(k_geom, dim3(L.ray_grid.x, kPipeC1), dim3(kBlock), 0, L.stream, L.g, L.o,
-                           rays->origins, rays->dirs, Q, P);
+        hipLaunchKernelGGL((k_geom<false>), dim3(L.ray_grid.x, kPipeC1), dim3(kBlock), 0, L.stream, L.g,
+                           L.o, rays->origins, rays->dirs, Q, P);
+        hipLaunchKernelGGL((k_geom<true>), dim3((unsigned)((L.ML.sp_cap + kBlock - 1) / kBlock)),
+                           dim3(kBlock), 0, L.stream, L.g, L.o, rays->origins, rays->dirs, Q, P);
         if (cache)
             hipLaunchKernelGGL((k_comp<B, true>), L.ray_grid, dim3(kBlock), 0, L.stream, L.g, L.o,
                                rays->dirs, Q, P, rgb_out, M, ca, cw, ct, cn, rv, rm, rn, kRecDepth);
@@ -316,12 +332,13 @@ int run_forward(const Launch& L, const asurf_rays* rays, float* rgb_out, int M, 
             hipLaunchKernelGGL((k_comp<B, false>), L.ray_grid, dim3(kBlock), 0, L.stream, L.g, L.o,
                                rays->dirs, Q, P, rgb_out, M, ca, cw, ct, cn, rv, rm, rn, kRecDepth);
         if (int e = launch_error("forward pipeline")) return e;
-        filter = P.n_items;
+        ray_list = P.flagged;
+        n_list = P.counters;
     }
 #define ASURF_FWD(CACHE, COUNT, CLDS)                                                            \
     hipLaunchKernelGGL((k_forward<B, CACHE, COUNT, CLDS>), L.ray_grid, dim3(kBlock), L.dyn_lds,  \
                        L.stream, L.g, L.o, rays->origins, rays->dirs, (long long)rays->n_rays,   \
-                       rgb_out, M, ca, cw, ct, cn, rv, rm, rn, kRecDepth, filter, cnt)
+                       rgb_out, M, ca, cw, ct, cn, rv, rm, rn, kRecDepth, ray_list, n_list, cnt)
 #define ASURF_FWD2(CACHE, COUNT)             \
     do {                                     \
         if (L.coarse_in_lds) ASURF_FWD(CACHE, COUNT, true); \

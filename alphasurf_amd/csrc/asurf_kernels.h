@@ -501,7 +501,8 @@ k_forward(KGrid g, KOpt o, const float* __restrict__ origins, const float* __res
           long long Q, float* __restrict__ rgb_out, int M, float* __restrict__ cache_a,
           float* __restrict__ cache_w, float* __restrict__ cache_t, int* __restrict__ cache_n,
           int* __restrict__ rec_v, int* __restrict__ rec_m, int* __restrict__ rec_n, int R,
-          const int* __restrict__ ray_filter, unsigned long long* counters) {
+          const int* __restrict__ ray_list, const int* __restrict__ n_list,
+          unsigned long long* counters) {
     extern __shared__ unsigned int s_coarse[];
     __shared__ float s_sph[kBlock * kSphPad];
     __shared__ LaneRec s_rec[kBlock];
@@ -521,9 +522,14 @@ k_forward(KGrid g, KOpt o, const float* __restrict__ origins, const float* __res
     const float* sph_wave = s_sph + (tid & ~63) * kSphPad;
     const LaneRec* rec_wave = s_rec + (tid & ~63);
 
-    const long long q = (long long)blockIdx.x * kBlock + tid;
-    // ray_filter: render only the rays the three-kernel pipeline handed back (entry < 0)
-    const bool valid = (q < Q) && (ray_filter == nullptr || ray_filter[q] < 0);
+    // ray_list: render only the rays the three-kernel pipeline handed back (compacted ids; a
+    // ray may be listed twice, which rewrites the same outputs)
+    long long q = (long long)blockIdx.x * kBlock + tid;
+    bool valid = q < Q;
+    if (ray_list != nullptr) {
+        valid = q < (long long)min(*n_list, (int)min(Q, (long long)0x7fffffff));
+        q = valid ? ray_list[q] : 0;
+    }
     if (!__any(valid)) return;
     Ray r;
     r.tmin = 1.f;

@@ -1,18 +1,20 @@
 // asurf_pipeline.h -- the forward pass as three dense kernels (gfx950, wave64).
 //
 //   k_walk : one ray per lane, nothing but the DDA + occupancy-bit tests (few registers, many
-//            waves per SIMD).  Work voxels go to a per-ray list [C1][Q] (lane-coalesced).
+//            waves per SIMD).  The first C1 work voxels of a ray go to a lane-coalesced table
+//            [C1][Q]; a ray with more re-walks once and appends the rest to a contiguous slice
+//            of a global spill list, so rays of any length stay on this path.
 //   k_geom : one WORK VOXEL per lane -- every lane of a wave is busy no matter how the work
 //            voxels are spread over rays.  Gathers the 8 corners, forms and solves the cubic
 //            (f64), validates the roots and leaves up to 3 sample candidates per voxel in a
-//            compact pool.
+//            sharded pool.  Launched twice: over the table and over the spill list.
 //   k_comp : one ray per lane again, for what is inherently sequential along a ray: the
 //            sigma gate, truncation window, compositing, the sample cache of the fused losses
 //            and the records the replaying backward kernel consumes.  Shading stays
 //            wave-cooperative (coop_shade_fwd).
 //
-// Rays with more than C1 work voxels or a voxel with more than 3 candidates are flagged and
-// rendered by the single-kernel path (k_forward with ray_filter); results are identical.
+// A ray is handed back to the one-kernel path (k_forward with a compacted ray list) only
+// when a voxel yields more than 3 candidates or a pool runs out; results are identical.
 #pragma once
 #include "asurf_kernels.h"
 
@@ -27,21 +29,38 @@ struct CandRec {  // 32 bytes
     int pad;
 };
 
-struct PipeBuf {
-    int* items;      // [C1][Q] packed work voxels
-    int* citem;      // [C1][Q] (pool base << 2) | candidate count
-    int* n_items;    // [Q]; < 0: ray left to the single-kernel path
-    int* cut;        // [Q] ordinal of the first work voxel the reference's BACKWARD would skip
-    int* n_flagged;  // [1]
-    int* pool_count; // [kPoolShards] one allocation cursor per shard of the candidate pool
-    CandRec* pool;
-    int shard_cap;   // records per shard
-    int C1;
-};
-
 // The candidate pool is cut into shards with their own cursors so that the allocating
 // atomics of k_geom do not serialise on one address.
 constexpr int kPoolShards = 256;
+
+struct PipeBuf {
+    int* items;      // [C1][Q] packed work voxels
+    int* citem;      // [C1][Q] (pool index << 2) | candidate count
+    int* n_items;    // [Q] work voxels of the ray; < 0: ray handed back to the one-kernel path
+    int* cut;        // [Q] ordinal of the first work voxel the reference's BACKWARD would skip
+    int* sp_base;    // [Q] first spill entry of the ray (valid when n_items > C1)
+    int* sp_items;   // [sp_cap] spilled work voxels, contiguous per ray
+    int* sp_citem;   // [sp_cap]
+    int* sp_ray;     // [sp_cap] owning ray
+    int* flagged;    // [Q] compacted ids of the rays handed back
+    int* counters;   // [0] n_flagged, [1] spill cursor, [2 .. 2+kPoolShards) pool cursors
+    CandRec* pool;
+    int shard_cap;   // records per pool shard
+    int sp_cap;
+    int C1;
+};
+
+__device__ __forceinline__ int wave_excl_scan(int v, int* total) {
+    const int lane = threadIdx.x & 63;
+    int incl = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int t = __shfl_up(incl, d);
+        if (lane >= d) incl += t;
+    }
+    *total = __shfl(incl, 63);
+    return incl - v;
+}
 
 // ------------------------------------------------------------------------------------
 template <bool CLDS>
@@ -55,20 +74,25 @@ k_walk(KGrid g, KOpt o, const float* __restrict__ origins, const float* __restri
         __syncthreads();
     }
     const long long q = (long long)blockIdx.x * kBlock + tid;
-    if (q >= Q) return;
+    const bool valid = q < Q;
     Ray r;
+    r.tmin = 1.f;
+    r.tmax = 0.f;
+    if (valid) {
 #pragma unroll
-    for (int k = 0; k < 3; ++k) {
-        r.o[k] = origins[3 * q + k];
-        r.d[k] = dirs[3 * q + k];
+        for (int k = 0; k < 3; ++k) {
+            r.o[k] = origins[3 * q + k];
+            r.d[k] = dirs[3 * q + k];
+        }
+        setup_ray(g, o, r);
     }
-    setup_ray(g, o, r);
-    bool active = !(r.tmin > r.tmax);
+    const bool hits_grid = valid && !(r.tmin > r.tmax);
     int cnt = 0;
     int cutv = 0x7fffffff;
-    if (active) {
+    if (hits_grid) {
         Walk w;
         walk_init(g, r, w);
+        bool active = true;
         while (active) {
             walk_step(g, r, w);
             const bool hit = walk_test<CLDS>(g, s_coarse, w);
@@ -81,113 +105,160 @@ k_walk(KGrid g, KOpt o, const float* __restrict__ origins, const float* __restri
             }
         }
     }
-    if (cnt > P.C1) {
-        cnt = -1;
-        atomicAdd(P.n_flagged, 1);
+    // rays longer than the table: reserve a contiguous spill slice (one atomic per wave) and
+    // walk again to fill it
+    const int extra = (cnt > P.C1) ? cnt - P.C1 : 0;
+    int total;
+    const int pre = wave_excl_scan(extra, &total);
+    if (total > 0) {
+        int base0 = 0;
+        if ((tid & 63) == 0) base0 = atomicAdd(&P.counters[1], total);
+        base0 = __shfl(base0, 0);
+        if (extra > 0) {
+            const int base = base0 + pre;
+            if (base + extra <= P.sp_cap) {
+                P.sp_base[q] = base;
+                Walk w;
+                walk_init(g, r, w);
+                bool active = true;
+                int k = 0;
+                while (active) {
+                    walk_step(g, r, w);
+                    const bool hit = walk_test<CLDS>(g, s_coarse, w);
+                    active = (w.t <= r.tmax);
+                    if (hit) {
+                        if (k >= P.C1) {
+                            P.sp_items[base + k - P.C1] = pack_voxel(w.vx, w.vy, w.vz);
+                            P.sp_ray[base + k - P.C1] = (int)q;
+                        }
+                        ++k;
+                    }
+                }
+            } else {  // spill list exhausted: the one-kernel path renders this ray
+                cnt = -1;
+                P.flagged[atomicAdd(&P.counters[0], 1)] = (int)q;
+                for (int e = base; e < min(base + extra, P.sp_cap); ++e) P.sp_ray[e] = -1;
+            }
+        }
     }
-    P.n_items[q] = cnt;
-    P.cut[q] = cutv;
+    if (valid) {
+        P.n_items[q] = cnt;
+        P.cut[q] = cutv;
+    }
 }
 
 // ------------------------------------------------------------------------------------
-// grid = (ceil(Q / 256), C1): block row s handles work voxel s of 256 consecutive rays
+// SPILL = false: grid (ceil(Q/256), C1), block row s handles table slot s of 256 rays.
+// SPILL = true : 1-D grid over the spill list.
+template <bool SPILL>
 __global__ void __launch_bounds__(kBlock)
 k_geom(KGrid g, KOpt o, const float* __restrict__ origins, const float* __restrict__ dirs,
        long long Q, PipeBuf P) {
-    const int s = blockIdx.y;
-    const long long q = (long long)blockIdx.x * kBlock + threadIdx.x;
-    const bool mine = (q < Q) && (s < P.n_items[q]);  // also skips flagged rays (n_items < 0)
+    long long q;
+    int packed_voxel = 0;
+    long long entry = 0;
+    bool mine;
+    if constexpr (SPILL) {
+        entry = (long long)blockIdx.x * kBlock + threadIdx.x;
+        const int n_sp = min(P.counters[1], P.sp_cap);
+        mine = entry < n_sp;
+        q = mine ? P.sp_ray[entry] : -1;
+        mine = (q >= 0) && (P.n_items[q] >= 0);
+        if (q < 0) q = 0;
+        if (mine) packed_voxel = P.sp_items[entry];
+    } else {
+        const int s = blockIdx.y;
+        q = (long long)blockIdx.x * kBlock + threadIdx.x;
+        mine = (q < Q) && (s < min(P.n_items[q], P.C1));  // n_items < 0: ray handed back
+        entry = (long long)s * Q + q;
+        if (mine) packed_voxel = P.items[entry];
+    }
     if (!__any(mine)) return;
     CandRec c[3];
     int nc = 0;
     bool overflow = false;
-  if (mine) {
-    Ray r;
+    if (mine) {
+        Ray r;
 #pragma unroll
-    for (int k = 0; k < 3; ++k) {
-        r.o[k] = origins[3 * q + k];
-        r.d[k] = dirs[3 * q + k];
-    }
-    setup_ray(g, o, r);
-    Vox v;
-    load_voxel(g, r, P.items[(size_t)s * Q + q], v);
-    bool vox_has_sample = false, vox_has_surf = false;
-    for (int li = 0; li < g.level_set_num; ++li) {  // surf_trav.cu:273-419 up to the sigma gate
-        const float lvf = g.level_set[li];
-        if (lvf < v.smin || lvf > v.smax) continue;
-        vox_has_surf = true;
-        double st[3] = {-1, -1, -1};
-        solve_cubic_vieta(v.fs[0] - (double)lvf, v.fs[1], v.fs[2], v.fs[3], st);
+        for (int k = 0; k < 3; ++k) {
+            r.o[k] = origins[3 * q + k];
+            r.d[k] = dirs[3 * q + k];
+        }
+        setup_ray(g, o, r);
+        Vox v;
+        load_voxel(g, r, packed_voxel, v);
+        bool vox_has_sample = false, vox_has_surf = false;
+        for (int li = 0; li < g.level_set_num; ++li) {  // surf_trav.cu:273-379 up to the sigma gate
+            const float lvf = g.level_set[li];
+            if (lvf < v.smin || lvf > v.smax) continue;
+            vox_has_surf = true;
+            double st[3] = {-1, -1, -1};
+            solve_cubic_vieta(v.fs[0] - (double)lvf, v.fs[1], v.fs[2], v.fs[3], st);
 #pragma unroll
-        for (int j = 0; j < 3; ++j) {
-            if (!(st[j] > 0)) continue;
+            for (int j = 0; j < 3; ++j) {
+                if (!(st[j] > 0)) continue;
+                float pos[3];
+                if (!root_position(r, v, st[j], pos)) continue;
+                vox_has_sample = true;
+                if (o.only_outward_intersect) {
+                    float sg[3];
+                    field_grad(v.surf, pos, sg);
+                    const float ndd = -(sg[0] * r.d[0] + sg[1] * r.d[1] + sg[2] * r.d[2]);
+                    if (ndd >= 0.f) continue;
+                }
+                if (nc < 3) {
+                    CandRec& cr = (nc == 0) ? c[0] : (nc == 1) ? c[1] : c[2];
+                    cr.px = pos[0];
+                    cr.py = pos[1];
+                    cr.pz = pos[2];
+                    cr.ts = (float)((double)v.t_close + st[j]);
+                    cr.raw = trilerp8(v.dens, pos);
+                    cr.ext = 0.f;
+                    cr.meta = (li << 3) | (j << 1);
+                    cr.pad = 0;
+                    ++nc;
+                } else {
+                    overflow = true;
+                }
+            }
+        }
+        // fake sample (surf_trav.cu:423-503): everything that does not depend on earlier samples
+        if (o.surf_fake_sample && !vox_has_sample && (!o.limited_fake_sample || vox_has_surf) &&
+            ((v.t_far - v.t_close) > o.surf_fake_sample_min_vox_len)) {
             float pos[3];
-            if (!root_position(r, v, st[j], pos)) continue;
-            vox_has_sample = true;
-            if (o.only_outward_intersect) {
-                float sg[3];
-                field_grad(v.surf, pos, sg);
-                const float ndd = -(sg[0] * r.d[0] + sg[1] * r.d[1] + sg[2] * r.d[2]);
-                if (ndd >= 0.f) continue;
-            }
-            if (nc < 3) {
-                CandRec& cr = (nc == 0) ? c[0] : (nc == 1) ? c[1] : c[2];
-                cr.px = pos[0];
-                cr.py = pos[1];
-                cr.pz = pos[2];
-                cr.ts = (float)((double)v.t_close + st[j]);
-                cr.raw = trilerp8(v.dens, pos);
-                cr.ext = 0.f;
-                cr.meta = (li << 3) | (j << 1);
-                cr.pad = 0;
-                ++nc;
-            } else {
-                overflow = true;
+            fake_position(r, v, pos);
+            const float raw = trilerp8(v.dens, pos);
+            if (raw > o.sigma_thresh) {
+                double miu, sd;
+                c[0].px = pos[0];
+                c[0].py = pos[1];
+                c[0].pz = pos[2];
+                c[0].ts = (v.t_far + v.t_close) / 2.f;
+                c[0].raw = raw;
+                c[0].ext = fake_distance(g, o, v, pos, &miu, &sd);
+                c[0].meta = 1;
+                c[0].pad = 0;
+                nc = 1;
             }
         }
+        if (overflow) nc = 0;
     }
-    // fake sample (surf_trav.cu:423-503): everything that does not depend on earlier samples
-    if (o.surf_fake_sample && !vox_has_sample && (!o.limited_fake_sample || vox_has_surf) &&
-        ((v.t_far - v.t_close) > o.surf_fake_sample_min_vox_len)) {
-        float pos[3];
-        fake_position(r, v, pos);
-        const float raw = trilerp8(v.dens, pos);
-        if (raw > o.sigma_thresh) {
-            double miu, sd;
-            c[0].px = pos[0];
-            c[0].py = pos[1];
-            c[0].pz = pos[2];
-            c[0].ts = (v.t_far + v.t_close) / 2.f;
-            c[0].raw = raw;
-            c[0].ext = fake_distance(g, o, v, pos, &miu, &sd);
-            c[0].meta = 1;
-            c[0].pad = 0;
-            nc = 1;
-        }
-    }
-    if (overflow) nc = 0;
-  }
     // one pool allocation per wave: exclusive prefix of the lanes' counts + a single atomic
-    const int lane = threadIdx.x & 63;
-    int incl = nc;
-#pragma unroll
-    for (int dlt = 1; dlt < 64; dlt <<= 1) {
-        const int t = __shfl_up(incl, dlt);
-        if (lane >= dlt) incl += t;
-    }
-    const int total = __shfl(incl, 63);
-    const int shard = (int)((blockIdx.x + blockIdx.y * 37u + (threadIdx.x >> 6) * 11u) % kPoolShards);
+    int total;
+    const int pre = wave_excl_scan(nc, &total);
+    const int shard =
+        (int)((blockIdx.x + blockIdx.y * 37u + (threadIdx.x >> 6) * 11u + (SPILL ? 101u : 0u)) % kPoolShards);
     int base0 = 0;
     if (total > 0) {
-        if (lane == 0) base0 = atomicAdd(&P.pool_count[shard], total);
+        if ((threadIdx.x & 63) == 0) base0 = atomicAdd(&P.counters[2 + shard], total);
         base0 = __shfl(base0, 0);
     }
     if (!mine) return;
     int packed = 0;
-    const int rel = base0 + incl - nc;
+    const int rel = base0 + pre;
     if (overflow || (nc > 0 && rel + nc > P.shard_cap)) {
-        P.n_items[q] = -1;  // later slots of this ray may still run; k_comp ignores the ray
-        atomicAdd(P.n_flagged, 1);
+        // hand the ray back once (other voxels of it may still run; k_comp ignores the ray)
+        if (atomicExch(&P.n_items[q], -1) >= 0) P.flagged[atomicAdd(&P.counters[0], 1)] = (int)q;
     } else if (nc > 0) {
         const int base = shard * P.shard_cap + rel;
 #pragma unroll
@@ -195,7 +266,8 @@ k_geom(KGrid g, KOpt o, const float* __restrict__ origins, const float* __restri
             if (i < nc) P.pool[base + i] = c[i];
         packed = (base << 2) | nc;
     }
-    P.citem[(size_t)s * Q + q] = packed;
+    if constexpr (SPILL) P.sp_citem[entry] = packed;
+    else P.citem[entry] = packed;
 }
 
 // ------------------------------------------------------------------------------------
@@ -213,7 +285,7 @@ k_comp(KGrid g, KOpt o, const float* __restrict__ dirs, long long Q, PipeBuf P,
     const long long q = (long long)blockIdx.x * kBlock + tid;
     const bool in_range = q < Q;
     const int n = in_range ? P.n_items[q] : 0;
-    const bool valid = in_range && n >= 0;  // flagged rays belong to the single-kernel path
+    const bool valid = in_range && n >= 0;  // handed-back rays belong to the one-kernel path
     if (valid) {
         float d[3] = {dirs[3 * q], dirs[3 * q + 1], dirs[3 * q + 2]};
         float sph[B];
@@ -223,6 +295,7 @@ k_comp(KGrid g, KOpt o, const float* __restrict__ dirs, long long Q, PipeBuf P,
     }
     const bool do_rec = CACHE && (rec_v != nullptr);
     const int cutv = (valid && do_rec) ? P.cut[q] : 0x7fffffff;
+    const int spb = (valid && n > P.C1) ? P.sp_base[q] : 0;
     float outv[3] = {0.f, 0.f, 0.f};
     float log_transmit = 0.f;
     int sample_i = 0, intersect_i = -1, rec_cnt = 0;
@@ -231,7 +304,8 @@ k_comp(KGrid g, KOpt o, const float* __restrict__ dirs, long long Q, PipeBuf P,
 
     for (int s = 0; __any(s < n_left); ++s) {
         const bool have = s < n_left;
-        const int ci = have ? P.citem[(size_t)s * Q + q] : 0;
+        int ci = 0;
+        if (have) ci = (s < P.C1) ? P.citem[(size_t)s * Q + q] : P.sp_citem[spb + s - P.C1];
         const int nc = ci & 3;
         if (!__any(nc > 0)) continue;
         const int base = ci >> 2;
@@ -269,7 +343,7 @@ k_comp(KGrid g, KOpt o, const float* __restrict__ dirs, long long Q, PipeBuf P,
                 shade = true;
             }
             if (shade && !links_loaded) {
-                pv = P.items[(size_t)s * Q + q];
+                pv = (s < P.C1) ? P.items[(size_t)s * Q + q] : P.sp_items[spb + s - P.C1];
                 const int vx = pv >> 20, vy = (pv >> 10) & 1023, vz = pv & 1023;
                 const int32_t* p = g.links + ((size_t)vx * g.offx + (size_t)vy * g.offy + vz);
                 s_rec[tid].link[0] = p[0];
