@@ -16,6 +16,7 @@
 #include "asurf_kernels.h"
 #include "asurf_optim.h"
 #include "asurf_pipeline.h"
+#include "asurf_bwd_pipeline.h"
 
 namespace {
 
@@ -38,7 +39,7 @@ struct MaskLayout {
     size_t coarse_words;
     size_t off_fine_work, off_fine_live, off_coarse_work, off_coarse_live;
     size_t off_cache_a, off_cache_w, off_cache_t, off_cache_n;
-    size_t off_rec_v, off_rec_m, off_rec_n;
+    size_t off_rec_v, off_rec_m, off_rec_n, off_rec_neff, off_rec_sws, off_rec_f;
     size_t off_p_items, off_p_citem, off_p_nitems, off_p_cut, off_p_flagged, off_p_counters, off_p_pool;
     size_t off_p_spbase, off_p_spill;
     int pool_shard_cap, sp_cap;
@@ -87,6 +88,12 @@ MaskLayout layout_for(const int32_t size[3], int64_t n_rays, int32_t M) {
     off = align_up(off + rplane, 256);
     L.off_rec_n = off;
     off = align_up(off + (size_t)(n_rays > 0 ? n_rays : 0) * 4, 256);
+    L.off_rec_neff = off;
+    off = align_up(off + (size_t)(n_rays > 0 ? n_rays : 0) * 4, 256);
+    L.off_rec_sws = off;
+    off = align_up(off + (size_t)(n_rays > 0 ? n_rays : 0) * 4, 256);
+    L.off_rec_f = off;  // 8 forward + 9 backward float planes [kRecDepth][Q]
+    off = align_up(off + 17 * rplane, 256);
     // three-kernel forward pipeline (asurf_pipeline.h)
     const size_t nr = (size_t)(n_rays > 0 ? n_rays : 0);
     const size_t iplane = (size_t)kPipeC1 * nr * 4;
@@ -293,6 +300,7 @@ int run_forward(const Launch& L, const asurf_rays* rays, float* rgb_out, int M, 
     int* rv = record ? reinterpret_cast<int*>(L.ws + L.ML.off_rec_v) : nullptr;
     int* rm = record ? reinterpret_cast<int*>(L.ws + L.ML.off_rec_m) : nullptr;
     int* rn = record ? reinterpret_cast<int*>(L.ws + L.ML.off_rec_n) : nullptr;
+    float* rf = record ? reinterpret_cast<float*>(L.ws + L.ML.off_rec_f) : nullptr;
     auto* cnt = reinterpret_cast<unsigned long long*>(counters);
     const long long Q = rays->n_rays;
     const int* ray_list = nullptr;
@@ -327,10 +335,10 @@ int run_forward(const Launch& L, const asurf_rays* rays, float* rgb_out, int M, 
                            dim3(kBlock), 0, L.stream, L.g, L.o, rays->origins, rays->dirs, Q, P);
         if (cache)
             hipLaunchKernelGGL((k_comp<B, true>), L.ray_grid, dim3(kBlock), 0, L.stream, L.g, L.o,
-                               rays->dirs, Q, P, rgb_out, M, ca, cw, ct, cn, rv, rm, rn, kRecDepth);
+                               rays->dirs, Q, P, rgb_out, M, ca, cw, ct, cn, rv, rm, rn, kRecDepth, rf);
         else
             hipLaunchKernelGGL((k_comp<B, false>), L.ray_grid, dim3(kBlock), 0, L.stream, L.g, L.o,
-                               rays->dirs, Q, P, rgb_out, M, ca, cw, ct, cn, rv, rm, rn, kRecDepth);
+                               rays->dirs, Q, P, rgb_out, M, ca, cw, ct, cn, rv, rm, rn, kRecDepth, rf);
         if (int e = launch_error("forward pipeline")) return e;
         ray_list = P.flagged;
         n_list = P.counters;
@@ -338,7 +346,7 @@ int run_forward(const Launch& L, const asurf_rays* rays, float* rgb_out, int M, 
 #define ASURF_FWD(CACHE, COUNT, CLDS)                                                            \
     hipLaunchKernelGGL((k_forward<B, CACHE, COUNT, CLDS>), L.ray_grid, dim3(kBlock), L.dyn_lds,  \
                        L.stream, L.g, L.o, rays->origins, rays->dirs, (long long)rays->n_rays,   \
-                       rgb_out, M, ca, cw, ct, cn, rv, rm, rn, kRecDepth, ray_list, n_list, cnt)
+                       rgb_out, M, ca, cw, ct, cn, rv, rm, rn, kRecDepth, rf, ray_list, n_list, cnt)
 #define ASURF_FWD2(CACHE, COUNT)             \
     do {                                     \
         if (L.coarse_in_lds) ASURF_FWD(CACHE, COUNT, true); \
@@ -358,8 +366,9 @@ int run_forward(const Launch& L, const asurf_rays* rays, float* rgb_out, int M, 
     return launch_error("k_forward");
 }
 
-// mode 0: walking backward over all rays; 1: record replay (fused only);
-// 2: walking backward restricted to the rays whose record overflowed (fused only)
+// mode 0: walking backward over all rays; 1: record replay in one kernel (fused only);
+// 2: walking backward restricted to the rays whose record overflowed (fused only);
+// 3: record replay as three kernels (asurf_bwd_pipeline.h)
 template <int B>
 int run_backward(const Launch& L, const asurf_rays* rays, const KLoss& loss, const KGrads& G,
                  const float* grad_in, const float* color_cache, int M, bool fused, int mode) {
@@ -376,7 +385,44 @@ int run_backward(const Launch& L, const asurf_rays* rays, const KLoss& loss, con
                        (REC) ? 0 : L.dyn_lds, L.stream, L.g, L.o, loss, G, rays->origins,          \
                        rays->dirs, (long long)rays->n_rays, grad_in, color_cache, M, ca, cw, ct,  \
                        cn, rv, rm, rn, filter)
-    if (mode == 1) {
+    if (mode == 3) {
+        // split replay: sequential scalars per ray, then one sample per wave step (SH) and
+        // one sample per lane (geometry)
+        SampleRec S;
+        const size_t plane = (size_t)kRecDepth * (size_t)rays->n_rays;
+        float* f = reinterpret_cast<float*>(L.ws + L.ML.off_rec_f);
+        S.v = const_cast<int*>(rv);
+        S.m = const_cast<int*>(rm);
+        S.n = const_cast<int*>(rn);
+        S.raw = f;
+        S.a = f + plane;
+        S.c0 = f + 2 * plane;
+        S.c1 = f + 3 * plane;
+        S.c2 = f + 4 * plane;
+        S.px = f + 5 * plane;
+        S.py = f + 6 * plane;
+        S.pz = f + 7 * plane;
+        S.w = f + 8 * plane;
+        S.g0 = f + 9 * plane;
+        S.g1 = f + 10 * plane;
+        S.g2 = f + 11 * plane;
+        S.cgr = f + 12 * plane;
+        S.gst = f + 13 * plane;
+        S.gx = f + 14 * plane;
+        S.gy = f + 15 * plane;
+        S.gz = f + 16 * plane;
+        S.n_eff = reinterpret_cast<int*>(L.ws + L.ML.off_rec_neff);
+        S.sws = reinterpret_cast<float*>(L.ws + L.ML.off_rec_sws);
+        S.R = kRecDepth;
+        const long long Q = rays->n_rays;
+        hipLaunchKernelGGL(k_bwd_seq, L.ray_grid, dim3(kBlock), 0, L.stream, L.o, loss, L.g.trunc_a, Q,
+                           grad_in, color_cache, M, ca, cw, ct, cn, S);
+        const dim3 grid2(L.ray_grid.x, kRecDepth);
+        hipLaunchKernelGGL((k_bwd_sh<B>), grid2, dim3(kBlock), 0, L.stream, L.g, G,
+                           L.o.no_surf_grad_from_sh ? 0 : 1, rays->dirs, Q, S);
+        hipLaunchKernelGGL(k_bwd_geo, grid2, dim3(kBlock), 0, L.stream, L.g, L.o, loss, G, rays->origins,
+                           rays->dirs, Q, S);
+    } else if (mode == 1) {
         ASURF_BWD(true, false, true);
     } else if (fused) {
         if (L.coarse_in_lds) ASURF_BWD(true, true, false);
@@ -386,7 +432,7 @@ int run_backward(const Launch& L, const asurf_rays* rays, const KLoss& loss, con
         else ASURF_BWD(false, false, false);
     }
 #undef ASURF_BWD
-    if (mode != 1) prof_mark(3, L.stream);
+    if (mode != 1 && mode != 3) prof_mark(3, L.stream);
     return launch_error("k_backward");
 }
 
@@ -500,7 +546,10 @@ int asurf_volume_render_surf_trav_fused(const asurf_grid* grid, const asurf_rays
     ASURF_DISPATCH_B(grid->basis_dim, run_forward<B_>(L, rays, rgb_out, M, true, replay, counters, pipe));
     if (rc) return rc;
     if (replay) {
-        ASURF_DISPATCH_B(grid->basis_dim, run_backward<B_>(L, rays, loss, G, fused->rgb_gt, rgb_out, M, true, 1));
+        const char* nosplit = getenv("ASURF_NO_SPLIT_BWD");
+        const int replay_mode = (nosplit && atoi(nosplit)) ? 1 : 3;
+        ASURF_DISPATCH_B(grid->basis_dim,
+                         run_backward<B_>(L, rays, loss, G, fused->rgb_gt, rgb_out, M, true, replay_mode));
         if (rc) return rc;
         ASURF_DISPATCH_B(grid->basis_dim, run_backward<B_>(L, rays, loss, G, fused->rgb_gt, rgb_out, M, true, 2));
     } else {

@@ -1,0 +1,444 @@
+// asurf_bwd_pipeline.h -- the fused backward pass as three dense kernels (gfx950, wave64).
+//
+// The forward pass leaves one record per composited sample (voxel, level set, root index,
+// intersection ordinal, raw opacity, re-weighted alpha, pre-clamp colour, position).  With the
+// colours on record the only part of trace_ray_surf_trav_backward (surf_trav.cu:1710-2911) that
+// is sequential along a ray is scalar arithmetic, so the pass splits into
+//
+//   k_bwd_seq : one RAY per lane -- the running quantities (transmittance, `accum`, the sample
+//               index of the fused losses, stop_thresh) and every term that needs the ray's
+//               sample cache; emits per sample: weight, dL/dcolour per channel, the first part
+//               of dL/d(rwalpha) and of dL/dt.
+//   k_bwd_sh  : one SAMPLE per wave step, lanes = (corner, SH coefficient) -- row-contiguous
+//               atomics into grad_sh and the d/dpos of the colour; no dependence between
+//               samples any more, so many waves keep their gathers in flight.
+//   k_bwd_geo : one SAMPLE per lane -- reloads the voxel, re-solves the cubic, finishes
+//               dL/d(raw alpha) and dL/dt, root gradient, density / surface scatter.
+//
+// Grid of the last two: (ceil(Q/256), R): block row r handles record r of 256 consecutive rays.
+#pragma once
+#include "asurf_kernels.h"
+
+namespace asurf {
+
+struct SampleRec {  // planes [R][Q]
+    // written by the forward pass
+    int* v;      // packed voxel
+    int* m;      // bit0 fake, bits1-2 root, bits3-7 level set, bits8.. intersection ordinal + 1
+    float* raw;  // raw opacity
+    float* a;    // re-weighted alpha
+    float* c0;   // colour before the +0.5 / clamp, per channel
+    float* c1;
+    float* c2;
+    float* px;   // position inside the voxel
+    float* py;
+    float* pz;
+    // written by k_bwd_seq
+    float* w;    // compositing weight (backward's clamped form)
+    float* g0;   // weight * [colour in range] * gout, per channel
+    float* g1;
+    float* g2;
+    float* cgr;  // dL/d(rwalpha): compositing + cache-dependent loss terms
+    float* gst;  // cache-dependent part of dL/dt
+    // written by k_bwd_sh
+    float* gx;   // dL/dpos through the SH coefficients
+    float* gy;
+    float* gz;
+    int* n;      // [Q] records of the ray (< 0: overflowed, ray belongs to the walking kernel)
+    int* n_eff;  // [Q] records the backward actually visits (stop_thresh)
+    float* sws;  // [Q] clamped sum of the cached weights (sparsity term)
+    int R;
+};
+
+// ------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(kBlock)
+k_bwd_seq(KOpt o, KLoss L, float trunc_a, long long Q, const float* __restrict__ rgb_gt,
+          const float* __restrict__ rgb_out, int M, const float* __restrict__ cache_a,
+          const float* __restrict__ cache_w, const float* __restrict__ cache_t,
+          const int* __restrict__ cache_n, SampleRec S) {
+    const long long q = (long long)blockIdx.x * kBlock + threadIdx.x;
+    if (q >= Q) return;
+    const int n_rec = S.n[q];
+    if (n_rec <= 0) {
+        S.n_eff[q] = 0;
+        return;
+    }
+    float gout[3];
+    float accum;
+    {
+        float cc[3];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {  // surf_trav.cu:3306-3316
+            cc[i] = rgb_out[3 * q + i];
+            const float resid = cc[i] - rgb_gt[3 * q + i];
+            gout[i] = resid * L.norm_l2 * L.lambda_l2;
+            gout[i] += (resid > 0.f) ? (L.norm_l1 * L.lambda_l1) : (-L.norm_l1 * L.lambda_l1);
+        }
+        accum = fmaf(cc[0], gout[0], fmaf(cc[1], gout[1], cc[2] * gout[2]));  // :1800-1802
+    }
+    // prologue over the sample cache (:1756-1793); entries >= n are implicit zeros
+    const int n = (M > 0) ? min(cache_n[q], M) : 0;
+    auto AL = [&](int i) -> float { return (i < n) ? cache_a[(size_t)i * Q + q] : 0.f; };
+    auto WE = [&](int i) -> float { return (i < n) ? cache_w[(size_t)i * Q + q] : 0.f; };
+    auto TS = [&](int i) -> float { return (i < n) ? cache_t[(size_t)i * Q + q] : 0.f; };
+    float sample_alpha_sum = 0.f, sample_weight_sum = 0.f;
+    for (int i = 0; i < n; ++i) {
+        sample_alpha_sum += AL(i);
+        sample_weight_sum += WE(i);
+    }
+    sample_alpha_sum = clamp_lo(sample_alpha_sum);
+    sample_weight_sum = clamp_lo(sample_weight_sum);
+    float Den_Dasum = 0.f, Den_Dwsum = 0.f, sample_t_mean = 0.f;
+    int valid_sample_n = 0;
+    float shared_Dmeant_sign = 0.f;
+    int max_sample_id = 0;
+    {
+        float max_weight = 0.f;
+        for (int i = 0; i < n; ++i) {
+            const float a = AL(i), ww = WE(i);
+            Den_Dasum += a * (log_ratio(a, sample_alpha_sum) + 1.f) / sqrf(sample_alpha_sum);
+            Den_Dwsum += ww * (log_ratio(ww, sample_weight_sum) + 1.f) / sqrf(sample_weight_sum);
+            sample_t_mean += ww / sample_weight_sum * TS(i);
+            if (ww > max_weight) {
+                max_weight = ww;
+                max_sample_id = i;
+            }
+        }
+        for (int i = 0; i < n; ++i) {
+            const float ts = TS(i);
+            if (ts > 0.f) {
+                valid_sample_n++;
+                shared_Dmeant_sign += (sample_t_mean > ts) ? 1.f : ((sample_t_mean < ts) ? -1.f : 0.f);
+            }
+        }
+    }
+    S.sws[q] = sample_weight_sum;
+
+    float log_transmit = 0.f;
+    int sample_i = 0;
+    int r = 0;
+    for (; r < n_rec; ++r) {
+        const size_t idx = (size_t)r * Q + q;
+        const int meta = S.m[idx];
+        const bool fake = meta & 1;
+        const float rwalpha = S.a[idx];
+        const float pcnt = -logf(clamp_lo(1.f - rwalpha));  // :2099
+        const float weight = expf(log_transmit) * (1.f - expf(-pcnt));
+        // colour terms (:2104-2122)
+        const float s0 = S.c0[idx] + 0.5f, s1 = S.c1[idx] + 0.5f, s2 = S.c2[idx] + 0.5f;
+        const float t0 = fmaxf(s0, 0.f), t1 = fmaxf(s1, 0.f), t2 = fmaxf(s2, 0.f);
+        const float total_color = (t0 * gout[0] + t2 * gout[2]) + t1 * gout[1];
+        S.w[idx] = weight;
+        S.g0[idx] = weight * (t0 == s0 ? 1.f : 0.f) * gout[0];
+        S.g1[idx] = weight * (t1 == s1 ? 1.f : 0.f) * gout[1];
+        S.g2[idx] = weight * (t2 == s2 ? 1.f : 0.f) * gout[2];
+        accum -= weight * total_color;
+        float cgr = accum / fminf(rwalpha - 1.f, -1e-8f) + total_color * expf(log_transmit);
+        // l_dist / l_entropy (:2141-2210, 2602-2666)
+        if (!fake || o.fake_sample_l_dist) {
+            const float denom = fminf(rwalpha - 1.f, -1e-8f);
+            if (L.lambda_l_dist > 0.f) {
+                float Dl = 0.f;
+                float log_Tk = log_transmit;
+                for (int k = sample_i; k < valid_sample_n; ++k) {
+                    float Dwk = 0.f;
+                    const float tk = TS(k);
+                    for (int j = 0; j < n; ++j) Dwk += WE(j) * fabsf(tk - TS(j));
+                    if (k == sample_i) {
+                        Dl += Dwk * expf(log_transmit);
+                    } else {
+                        log_Tk += logf(clamp_lo(1.f - AL(k - 1)));
+                        Dl += Dwk * expf(log_Tk) * AL(k) / denom;
+                    }
+                }
+                cgr += L.lambda_l_dist * Dl;
+            }
+            if (L.lambda_l_entropy > 0.f) {
+                auto Den_Dw = [&](int k) -> float {
+                    if (L.no_norm_weight_l_entropy) return -(logf(clamp_lo(WE(k))) + 1.f);
+                    return -(log_ratio(WE(k), sample_weight_sum) + 1.f) / sample_weight_sum + Den_Dwsum;
+                };
+                float Den_Dai = Den_Dw(sample_i) * expf(log_transmit);
+                float log_Tk = log_transmit;
+                for (int k = sample_i + 1; k < valid_sample_n; ++k) {
+                    const float Dwk = Den_Dw(k);
+                    log_Tk += logf(clamp_lo(1.f - AL(k - 1)));
+                    Den_Dai += Dwk * expf(log_Tk) * AL(k) / denom;
+                }
+                cgr += L.lambda_l_entropy * Den_Dai;
+            }
+        }
+        log_transmit -= pcnt;
+        float gst = 0.f;
+        if (!fake || o.fake_sample_l_dist) {
+            const float ts_i = TS(sample_i);
+            if (L.lambda_l_dist_a > 0.f) {
+                float ga = 0.f;
+                for (int j = 0; j < n; ++j) ga += AL(j) * fabsf(ts_i - TS(j));
+                cgr += L.lambda_l_dist_a * ga;
+            }
+            if (L.lambda_l_entropy_a > 0.f) {
+                const float Den_Dai = -(log_ratio(AL(sample_i), sample_alpha_sum) + 1.f) / sample_alpha_sum;
+                cgr += L.lambda_l_entropy_a * (Den_Dai + Den_Dasum);
+            }
+            if (!fake) {  // dL/dt terms exist for real intersections only (:2365-2400)
+                if (L.lambda_l_dist > 0.f || L.lambda_l_dist_a > 0.f) {
+                    float gw = 0.f, ga = 0.f;
+                    const float wi = WE(sample_i), ai = AL(sample_i);
+                    for (int j = 0; j < n; ++j) {
+                        const float tj = TS(j);
+                        const float sgn = (ts_i > tj) ? 1.f : (ts_i < tj) ? -1.f : 0.f;
+                        gw += sgn * wi * WE(j);
+                        ga += sgn * ai * AL(j);
+                    }
+                    gst += L.lambda_l_dist * gw + L.lambda_l_dist_a * ga;
+                }
+                if (L.lambda_l_samp_dist > 0.f) {
+                    const float sgn = (sample_t_mean > ts_i) ? 1.f : (sample_t_mean < ts_i) ? -1.f : 0.f;
+                    gst += L.lambda_l_samp_dist *
+                           (shared_Dmeant_sign * AL(sample_i) / sample_weight_sum + sgn * (-1.f));
+                }
+                const float trunc_reweight =
+                    o.truncated_vol_render ? trunc_rw((float)((meta >> 8) - 1), trunc_a, o.trunc_vol_weight_min)
+                                           : 1.f;
+                if (L.lambda_conv_mode_samp > 0.f && trunc_reweight > o.trunc_vol_weight_min) {
+                    const float tm = TS(max_sample_id);
+                    const float gcm = (ts_i > tm) ? 1.f : (ts_i < tm) ? -1.f : 0.f;
+                    gst += L.lambda_conv_mode_samp * gcm;
+                }
+            }
+            if (sample_i < M - 1) sample_i += 1;
+        }
+        S.cgr[idx] = cgr;
+        S.gst[idx] = gst;
+        // the reference tests stop_thresh once per voxel, after all of its samples (:2893-2895)
+        const bool last_of_voxel = (r + 1 >= n_rec) || (S.v[(size_t)(r + 1) * Q + q] != S.v[idx]);
+        if (last_of_voxel && expf(log_transmit) < o.stop_thresh) {
+            ++r;
+            break;
+        }
+    }
+    S.n_eff[q] = min(r, n_rec);
+}
+
+// ------------------------------------------------------------------------------------
+template <int B>
+__global__ void __launch_bounds__(kBlock)
+k_bwd_sh(KGrid g, KGrads G, int want_dpos, const float* __restrict__ dirs, long long Q, SampleRec S) {
+    using C = Coop<B>;
+    __shared__ float s_sph[kBlock * kSphPad];
+    __shared__ LaneRec s_rec[kBlock];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int r = blockIdx.y;
+    const long long q = (long long)blockIdx.x * kBlock + tid;
+    const bool mine = (q < Q) && (r < S.n_eff[q]);
+    const unsigned long long need0 = __ballot(mine);
+    if (!need0) return;
+    const size_t idx = (size_t)r * Q + (mine ? q : 0);
+    float pos[3] = {0.f, 0.f, 0.f}, gch[3] = {0.f, 0.f, 0.f};
+    bool real = false;
+    if (mine) {
+        const int pv = S.v[idx];
+        const int vx = pv >> 20, vy = (pv >> 10) & 1023, vz = pv & 1023;
+        const int32_t* p = g.links + ((size_t)vx * g.offx + (size_t)vy * g.offy + vz);
+        s_rec[tid].link[0] = p[0];
+        s_rec[tid].link[1] = p[1];
+        s_rec[tid].link[2] = p[g.offy];
+        s_rec[tid].link[3] = p[g.offy + 1];
+        s_rec[tid].link[4] = p[g.offx];
+        s_rec[tid].link[5] = p[g.offx + 1];
+        s_rec[tid].link[6] = p[g.offx + g.offy];
+        s_rec[tid].link[7] = p[g.offx + g.offy + 1];
+        float d[3] = {dirs[3 * q], dirs[3 * q + 1], dirs[3 * q + 2]};
+        float sph[B];
+        eval_sh<B>(d, sph);
+#pragma unroll
+        for (int k = 0; k < B; ++k) s_sph[tid * kSphPad + k] = sph[k];
+        pos[0] = S.px[idx];
+        pos[1] = S.py[idx];
+        pos[2] = S.pz[idx];
+        gch[0] = S.g0[idx];
+        gch[1] = S.g1[idx];
+        gch[2] = S.g2[idx];
+        real = !(S.m[idx] & 1);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    const float* sph_wave = s_sph + (tid & ~63) * kSphPad;
+    const LaneRec* rec_wave = s_rec + (tid & ~63);
+    const int cs = lane / C::D;
+    const int e = lane - cs * C::D;
+    const int ch = e / B;
+    const int k = e - ch * B;
+    const bool on = cs < C::CPR;
+    float gx_out = 0.f, gy_out = 0.f, gz_out = 0.f;
+    unsigned long long need = need0;
+    while (need) {
+        const int sl = __ffsll((long long)need) - 1;
+        need &= need - 1;
+        const float px = bcast_f(pos[0], sl), py = bcast_f(pos[1], sl), pz = bcast_f(pos[2], sl);
+        const float g0 = bcast_f(gch[0], sl), g1 = bcast_f(gch[1], sl), g2 = bcast_f(gch[2], sl);
+        // fake samples carry no d/dpos (surf_trav.cu:2722)
+        const bool dpos = want_dpos && (bcast_i(real ? 1 : 0, sl) != 0);
+        const float sphk = on ? sph_wave[sl * kSphPad + k] : 0.f;
+        const float cg = sphk * ((ch == 0) ? g0 : (ch == 1) ? g1 : g2);  // :2120-2122
+        float ax = 0.f, ay = 0.f, az = 0.f;
+#pragma unroll
+        for (int rd = 0; rd < C::ROUNDS; ++rd) {
+            const int c = rd * C::CPR + cs;
+            if (on && c < 8) {
+                const int link = rec_wave[sl].link[c];
+                const float wx = (c & 4) ? px : 1.f - px;
+                const float wy = (c & 2) ? py : 1.f - py;
+                const float wz = (c & 1) ? pz : 1.f - pz;
+                if (G.grad_sh != nullptr) atomicAdd(&G.grad_sh[(size_t)link * C::D + e], wx * wy * wz * cg);
+                if (dpos) {
+                    const float val = g.sh[(size_t)link * C::D + e];
+                    ax = fmaf(((c & 4) ? wy : -wy) * wz, val, ax);
+                    ay = fmaf(((c & 2) ? wx : -wx) * wz, val, ay);
+                    az = fmaf(((c & 1) ? wx : -wx) * wy, val, az);
+                }
+            }
+        }
+        if (dpos) {  // :2249-2264
+            const float gx = wave_sum(cg * ax), gy = wave_sum(cg * ay), gz = wave_sum(cg * az);
+            if (lane == sl) {
+                gx_out = gx;
+                gy_out = gy;
+                gz_out = gz;
+            }
+        }
+    }
+    if (mine) {
+        S.gx[idx] = gx_out;
+        S.gy[idx] = gy_out;
+        S.gz[idx] = gz_out;
+    }
+}
+
+// ------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(kBlock)
+k_bwd_geo(KGrid g, KOpt o, KLoss L, KGrads G, const float* __restrict__ origins,
+          const float* __restrict__ dirs, long long Q, SampleRec S) {
+    const int r_i = blockIdx.y;
+    const long long q = (long long)blockIdx.x * kBlock + threadIdx.x;
+    if (q >= Q) return;
+    if (r_i >= S.n_eff[q]) return;
+    const size_t idx = (size_t)r_i * Q + q;
+    const int meta = S.m[idx];
+    const bool fake = meta & 1;
+    const int st_id = (meta >> 1) & 3;
+    const int li = (meta >> 3) & 31;
+    const int ord = (meta >> 8) - 1;  // intersect_i at the sample
+    Ray r;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        r.o[k] = origins[3 * q + k];
+        r.d[k] = dirs[3 * q + k];
+    }
+    setup_ray(g, o, r);
+    Vox v;
+    load_voxel(g, r, S.v[idx], v);
+    const float raw_alpha = S.raw[idx];
+    const float weight = S.w[idx];
+    const float sws = S.sws[q];
+    float cgr = S.cgr[idx];
+    const float alpha = alpha_act(raw_alpha, o.alpha_activation_type);
+    const float trunc_reweight =
+        o.truncated_vol_render ? trunc_rw((float)ord, g.trunc_a, o.trunc_vol_weight_min) : 1.f;
+    auto sparsity_term = [&](float curr, float a) -> float {  // :2286-2300
+        const float _1_a = clamp_lo(1.f - a);
+        const double add = -(double)L.sparsity_loss * (1.0 / fmin((double)(_1_a * logf(_1_a)), -1e-8)) *
+                           (double)(1.f - weight / sws);
+        return (float)((double)curr + add);
+    };
+    auto inwards = [&](const float* pos, float& curr) {  // :2302-2323
+        float sg[3];
+        field_grad(v.surf, pos, sg);
+        const float nn = clamp_lo(sqrtf(sqrf(sg[0]) + sqrf(sg[1]) + sqrf(sg[2])));
+        const float nd = (-sg[0] / nn) * r.d[0] + (-sg[1] / nn) * r.d[1] + (-sg[2] / nn) * r.d[2];
+        if (nd > 0.f) curr += L.lambda_inwards_norm_loss * sqrf(nd);
+    };
+
+    if (!fake) {
+        const float lvf = g.level_set[li];
+        double fs[4] = {v.fs[0] - (double)lvf, v.fs[1], v.fs[2], v.fs[3]};
+        double st[3] = {-1, -1, -1};
+        const int root_type = solve_cubic_vieta(fs[0], fs[1], fs[2], fs[3], st);
+        const double stv = (st_id == 0) ? st[0] : (st_id == 1) ? st[1] : st[2];
+        float pos[3];
+        root_position(r, v, stv, pos);
+        if (L.sparsity_loss > 0.f && raw_alpha > 0.f) cgr = sparsity_term(cgr, alpha);
+        if (L.lambda_inwards_norm_loss > 0.f) inwards(pos, cgr);
+        const float curr_grad_alpha = cgr * trunc_reweight;
+        float curr_grad_raw_alpha = curr_grad_alpha * alpha_act_grad(alpha, o.alpha_activation_type);
+        {
+            float cw[8];
+            corner_weights(pos, curr_grad_raw_alpha, cw);
+            scatter8(G.grad_density, G.mask, v.lk, cw);
+        }
+        if (L.lambda_l_di > 0.f && alpha < L.l_di_alpha_thresh)
+            curr_grad_raw_alpha += L.lambda_l_di * (-1.f) * alpha_act_grad(alpha, o.alpha_activation_type);
+        float grad_xyz[3] = {S.gx[idx], S.gy[idx], S.gz[idx]};
+        trilerp_dpos(v.dens, pos, curr_grad_raw_alpha, grad_xyz);
+        float grad_st = grad_xyz[0] * r.d[0] + grad_xyz[1] * r.d[1] + grad_xyz[2] * r.d[2];
+        grad_st += S.gst[idx];
+        float grad_fs[4] = {grad_st, grad_st, grad_st, grad_st};
+        cubic_root_grad_vieta(root_type, st_id, fs, grad_fs);
+        float gsurf[8];
+        const float nof[3] = {(float)((double)v.new_origin[0] - (double)v.vx),
+                              (float)((double)v.new_origin[1] - (double)v.vy),
+                              (float)((double)v.new_origin[2] - (double)v.vz)};
+        surface_cubic_grad(nof, r.d, grad_fs, gsurf);
+        scatter8(G.grad_surface, G.mask, v.lk, gsurf);
+        if (alpha < L.surf_sparse_alpha_thresh) {  // :2436-2445
+            float cw[8];
+            corner_weights(pos, L.lambda_inplace_surf_sparse, cw);
+            scatter8(G.grad_surface, G.mask, v.lk, cw);
+        }
+    } else {  // fake sample (:2460-2866)
+        float pos[3];
+        fake_position(r, v, pos);
+        double miu, sd;
+        const float dist = fake_distance(g, o, v, pos, &miu, &sd);
+        const float reweight = expf((float)(-.5 * (double)sqrf(dist / g.fake_sample_std)));
+        const float rw_alpha = alpha * reweight * trunc_reweight;
+        if (L.sparsity_loss > 0.f && raw_alpha > 0.f) cgr = sparsity_term(cgr, rw_alpha);
+        if (L.lambda_inwards_norm_loss > 0.f) inwards(pos, cgr);
+        const float curr_grad_alpha = cgr * reweight * trunc_reweight;
+        const float curr_grad_raw_alpha = curr_grad_alpha * alpha_act_grad(alpha, o.alpha_activation_type);
+        {
+            float cw[8];
+            corner_weights(pos, curr_grad_raw_alpha, cw);
+            scatter8(G.grad_density, G.mask, v.lk, cw);
+        }
+        const float grad_fake_dist =
+            cgr * (-alpha * trunc_reweight * dist * reweight / sqrf(g.fake_sample_std));
+        float grad_ns[8];
+        corner_weights(pos, grad_fake_dist, grad_ns);
+        float gsurf[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (!o.fake_sample_normalize_surf) {
+#pragma unroll
+            for (int ks = 0; ks < 8; ++ks) gsurf[ks] = grad_ns[ks];
+        } else {
+            const double std3 = cubd(sd);
+#pragma unroll
+            for (int ks = 0; ks < 8; ++ks) {
+#pragma unroll
+                for (int kn = 0; kn < 8; ++kn) {
+                    double jac = (double)v.surf[kn] * (miu - (double)v.surf[ks]) / 8.f / std3;
+                    if (ks == kn) jac += 1.f / sd;
+                    gsurf[ks] = (float)((double)gsurf[ks] + (double)grad_ns[kn] * jac);
+                }
+            }
+        }
+        scatter8(G.grad_surface, G.mask, v.lk, gsurf);
+        if (G.grad_fake_sample_std != nullptr) {
+            const float gstd = cgr * alpha * sqrf(dist) * reweight * trunc_reweight /
+                               (g.fake_sample_std * g.fake_sample_std * g.fake_sample_std);
+            atomicAdd(G.grad_fake_sample_std, gstd);
+        }
+    }
+}
+
+}  // namespace asurf

@@ -478,6 +478,23 @@ __device__ __forceinline__ void coop_shade_bwd(const KGrid& g, const KGrads& G, 
     }
 }
 
+// Float fields of a sample record, planes [8][R][Q]: raw opacity, re-weighted alpha, the three
+// pre-clamp colours, position inside the voxel (read by the split backward, asurf_bwd_pipeline.h)
+__device__ __forceinline__ void write_rec_floats(float* rec_f, int R, int slot, long long Q, long long q,
+                                                 float raw, float a, const float* color, const float* pos) {
+    if (rec_f == nullptr) return;
+    const size_t plane = (size_t)R * Q;
+    float* p = rec_f + (size_t)slot * Q + q;
+    p[0] = raw;
+    p[plane] = a;
+    p[2 * plane] = color[0];
+    p[3 * plane] = color[1];
+    p[4 * plane] = color[2];
+    p[5 * plane] = pos[0];
+    p[6 * plane] = pos[1];
+    p[7 * plane] = pos[2];
+}
+
 // per-lane scatter of 8 corner contributions into a [N,1] gradient plane + touched mask
 __device__ __forceinline__ void scatter8(float* out, uint8_t* mask, const int* lk, const float* w) {
     if (out == nullptr) return;
@@ -501,7 +518,7 @@ k_forward(KGrid g, KOpt o, const float* __restrict__ origins, const float* __res
           long long Q, float* __restrict__ rgb_out, int M, float* __restrict__ cache_a,
           float* __restrict__ cache_w, float* __restrict__ cache_t, int* __restrict__ cache_n,
           int* __restrict__ rec_v, int* __restrict__ rec_m, int* __restrict__ rec_n, int R,
-          const int* __restrict__ ray_list, const int* __restrict__ n_list,
+          float* __restrict__ rec_f, const int* __restrict__ ray_list, const int* __restrict__ n_list,
           unsigned long long* counters) {
     extern __shared__ unsigned int s_coarse[];
     __shared__ float s_sph[kBlock * kSphPad];
@@ -612,10 +629,10 @@ k_forward(KGrid g, KOpt o, const float* __restrict__ origins, const float* __res
                     if (ndd >= 0.f) cand = false;
                 }
                 bool shade = false;
-                float rwalpha = 0.f;
+                float rwalpha = 0.f, raw_alpha = 0.f;
                 if (cand) {
                     ++intersect_i;
-                    const float raw_alpha = trilerp8(v.dens, pos);
+                    raw_alpha = trilerp8(v.dens, pos);
                     if (raw_alpha > o.sigma_thresh) {
                         const float alpha = alpha_act(raw_alpha, o.alpha_activation_type);
                         const float rw = o.truncated_vol_render
@@ -650,6 +667,7 @@ k_forward(KGrid g, KOpt o, const float* __restrict__ origins, const float* __res
                             if (rec_cnt < R) {
                                 rec_v[(size_t)rec_cnt * Q + q] = pack_voxel(v.vx, v.vy, v.vz);
                                 rec_m[(size_t)rec_cnt * Q + q] = ((intersect_i + 1) << 8) | (li << 3) | (j << 1);
+                                write_rec_floats(rec_f, R, rec_cnt, Q, q, raw_alpha, rwalpha, color, pos);
                                 ++rec_cnt;
                             } else {
                                 rec_over = true;
@@ -665,10 +683,11 @@ k_forward(KGrid g, KOpt o, const float* __restrict__ origins, const float* __res
                       (!o.limited_fake_sample || vox_has_surf) &&
                       ((v.t_far - v.t_close) > o.surf_fake_sample_min_vox_len);
             float pos[3] = {0.f, 0.f, 0.f};
-            float alpha = 0.f;
+            float alpha = 0.f, raw_f = 0.f;
             if (fk) {
                 fake_position(r, v, pos);
                 alpha = trilerp8(v.dens, pos);
+                raw_f = alpha;
                 fk = alpha > o.sigma_thresh;
             }
             if (fk) {
@@ -706,6 +725,7 @@ k_forward(KGrid g, KOpt o, const float* __restrict__ origins, const float* __res
                         if (rec_cnt < R) {
                             rec_v[(size_t)rec_cnt * Q + q] = pack_voxel(v.vx, v.vy, v.vz);
                             rec_m[(size_t)rec_cnt * Q + q] = ((intersect_i + 1) << 8) | 1;
+                            write_rec_floats(rec_f, R, rec_cnt, Q, q, raw_f, alpha, color, pos);
                             ++rec_cnt;
                         } else {
                             rec_over = true;

@@ -276,7 +276,7 @@ __global__ void __launch_bounds__(kBlock)
 k_comp(KGrid g, KOpt o, const float* __restrict__ dirs, long long Q, PipeBuf P,
        float* __restrict__ rgb_out, int M, float* __restrict__ cache_a, float* __restrict__ cache_w,
        float* __restrict__ cache_t, int* __restrict__ cache_n, int* __restrict__ rec_v,
-       int* __restrict__ rec_m, int* __restrict__ rec_n, int R) {
+       int* __restrict__ rec_m, int* __restrict__ rec_n, int R, float* __restrict__ rec_f) {
     __shared__ float s_sph[kBlock * kSphPad];
     __shared__ LaneRec s_rec[kBlock];
     const int tid = threadIdx.x;
@@ -380,6 +380,7 @@ k_comp(KGrid g, KOpt o, const float* __restrict__ dirs, long long Q, PipeBuf P,
                 if (rec_cnt < R) {
                     rec_v[(size_t)rec_cnt * Q + q] = pv;
                     rec_m[(size_t)rec_cnt * Q + q] = ((intersect_i + 1) << 8) | (cr.meta & 0xff);
+                    write_rec_floats(rec_f, R, rec_cnt, Q, q, cr.raw, a, color, pos);
                     ++rec_cnt;
                 } else {
                     rec_over = true;

@@ -243,10 +243,17 @@ def test_replay_equals_walking_backward(hip, monkeypatch):
         monkeypatch.setenv("ASURF_NO_REPLAY", "1")
         rgb2, g2 = hip.render_fused(sc, o, d, OPTION_SETS[optname], gt, fused)
         monkeypatch.delenv("ASURF_NO_REPLAY", raising=False)
-        assert np.abs(rgb1 - rgb2).max() == 0
+        # replay in one kernel instead of three, and the one-kernel forward instead of the pipeline
+        monkeypatch.setenv("ASURF_NO_SPLIT_BWD", "1")
+        monkeypatch.setenv("ASURF_NO_PIPELINE", "1")
+        rgb3, g3 = hip.render_fused(sc, o, d, OPTION_SETS[optname], gt, fused)
+        monkeypatch.delenv("ASURF_NO_SPLIT_BWD", raising=False)
+        monkeypatch.delenv("ASURF_NO_PIPELINE", raising=False)
+        assert np.abs(rgb1 - rgb2).max() <= 1e-6 and np.abs(rgb1 - rgb3).max() <= 1e-6
         for k in ("sh", "density", "surface"):
-            grad_close(g1[k], g2[k], 1e-5, f"{optname} grad_{k}")
-        assert (g1["mask"] == g2["mask"]).all()
+            grad_close(g1[k], g2[k], 1e-5, f"{optname} grad_{k} (replay vs walk)")
+            grad_close(g1[k], g3[k], 1e-5, f"{optname} grad_{k} (split vs one-kernel)")
+        assert (g1["mask"] == g2["mask"]).all() and (g1["mask"] == g3["mask"]).all()
 
 
 def test_error_behaviour(hip):
