@@ -118,6 +118,10 @@ struct Walk {
     float tf0, tf1, tf2; // far-plane crossing times of the NEXT voxel
     int sx, sy, sz;      // step direction per axis (+1 / -1)
     float t, t_far;
+    // per-ray constants as scalars: selecting between array elements of Ray / KGrid makes the
+    // compiler index them in scratch / kernarg memory inside the DDA loop
+    float ox, oy, oz, dx, dy, dz, t_leave;
+    int lim0, lim1, lim2;
     // register cache of the occupancy pyramid
     int cur_key;         // packed brick coordinates
     int cur_brick;       // linear brick index
@@ -133,21 +137,25 @@ __device__ __forceinline__ float plane_time(int n, int s, float o, float d) {
 
 __device__ __forceinline__ void walk_init(const KGrid& g, const Ray& r, Walk& w) {
     w.t = r.tmin;
-    int v[3];
-#pragma unroll
-    for (int j = 0; j < 3; ++j) {
-        v[j] = (int)fmaf(w.t, r.d[j], r.o[j]);
-        v[j] = min(max(v[j], 0), g.size[j] - 2);
-    }
-    w.nx = v[0];
-    w.ny = v[1];
-    w.nz = v[2];
-    w.sx = (r.d[0] > 0.f) ? 1 : -1;
-    w.sy = (r.d[1] > 0.f) ? 1 : -1;
-    w.sz = (r.d[2] > 0.f) ? 1 : -1;
-    w.tf0 = plane_time(w.nx, w.sx, r.o[0], r.d[0]);
-    w.tf1 = plane_time(w.ny, w.sy, r.o[1], r.d[1]);
-    w.tf2 = plane_time(w.nz, w.sz, r.o[2], r.d[2]);
+    w.ox = r.o[0];
+    w.oy = r.o[1];
+    w.oz = r.o[2];
+    w.dx = r.d[0];
+    w.dy = r.d[1];
+    w.dz = r.d[2];
+    w.t_leave = r.tmax + 1.f;
+    w.lim0 = g.size[0] - 1;
+    w.lim1 = g.size[1] - 1;
+    w.lim2 = g.size[2] - 1;
+    w.nx = min(max((int)fmaf(w.t, w.dx, w.ox), 0), w.lim0 - 1);
+    w.ny = min(max((int)fmaf(w.t, w.dy, w.oy), 0), w.lim1 - 1);
+    w.nz = min(max((int)fmaf(w.t, w.dz, w.oz), 0), w.lim2 - 1);
+    w.sx = (w.dx > 0.f) ? 1 : -1;
+    w.sy = (w.dy > 0.f) ? 1 : -1;
+    w.sz = (w.dz > 0.f) ? 1 : -1;
+    w.tf0 = plane_time(w.nx, w.sx, w.ox, w.dx);
+    w.tf1 = plane_time(w.ny, w.sy, w.oy, w.dy);
+    w.tf2 = plane_time(w.nz, w.sz, w.oz, w.dz);
     w.vx = w.vy = w.vz = 0;
     w.t_far = 0.f;
     w.cur_key = -1;
@@ -166,13 +174,18 @@ __device__ __forceinline__ void walk_step(const KGrid& g, const Ray& r, Walk& w)
     w.t_far = t_far;
     const bool a0 = (t_far == w.tf0);
     const bool a1 = !a0 && (t_far == w.tf1);
-    const int n_new = a0 ? w.nx + w.sx : (a1 ? w.ny + w.sy : w.nz + w.sz);
-    const int lim = a0 ? g.size[0] - 1 : (a1 ? g.size[1] - 1 : g.size[2] - 1);
-    const int s = a0 ? w.sx : (a1 ? w.sy : w.sz);
-    const float o = a0 ? r.o[0] : (a1 ? r.o[1] : r.o[2]);
-    const float d = a0 ? r.d[0] : (a1 ? r.d[1] : r.d[2]);
+    // read every member unconditionally first: a load inside a ?: arm is merged by the
+    // optimiser into one load from a selected ADDRESS, which pins the struct in scratch
+    const int nx = w.nx, ny = w.ny, nz = w.nz, sx = w.sx, sy = w.sy, sz = w.sz;
+    const int l0 = w.lim0, l1 = w.lim1, l2 = w.lim2;
+    const float ox = w.ox, oy = w.oy, oz = w.oz, dx = w.dx, dy = w.dy, dz = w.dz;
+    const int n_new = a0 ? nx + sx : (a1 ? ny + sy : nz + sz);
+    const int lim = a0 ? l0 : (a1 ? l1 : l2);
+    const int s = a0 ? sx : (a1 ? sy : sz);
+    const float o = a0 ? ox : (a1 ? oy : oz);
+    const float d = a0 ? dx : (a1 ? dy : dz);
     const bool leaves = (n_new < 0) || (n_new >= lim);
-    w.t = leaves ? r.tmax + 1.f : t_far;
+    w.t = leaves ? w.t_leave : t_far;
     const float q = plane_time(n_new, s, o, d);
     if (a0) {
         w.nx = n_new;

@@ -29,6 +29,18 @@ struct CandRec {  // 32 bytes
     int pad;
 };
 
+// value-select store: keeps the candidates in registers (selecting a destination ADDRESS
+// would put them in scratch)
+__device__ __forceinline__ void cand_put(CandRec& dst, const CandRec& src, bool sel) {
+    dst.px = sel ? src.px : dst.px;
+    dst.py = sel ? src.py : dst.py;
+    dst.pz = sel ? src.pz : dst.pz;
+    dst.ts = sel ? src.ts : dst.ts;
+    dst.raw = sel ? src.raw : dst.raw;
+    dst.ext = sel ? src.ext : dst.ext;
+    dst.meta = sel ? src.meta : dst.meta;
+}
+
 // The candidate pool is cut into shards with their own cursors so that the allocating
 // atomics of k_geom do not serialise on one address.
 constexpr int kPoolShards = 256;
@@ -150,8 +162,11 @@ k_walk(KGrid g, KOpt o, const float* __restrict__ origins, const float* __restri
 // ------------------------------------------------------------------------------------
 // SPILL = false: grid (ceil(Q/256), C1), block row s handles table slot s of 256 rays.
 // SPILL = true : 1-D grid over the spill list.
+#ifndef ASURF_GEOM_WAVES
+#define ASURF_GEOM_WAVES 3
+#endif
 template <bool SPILL>
-__global__ void __launch_bounds__(kBlock)
+__global__ void __launch_bounds__(kBlock, ASURF_GEOM_WAVES)
 k_geom(KGrid g, KOpt o, const float* __restrict__ origins, const float* __restrict__ dirs,
        long long Q, PipeBuf P) {
     long long q;
@@ -174,7 +189,11 @@ k_geom(KGrid g, KOpt o, const float* __restrict__ origins, const float* __restri
         if (mine) packed_voxel = P.items[entry];
     }
     if (!__any(mine)) return;
-    CandRec c[3];
+    CandRec c0, c1, c2;
+    c0.px = c0.py = c0.pz = c0.ts = c0.raw = c0.ext = 0.f;
+    c0.meta = c0.pad = 0;
+    c1 = c0;
+    c2 = c0;
     int nc = 0;
     bool overflow = false;
     if (mine) {
@@ -207,7 +226,7 @@ k_geom(KGrid g, KOpt o, const float* __restrict__ origins, const float* __restri
                     if (ndd >= 0.f) continue;
                 }
                 if (nc < 3) {
-                    CandRec& cr = (nc == 0) ? c[0] : (nc == 1) ? c[1] : c[2];
+                    CandRec cr;
                     cr.px = pos[0];
                     cr.py = pos[1];
                     cr.pz = pos[2];
@@ -216,6 +235,9 @@ k_geom(KGrid g, KOpt o, const float* __restrict__ origins, const float* __restri
                     cr.ext = 0.f;
                     cr.meta = (li << 3) | (j << 1);
                     cr.pad = 0;
+                    cand_put(c0, cr, nc == 0);
+                    cand_put(c1, cr, nc == 1);
+                    cand_put(c2, cr, nc == 2);
                     ++nc;
                 } else {
                     overflow = true;
@@ -230,14 +252,14 @@ k_geom(KGrid g, KOpt o, const float* __restrict__ origins, const float* __restri
             const float raw = trilerp8(v.dens, pos);
             if (raw > o.sigma_thresh) {
                 double miu, sd;
-                c[0].px = pos[0];
-                c[0].py = pos[1];
-                c[0].pz = pos[2];
-                c[0].ts = (v.t_far + v.t_close) / 2.f;
-                c[0].raw = raw;
-                c[0].ext = fake_distance(g, o, v, pos, &miu, &sd);
-                c[0].meta = 1;
-                c[0].pad = 0;
+                c0.px = pos[0];
+                c0.py = pos[1];
+                c0.pz = pos[2];
+                c0.ts = (v.t_far + v.t_close) / 2.f;
+                c0.raw = raw;
+                c0.ext = fake_distance(g, o, v, pos, &miu, &sd);
+                c0.meta = 1;
+                c0.pad = 0;
                 nc = 1;
             }
         }
@@ -261,9 +283,9 @@ k_geom(KGrid g, KOpt o, const float* __restrict__ origins, const float* __restri
         if (atomicExch(&P.n_items[q], -1) >= 0) P.flagged[atomicAdd(&P.counters[0], 1)] = (int)q;
     } else if (nc > 0) {
         const int base = shard * P.shard_cap + rel;
-#pragma unroll
-        for (int i = 0; i < 3; ++i)
-            if (i < nc) P.pool[base + i] = c[i];
+        P.pool[base] = c0;
+        if (nc > 1) P.pool[base + 1] = c1;
+        if (nc > 2) P.pool[base + 2] = c2;
         packed = (base << 2) | nc;
     }
     if constexpr (SPILL) P.sp_citem[entry] = packed;
