@@ -1124,10 +1124,410 @@ Dump make_dump(const oracle_stats* st, int64_t q) {
     return d;
 }
 
+// ---------------------------------------------------------------------------------
+// Legacy `surface` backend (render_lerp_kernel_surface.cu): the caller supplies each
+// ray's voxel list; coefficients are taken about the ray ORIGIN (global t), the solver
+// is the f/g/h form, alpha is always a sigmoid, one level set, no sigma gate.
+// ---------------------------------------------------------------------------------
+constexpr int CUBIC_ONE_R = 204;  // data_spec.hpp:24-31 (triple root)
+
+// render_util.cuh:753-787
+void surface_cubic_global(const double* s, const double* o, const double* d, const int32_t* l,
+                          double* f) {
+    double lo[3], hi[3];  // trilinear factors at t = 0: corner bit 0 / bit 1
+    for (int k = 0; k < 3; ++k) {
+        lo[k] = 1 - o[k] + l[k];
+        hi[k] = o[k] - l[k];
+    }
+    double c[2], dd[2], e[2];
+    for (int x = 0; x < 2; ++x) {
+        const double* sx = s + 4 * x;
+        const double a0 = sx[0] * lo[2] + sx[1] * hi[2];
+        const double a1 = sx[2] * lo[2] + sx[3] * hi[2];
+        const double b0 = -sx[0] + sx[1];
+        const double b1 = -sx[2] + sx[3];
+        c[x] = a0 * lo[1] + a1 * hi[1];
+        dd[x] = -(a0 * d[1] - d[2] * b0 * lo[1]) + (a1 * d[1] + d[2] * b1 * hi[1]);
+        e[x] = -d[1] * d[2] * b0 + d[1] * d[2] * b1;
+    }
+    f[3] = -e[0] * d[0] + e[1] * d[0];
+    f[2] = -dd[0] * d[0] + e[0] * lo[0] + dd[1] * d[0] + e[1] * hi[0];
+    f[1] = -c[0] * d[0] + dd[0] * lo[0] + c[1] * d[0] + dd[1] * hi[0];
+    f[0] = c[0] * lo[0] + c[1] * hi[0];
+}
+
+inline double cond_cbrt(double x) { return (x >= 0) ? cbrt(x) : -1. * cbrt(-x); }  // util.hpp:33
+inline double d_cond_cbrt(double x) {                                             // util.hpp:36
+    return (x >= 0) ? ((x > 0) ? (1. / 3. / sqrd(cbrt(x))) : 1.) : cbrt(-x) / -3. / x;
+}
+
+// render_util.cuh:940-1102
+int solve_cubic_legacy(double f0, double f1, double f2, double f3, double eps, double* st) {
+    auto tiny = [&](double x) { return std::abs(x) < eps; };
+    if (tiny(f3)) {
+        if (tiny(f2)) {
+            if (tiny(f1)) return CUBIC_NO_ROOT;
+            st[0] = -f0 / f1;
+            return CUBIC_LINEAR;
+        }
+        const double D = sqrd(f1) - 4.0 * f2 * f0;
+        const double sD = sqrt(D);
+        if (D > 0) {
+            if (f2 > 0) {
+                st[0] = (-f1 - sD) / (2 * f2);
+                st[1] = (-f1 + sD) / (2 * f2);
+            } else {
+                st[0] = (-f1 + sD) / (2 * f2);
+                st[1] = (-f1 - sD) / (2 * f2);
+            }
+            if (tiny(st[0] - st[1])) {
+                st[1] = -1;
+                return CUBIC_POLY_ONE_R;
+            }
+            return CUBIC_POLY;
+        }
+        return CUBIC_NO_ROOT;
+    }
+    const double b = f2 / f3, c = f1 / f3, d = f0 / f3;  // the reference's a == 1 exactly
+    const double f = ((3 * c) - sqrd(b)) / 3;
+    const double g = ((2 * cubd(b)) - (9 * b * c) + (27 * d)) / 27;
+    const double h = sqrd(g) / 4 + cubd(f) / 27;
+    if (tiny(f) & tiny(g) & tiny(h)) {
+        st[0] = cond_cbrt(d);
+        return CUBIC_ONE_R;
+    }
+    if (h <= 0) {
+        if (h == 0) return CUBIC_NO_ROOT;
+        const double i = sqrt((sqrd(g) / 4.) - h);
+        const double j = cbrt(i);
+        const double k = acos(-(g / (2 * i)));
+        const double M = cos(k / 3.);
+        const double N = sqrt(3) * sin(k / 3.);
+        const double P = (b / 3.) * -1;
+        st[0] = -1 * j * (M + N) + P;
+        st[1] = -1 * j * (M - N) + P;
+        st[2] = 2 * j * M + P;
+        return CUBIC_THREE_R;
+    }
+    const double R = -(g / 2.) + sqrt(h);
+    const double T = -(g / 2.) - sqrt(h);
+    st[0] = (cond_cbrt(R) + cond_cbrt(T)) - (b / 3.);
+    return CUBIC_ONE_R_;
+}
+
+// render_util.cuh:1418-1702: m[k] = d t / d f_k of root st_id (0 where the reference assigns 0)
+void cubic_root_grad_legacy_mult(int type, int st_id, const double* fs, double* m) {
+    for (int k = 0; k < 4; ++k) m[k] = 0.;
+    if (type == CUBIC_LINEAR) {
+        m[0] = -1. / fs[1];
+        m[1] = fs[0] / sqrd(fs[1]);
+        return;
+    }
+    if (type == CUBIC_POLY_ONE_R || type == CUBIC_POLY) {
+        const double D = sqrd(fs[1]) - 4. * fs[2] * fs[0];
+        const double sD = sqrt(D);
+        // smaller root (st_id 0 of the two-root case) takes the "+sqrt" branch of :1447-1451
+        const bool small = (type == CUBIC_POLY) && (st_id == 0);
+        const double sgn = small ? -1. : 1.;
+        const double dt_dD = sgn / (4. * fs[2] * sD);
+        const double den = (type == CUBIC_POLY) ? 2. * sqrd(fs[2]) : 4. * sqrd(fs[2]);
+        m[0] = -sgn / sD;
+        m[1] = (-1) / (2 * fs[2]) + (dt_dD * 2 * fs[1]);
+        m[2] = (fs[1] - sgn * sD) / den + (dt_dD * (-4) * fs[0]);
+        return;
+    }
+    const double b = fs[2] / fs[3], c = fs[1] / fs[3], d = fs[0] / fs[3];
+    // d(b,c,d)/d(f0..f3)
+    const double Db[4] = {0., 0., 1. / fs[3], (-fs[2]) / fs[3] / fs[3]};
+    const double Dc[4] = {0., 1. / fs[3], 0., (-fs[1]) / fs[3] / fs[3]};
+    const double Dd[4] = {1. / fs[3], 0., 0., (-fs[0]) / fs[3] / fs[3]};
+    if (type == CUBIC_ONE_R) {
+        const double dc = d_cond_cbrt(d);
+        m[0] = dc * Dd[0];
+        m[3] = dc * Dd[3];
+        return;
+    }
+    const double f = ((3. * c) - sqrd(b)) / 3.;
+    const double g = ((2. * cubd(b)) - (9. * b * c) + (27. * d)) / 27.;
+    const double h = sqrd(g) / 4. + cubd(f) / 27.;
+    const double Df_Db = -2. * b / 3., Df_Dc = 1.;
+    const double Dg_Db = -c / 3. + 2. * sqrd(b) / 9., Dg_Dc = -b / 3., Dg_Dd = 1.;
+    const double Dh_Df = sqrd(f) / 9., Dh_Dg = g / 2.;
+    const double Dh_Db = Dh_Df * Df_Db + Dh_Dg * Dg_Db;
+    const double Dh_Dc = Dh_Df * Df_Dc + Dh_Dg * Dg_Dc;
+    const double Dh_Dd = Dh_Dg * Dg_Dd;
+    double Dg[4], Dh[4];
+    for (int k = 0; k < 4; ++k) {
+        Dg[k] = Dg_Db * Db[k] + Dg_Dc * Dc[k] + Dg_Dd * Dd[k];
+        Dh[k] = Dh_Db * Db[k] + Dh_Dc * Dc[k] + Dh_Dd * Dd[k];
+    }
+    const double Dst_Db = -1. / 3.;
+    if (type == CUBIC_THREE_R) {
+        const double w = sqrd(g) / 4. - h;
+        const double i = sqrt(w);
+        const double j = cbrt(i);
+        const double k = acos(-(g / (2. * i)));
+        const double M = cos(k / 3.);
+        const double sn = sin(k / 3.);
+        const double N = sqrt(3.) * sn;
+        const double Dj_Dg = g / (12. * pow(w, 5. / 6.));
+        const double Dj_Dh = -1. / (6. * pow(w, 5. / 6.));
+        const double rad = sqrt(-sqrd(g) / (4. * w) + 1.);
+        const double Dk_Dg = -(sqrd(g) / (8. * pow(w, 3. / 2.)) - 1. / (2. * sqrt(w))) / rad;
+        const double Dk_Dh = g / (4. * pow(w, 3. / 2.) * rad);
+        double Dst_Dj, Dst_Dk;
+        if (st_id == 0) {
+            Dst_Dj = -M - N;
+            Dst_Dk = -j * (-sn / 3. + sqrt(3.) * M / 3.);
+        } else if (st_id == 1) {
+            Dst_Dj = -M + N;
+            Dst_Dk = -j * (-sn / 3. - sqrt(3.) * M / 3.);
+        } else {
+            Dst_Dj = 2. * M;
+            Dst_Dk = -2. * j * sn / 3.;
+        }
+        for (int q = 0; q < 4; ++q)
+            m[q] = Dst_Dj * (Dj_Dg * Dg[q] + Dj_Dh * Dh[q]) + Dst_Dk * (Dk_Dg * Dg[q] + Dk_Dh * Dh[q]) +
+                   Dst_Db * Db[q];
+    } else {  // CUBIC_ONE_R_
+        const double R = -(g / 2.) + sqrt(h);
+        const double T = -(g / 2.) - sqrt(h);
+        const double dR = d_cond_cbrt(R), dT = d_cond_cbrt(T);
+        const double DR_Dh = 1. / (2. * sqrt(h)), DT_Dh = -1. / (2. * sqrt(h));
+        for (int q = 0; q < 4; ++q)
+            m[q] = dR * (-0.5 * Dg[q] + DR_Dh * Dh[q]) + dT * (-0.5 * Dg[q] + DT_Dh * Dh[q]) +
+                   Dst_Db * Db[q];
+    }
+}
+
+// grad[k] holds dL/dt on entry, dL/df_k on exit (float32 products, as the reference)
+void cubic_root_grad_legacy(int type, int st_id, const double* fs, float* grad) {
+    double m[4];
+    cubic_root_grad_legacy_mult(type, st_id, fs, m);
+    for (int k = 0; k < 4; ++k) grad[k] = (m[k] == 0.) ? 0.f : grad[k] * (float)m[k];
+}
+
+// render_util.cuh:1705-1775: d f_k / d s_corner of surface_cubic_global, float32.
+// Each corner's trilinear weight along the ray is a product of three linear factors
+// (A_x + B_x t)(A_y + B_y t)(A_z + B_z t); f_k picks the t^k coefficient.
+template <typename T>
+void surface_cubic_global_grad_t(const float* o, const float* d, const int32_t* l, const T* gf,
+                                 float* gs) {
+    for (int cr = 0; cr < 8; ++cr) {
+        T A[3], Bc[3];
+        for (int k = 0; k < 3; ++k) {
+            const bool hi = (cr >> (2 - k)) & 1;
+            A[k] = hi ? (-(T)l[k] + (T)o[k]) : ((T)l[k] - (T)o[k] + 1);
+            Bc[k] = hi ? (T)d[k] : -(T)d[k];
+        }
+        const T t0 = A[0] * A[1] * A[2];
+        const T t1 = Bc[0] * A[1] * A[2] + A[0] * (Bc[1] * A[2] + Bc[2] * A[1]);
+        const T t2 = Bc[0] * (Bc[1] * A[2] + Bc[2] * A[1]) + Bc[1] * Bc[2] * A[0];
+        const T t3 = Bc[0] * Bc[1] * Bc[2];
+        gs[cr] = (float)((T)gf[0] * t0 + (T)gf[1] * t1 + (T)gf[2] * t2 + (T)gf[3] * t3);
+    }
+}
+
+// Diagnostic switch (tests only): carry dL/df_k and the expression above in float64.  The
+// reference works in float32, where the four terms cancel to ~1e-4 of their size for
+// far-away origins.
+int g_legacy_f64_surface_grad = 0;
+
+void legacy_surface_grad(int type, int st_id, const double* fs, float grad_st, const float* o,
+                         const float* d, const int32_t* l, float* gs) {
+    if (g_legacy_f64_surface_grad) {
+        double m[4];
+        cubic_root_grad_legacy_mult(type, st_id, fs, m);
+        for (int k = 0; k < 4; ++k) m[k] *= (double)grad_st;
+        surface_cubic_global_grad_t<double>(o, d, l, m, gs);
+    } else {
+        float gf[4] = {grad_st, grad_st, grad_st, grad_st};
+        cubic_root_grad_legacy(type, st_id, fs, gf);
+        surface_cubic_global_grad_t<float>(o, d, l, gf, gs);
+    }
+}
+
+inline float sigmoid_ref(float x) { return (float)(1. / (1. + (double)expf(-x))); }  // util.hpp:18
+
+struct LegacyVoxel {
+    int32_t l[3];
+    int32_t lk[8];
+    double fs[4];
+    bool has_level;
+};
+
+// gates + coefficients of one listed voxel; surface.cu:66-126 == :385-416
+bool legacy_load(const oracle_grid& g, const Ray& r, const int32_t* vox, LegacyVoxel& v) {
+    for (int k = 0; k < 3; ++k) v.l[k] = vox[k];
+    if ((v.l[0] + 1 >= g.size[0]) || (v.l[1] + 1 >= g.size[1]) || (v.l[2] + 1 >= g.size[2])) return false;
+    if (v.l[0] < 0 || v.l[1] < 0 || v.l[2] < 0) return false;  // (the reference would read out of bounds)
+    if (!voxel_links(g, v.l, v.lk)) return false;
+    double s[8];
+    double mn = 0, mx = 0;
+    for (int i = 0; i < 8; ++i) {
+        s[i] = (double)g.surface_data[v.lk[i]];
+        mn = (i == 0) ? s[i] : std::fmin(mn, s[i]);
+        mx = (i == 0) ? s[i] : std::fmax(mx, s[i]);
+    }
+    const double od[3] = {r.origin[0], r.origin[1], r.origin[2]};
+    const double dd[3] = {r.dir[0], r.dir[1], r.dir[2]};
+    surface_cubic_global(s, od, dd, v.l, v.fs);
+    const double lv = g.level_set_data[0];
+    v.has_level = !((lv < mn) || (lv > mx));
+    v.fs[0] -= lv;
+    return true;
+}
+
+bool legacy_position(const oracle_grid& g, const Ray& r, const LegacyVoxel& v, double st, float* pos) {
+    for (int k = 0; k < 3; ++k) {
+        pos[k] = fmaf((float)st, r.dir[k], r.origin[k]);
+        pos[k] -= (float)std::min(v.l[k], g.size[k] - 2);
+    }
+    return !((pos[0] < 0) | (pos[0] > 1) | (pos[1] < 0) | (pos[1] > 1) | (pos[2] < 0) | (pos[2] > 1));
+}
+
+void legacy_shade(const oracle_grid& g, const Ray& r, const int32_t* lk, const float* pos, float* color) {
+    const int B = g.basis_dim;
+    for (int c = 0; c < 3; ++c) {
+        float acc = 0.f;
+        for (int k = 0; k < B; ++k) {
+            float v[8];
+            for (int i = 0; i < 8; ++i) v[i] = g.sh_data[(size_t)lk[i] * (3 * B) + c * B + k];
+            acc += trilerp(v, pos) * r.sph[k];
+        }
+        color[c] = acc;
+    }
+}
+
+// surface.cu:35-234
+void legacy_forward(const oracle_grid& g, const oracle_render_options& o, const Ray& r,
+                    const int32_t* voxel_ls, int32_t start, int32_t num, float* out_rgb) {
+    const float bg = (g.background_nlayers == 0) ? o.background_brightness : 0.f;
+    if (r.tmin > r.tmax) {
+        for (int c = 0; c < 3; ++c) out_rgb[c] = bg;
+        return;
+    }
+    float outv[3] = {0.f, 0.f, 0.f};
+    float log_transmit = 0.f;
+    for (int vi = 0; vi < num; ++vi) {
+        LegacyVoxel v;
+        if (!legacy_load(g, r, voxel_ls + 3 * ((size_t)start + vi), v)) continue;
+        if (v.has_level) {
+            double st[3] = {-1, -1, -1};
+            solve_cubic_legacy(v.fs[0], v.fs[1], v.fs[2], v.fs[3], 1e-10, st);
+            for (int j = 0; j < 3; ++j) {
+                if (st[j] <= 0) continue;
+                float pos[3];
+                if (!legacy_position(g, r, v, st[j], pos)) continue;
+                float dens[8];
+                for (int i = 0; i < 8; ++i) dens[i] = g.density_data[v.lk[i]];
+                const float alpha = sigmoid_ref(trilerp(dens, pos));
+                float color[3];
+                legacy_shade(g, r, v.lk, pos, color);
+                const float pcnt = -1 * logf(1 - alpha);
+                const float weight = expf(log_transmit) * (1.f - expf(-pcnt));
+                log_transmit -= pcnt;
+                for (int c = 0; c < 3; ++c) outv[c] += weight * fmaxf(color[c] + 0.5f, 0.f);
+            }
+        }
+        if (expf(log_transmit) < o.stop_thresh) {
+            log_transmit = -1e3f;
+            break;
+        }
+    }
+    if (g.background_nlayers == 0)
+        for (int c = 0; c < 3; ++c) outv[c] += expf(log_transmit) * o.background_brightness;
+    for (int c = 0; c < 3; ++c) out_rgb[c] = outv[c];
+}
+
+// surface.cu:341-645
+void legacy_backward(const oracle_grid& g, const oracle_render_options& o, const Ray& r,
+                     const int32_t* voxel_ls, int32_t start, int32_t num, const float* gout,
+                     const float* color_cache, float sparsity_loss, const oracle_grads& G) {
+    const int B = g.basis_dim, D = 3 * B;
+    float accum = fmaf(color_cache[0], gout[0], fmaf(color_cache[1], gout[1], color_cache[2] * gout[2]));
+    if (r.tmin > r.tmax) return;
+    float log_transmit = 0.f;
+    for (int vi = 0; vi < num; ++vi) {
+        LegacyVoxel v;
+        if (!legacy_load(g, r, voxel_ls + 3 * ((size_t)start + vi), v)) continue;
+        if (v.has_level) {
+            double st[3] = {-1, -1, -1};
+            const int type = solve_cubic_legacy(v.fs[0], v.fs[1], v.fs[2], v.fs[3], 1e-10, st);
+            for (int j = 0; j < 3; ++j) {
+                if (st[j] <= 0) continue;
+                float pos[3];
+                if (!legacy_position(g, r, v, st[j], pos)) continue;
+                float dens[8];
+                for (int i = 0; i < 8; ++i) dens[i] = g.density_data[v.lk[i]];
+                const float raw_alpha = trilerp(dens, pos);
+                const float alpha = sigmoid_ref(raw_alpha);
+                float color[3];
+                legacy_shade(g, r, v.lk, pos, color);
+                const float pcnt = -1 * logf(1 - alpha);
+                const float weight = expf(log_transmit) * (1.f - expf(-pcnt));
+                float total_ch[3], in01[3];
+                for (int c = 0; c < 3; ++c) {
+                    const float lc = color[c] + 0.5f;
+                    const float cl = fmaxf(lc, 0.f);
+                    in01[c] = (cl == lc) ? 1.f : 0.f;
+                    total_ch[c] = cl * gout[c];
+                }
+                const float total_color = (total_ch[0] + total_ch[2]) + total_ch[1];  // :487-489
+                accum -= weight * total_color;
+                float curr_grad_alpha = accum / (alpha - 1) + total_color * expf(log_transmit);
+                log_transmit -= pcnt;
+                if (sparsity_loss > 0.f) curr_grad_alpha += sparsity_loss * (4 * alpha / (1 + 2 * (alpha * alpha)));
+                // SH scatter (:508-513) and d/dpos through the colour (:516-528)
+                float grad_xyz[3] = {0.f, 0.f, 0.f};
+                float cw[8];
+                corner_weights(pos, 1.f, cw);
+                for (int c = 0; c < 3; ++c) {
+                    for (int k = 0; k < B; ++k) {
+                        const int e = c * B + k;
+                        const float cg = r.sph[k] * (weight * in01[c] * gout[c]);
+                        float vv[8];
+                        for (int i = 0; i < 8; ++i) {
+                            vv[i] = g.sh_data[(size_t)v.lk[i] * D + e];
+                            if (G.grad_sh_out) atomic_addf(&G.grad_sh_out[(size_t)v.lk[i] * D + e], cw[i] * cg);
+                        }
+                        trilerp_dpos(vv, pos, cg, grad_xyz);
+                    }
+                }
+                const double sg = 1. / (1. + (double)expf(-raw_alpha));  // _D_SIGMOID, util.hpp:29
+                const float curr_grad_raw_alpha = (float)((double)curr_grad_alpha * (sg * (1 - sg)));
+                {
+                    float dw[8];
+                    corner_weights(pos, curr_grad_raw_alpha, dw);
+                    scatter8(G.grad_density_out, G.mask_out, v.lk, dw);
+                }
+                trilerp_dpos(dens, pos, curr_grad_raw_alpha, grad_xyz);
+                const float grad_st = grad_xyz[0] * r.dir[0] + grad_xyz[1] * r.dir[1] + grad_xyz[2] * r.dir[2];
+                float gs[8];
+                int32_t lc[3];
+                for (int k = 0; k < 3; ++k) lc[k] = std::min(v.l[k], g.size[k] - 2);
+                legacy_surface_grad(type, j, v.fs, grad_st, r.origin, r.dir, lc, gs);
+                scatter8(G.grad_surface_out, G.mask_out, v.lk, gs);
+            }
+        }
+        if (expf(log_transmit) < o.stop_thresh) break;
+    }
+}
+
+int legacy_check(const oracle_grid* g, const oracle_rays* r, const oracle_ray_vox* rv,
+                 const oracle_render_options* o) {
+    if (check_common(g, r, o)) return -1;
+    if (!rv || !rv->vox_start_i || !rv->vox_num) return -1;
+    if (rv->n_vox > 0 && !rv->voxel_ls) return -1;
+    if (g->level_set_num < 1) return -1;
+    return 0;
+}
+
 }  // namespace
 
 extern "C" {
 
+void oracle_set_legacy_f64_surface_grad(int on) { g_legacy_f64_surface_grad = on; }
 int oracle_num_threads(void) { return omp_get_max_threads(); }
 void oracle_set_num_threads(int n) { omp_set_num_threads(n); }
 
@@ -1257,7 +1657,22 @@ int64_t oracle_trace_voxel_lists(const oracle_grid* grid, const oracle_rays* ray
 
 int oracle_test_cubic_root_grad(const double* fs, const int32_t* st_ids, float* grad_fs,
                                 float* st, int64_t n, int32_t use_vieta) {
-    if (!use_vieta) return -2;
+    if (!use_vieta) {  // test_cuda.cu:32-106: Vieta roots, gradient through the f/g/h chain
+        for (int64_t i = 0; i < n; ++i) {
+            double roots[3] = {-1, -1, -1};
+            const int type = solve_cubic_vieta(fs[4 * i], fs[4 * i + 1], fs[4 * i + 2], fs[4 * i + 3], 1e-10, roots);
+            for (int j = 0; j < 3; ++j) st[3 * i + j] = (float)roots[j];
+            int root_num = 1;
+            if (type == CUBIC_POLY) root_num = 2;
+            else if (type == CUBIC_THREE_R) root_num = 3;
+            if (type == CUBIC_NO_ROOT || st_ids[i] >= root_num) {
+                for (int k = 0; k < 4; ++k) grad_fs[4 * i + k] = 0;
+                continue;
+            }
+            cubic_root_grad_legacy(type, st_ids[i], fs + 4 * i, grad_fs + 4 * i);
+        }
+        return 0;
+    }
     for (int64_t i = 0; i < n; ++i) {  // test_cuda.cu:32-106
         double roots[3] = {-1, -1, -1};
         const int type = solve_cubic_vieta(fs[4 * i], fs[4 * i + 1], fs[4 * i + 2], fs[4 * i + 3], 1e-10, roots);
@@ -1274,19 +1689,58 @@ int oracle_test_cubic_root_grad(const double* fs, const int32_t* st_ids, float* 
     return 0;
 }
 
-int oracle_volume_render_surface(const oracle_grid*, const oracle_rays*, const oracle_ray_vox*,
-                                 const oracle_render_options*, float*) {
-    return -2;
+int oracle_volume_render_surface(const oracle_grid* grid, const oracle_rays* rays,
+                                 const oracle_ray_vox* ray_vox, const oracle_render_options* opt,
+                                 float* rgb_out) {
+    if (int rc = legacy_check(grid, rays, ray_vox, opt)) return rc;
+#pragma omp parallel for schedule(dynamic, 64)
+    for (int64_t q = 0; q < rays->n_rays; ++q) {
+        Ray r;
+        setup_ray(*grid, *opt, rays->origins + 3 * q, rays->dirs + 3 * q, r);
+        legacy_forward(*grid, *opt, r, ray_vox->voxel_ls, ray_vox->vox_start_i[q], ray_vox->vox_num[q],
+                       rgb_out + 3 * q);
+    }
+    return 0;
 }
-int oracle_volume_render_surface_backward(const oracle_grid*, const oracle_rays*,
-                                          const oracle_ray_vox*, const oracle_render_options*,
-                                          const float*, const float*, const oracle_grads*) {
-    return -2;
+
+int oracle_volume_render_surface_backward(const oracle_grid* grid, const oracle_rays* rays,
+                                          const oracle_ray_vox* ray_vox,
+                                          const oracle_render_options* opt, const float* grad_out,
+                                          const float* color_cache, const oracle_grads* grads) {
+    if (int rc = legacy_check(grid, rays, ray_vox, opt)) return rc;
+    if (!grads || !grad_out || !color_cache) return -1;
+#pragma omp parallel for schedule(dynamic, 64)
+    for (int64_t q = 0; q < rays->n_rays; ++q) {
+        Ray r;
+        setup_ray(*grid, *opt, rays->origins + 3 * q, rays->dirs + 3 * q, r);
+        legacy_backward(*grid, *opt, r, ray_vox->voxel_ls, ray_vox->vox_start_i[q], ray_vox->vox_num[q],
+                        grad_out + 3 * q, color_cache + 3 * q, 0.f, *grads);
+    }
+    return 0;
 }
-int oracle_volume_render_surface_fused(const oracle_grid*, const oracle_rays*,
-                                       const oracle_ray_vox*, const oracle_render_options*,
-                                       const float*, float, float, float*, const oracle_grads*) {
-    return -2;
+
+// surface.cu:1325-1439: forward, then backward with gout = (rgb - gt) * 2 / (3 Q) (:1013-1018)
+int oracle_volume_render_surface_fused(const oracle_grid* grid, const oracle_rays* rays,
+                                       const oracle_ray_vox* ray_vox,
+                                       const oracle_render_options* opt, const float* rgb_gt,
+                                       float beta_loss, float sparsity_loss, float* rgb_out,
+                                       const oracle_grads* grads) {
+    (void)beta_loss;  // only reaches the background model (:636-640), which is not rendered here
+    if (int rc = legacy_check(grid, rays, ray_vox, opt)) return rc;
+    if (!grads || !rgb_gt || !rgb_out) return -1;
+    const float norm = 2.f / (3 * (int)rays->n_rays);
+#pragma omp parallel for schedule(dynamic, 64)
+    for (int64_t q = 0; q < rays->n_rays; ++q) {
+        Ray r;
+        setup_ray(*grid, *opt, rays->origins + 3 * q, rays->dirs + 3 * q, r);
+        legacy_forward(*grid, *opt, r, ray_vox->voxel_ls, ray_vox->vox_start_i[q], ray_vox->vox_num[q],
+                       rgb_out + 3 * q);
+        float gout[3];
+        for (int c = 0; c < 3; ++c) gout[c] = (rgb_out[3 * q + c] - rgb_gt[3 * q + c]) * norm;
+        legacy_backward(*grid, *opt, r, ray_vox->voxel_ls, ray_vox->vox_start_i[q], ray_vox->vox_num[q],
+                        gout, rgb_out + 3 * q, sparsity_loss, *grads);
+    }
+    return 0;
 }
 
 }  // extern "C"

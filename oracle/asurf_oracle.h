@@ -156,6 +156,10 @@ int oracle_volume_render_surface_fused(const oracle_grid* grid, const oracle_ray
                                        float beta_loss, float sparsity_loss, float* rgb_out,
                                        const oracle_grads* grads);
 
+/* diagnostic: evaluate the legacy d f_k / d s_corner expression (render_util.cuh:1705-1775)
+ * in float64 instead of the reference's float32 */
+void oracle_set_legacy_f64_surface_grad(int on);
+
 /* test_cuda.cu:32-122 */
 int oracle_test_cubic_root_grad(const double* fs, const int32_t* st_ids, float* grad_fs,
                                 float* st, int64_t n, int32_t use_vieta);

@@ -284,6 +284,57 @@ def trace_voxel_lists(sc, origins, dirs, opts=None):
     return vox[:total], start, num
 
 
+class RayVox(C.Structure):
+    _fields_ = [("voxel_ls", c_i), ("vox_start_i", c_i), ("vox_num", c_i), ("n_vox", C.c_int64)]
+
+
+def _ray_vox(voxel_ls, start, num):
+    voxel_ls = np.ascontiguousarray(voxel_ls, np.int32).reshape(-1, 3)
+    start = np.ascontiguousarray(start, np.int32)
+    num = np.ascontiguousarray(num, np.int32)
+    rv = RayVox(_i(voxel_ls) if voxel_ls.size else None, _i(start), _i(num), voxel_ls.shape[0])
+    rv._keep = (voxel_ls, start, num)
+    return rv
+
+
+def surface_forward(sc, origins, dirs, ray_vox, opts=None):
+    """Legacy volume_render_surface: ray_vox = (voxel_ls[V,3], vox_start_i[Q], vox_num[Q])."""
+    r = _rays(origins, dirs)
+    rgb = np.zeros((r.n_rays, 3), np.float32)
+    g, o, rv = _grid(sc), make_opts(opts), _ray_vox(*ray_vox)
+    _check(lib().oracle_volume_render_surface(C.byref(g), C.byref(r), C.byref(rv), C.byref(o), _f(rgb)),
+           "surface forward")
+    return rgb
+
+
+def surface_backward(sc, origins, dirs, ray_vox, opts, grad_out, color_cache, grads=None):
+    r = _rays(origins, dirs)
+    grads = grads if grads is not None else zero_grads(sc)
+    grad_out = np.ascontiguousarray(grad_out, np.float32)
+    color_cache = np.ascontiguousarray(color_cache, np.float32)
+    g, o, gg, rv = _grid(sc), make_opts(opts), _grads(grads), _ray_vox(*ray_vox)
+    _check(lib().oracle_volume_render_surface_backward(
+        C.byref(g), C.byref(r), C.byref(rv), C.byref(o), _f(grad_out), _f(color_cache), C.byref(gg)),
+        "surface backward")
+    return grads
+
+
+def surface_fused(sc, origins, dirs, ray_vox, opts, rgb_gt, beta_loss=0.0, sparsity_loss=0.0, grads=None):
+    r = _rays(origins, dirs)
+    grads = grads if grads is not None else zero_grads(sc)
+    rgb_gt = np.ascontiguousarray(rgb_gt, np.float32)
+    rgb = np.zeros((r.n_rays, 3), np.float32)
+    g, o, gg, rv = _grid(sc), make_opts(opts), _grads(grads), _ray_vox(*ray_vox)
+    _check(lib().oracle_volume_render_surface_fused(
+        C.byref(g), C.byref(r), C.byref(rv), C.byref(o), _f(rgb_gt), C.c_float(beta_loss),
+        C.c_float(sparsity_loss), _f(rgb), C.byref(gg)), "surface fused")
+    return rgb, grads
+
+
+def set_legacy_f64_surface_grad(on):
+    lib().oracle_set_legacy_f64_surface_grad(int(bool(on)))
+
+
 def test_cubic_root_grad(fs, st_ids, grad_in, use_vieta=True):
     fs = np.ascontiguousarray(fs, np.float64)
     st_ids = np.ascontiguousarray(st_ids, np.int32)

@@ -9,6 +9,7 @@ GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 STORED_CASES = [
     "r16_sh9_l1", "r16_sh9_l1_noconv", "r16_sh1_sigmoid", "r16_sh4_lv3", "r16_sh16",
     "r16_sh9_l2", "r16_sh9_entropy", "r16_sh9_allfake", "r16_sh9_sparsity", "r32_sh4_l2",
+    "r16_sh9_legacy", "r16_sh4_legacy",
 ]
 ALL_CASES = STORED_CASES + ["cfg1_r64_sh1"]
 
