@@ -17,6 +17,7 @@
 #include "asurf_optim.h"
 #include "asurf_pipeline.h"
 #include "asurf_bwd_pipeline.h"
+#include "asurf_legacy.h"
 
 namespace {
 
@@ -454,6 +455,67 @@ KGrads make_grads(const asurf_grads* g) {
     return k;
 }
 
+// the legacy backend walks caller-supplied voxel lists: no occupancy pyramid
+KGrid make_kgrid_plain(const asurf_grid* g) {
+    KGrid k;
+    k.links = g->links;
+    k.density = g->density_data;
+    k.surface = g->surface_data;
+    k.sh = g->sh_data;
+    k.level_set = g->level_set_data;
+    for (int i = 0; i < 3; ++i) {
+        k.size[i] = g->size[i];
+        k.offset[i] = g->offset[i];
+        k.scaling[i] = g->scaling[i];
+        k.nb[i] = 0;
+    }
+    k.offx = g->size[1] * g->size[2];
+    k.offy = g->size[2];
+    k.level_set_num = g->level_set_num;
+    k.fake_sample_std = g->fake_sample_std;
+    k.trunc_a = g->truncated_vol_render_a;
+    k.fine = nullptr;
+    k.fine_live = nullptr;
+    k.coarse = nullptr;
+    k.nwz = 0;
+    k.coarse_words = 0;
+    return k;
+}
+
+int check_legacy(const asurf_grid* grid, const asurf_rays* rays, const asurf_ray_vox* rv,
+                 const asurf_render_options* opt) {
+    if (int e = check_grid(grid)) return e;
+    if (int e = check_rays(rays)) return e;
+    if (!opt) return fail(ASURF_E_INVALID, "opt is NULL");
+    if (!rv) return fail(ASURF_E_INVALID, "ray_vox is NULL");
+    if (rv->n_vox < 0) return fail(ASURF_E_INVALID, "ray_vox.n_vox < 0");
+    if (rays->n_rays > 0 && (!rv->vox_start_i || !rv->vox_num))
+        return fail(ASURF_E_INVALID, "ray_vox.vox_start_i / vox_num is NULL");
+    if (rv->n_vox > 0 && !rv->voxel_ls) return fail(ASURF_E_INVALID, "ray_vox.voxel_ls is NULL");
+    if (grid->level_set_num < 1 || !grid->level_set_data)
+        return fail(ASURF_E_INVALID, "the surface backend needs level_set_data[0]");
+    return 0;
+}
+
+template <int B>
+int leg_fwd(dim3 gd, hipStream_t s, const KGrid& g, const KOpt& o, const asurf_rays* rays,
+            const asurf_ray_vox* rv, float* rgb_out) {
+    hipLaunchKernelGGL((k_surface_fwd<B>), gd, dim3(kBlock), 0, s, g, o, rays->origins, rays->dirs,
+                       (long long)rays->n_rays, rv->voxel_ls, rv->vox_start_i, rv->vox_num,
+                       (long long)rv->n_vox, rgb_out);
+    return 0;
+}
+
+template <int B>
+int leg_bwd(dim3 gd, hipStream_t s, const KGrid& g, const KOpt& o, const KGrads& G, const asurf_rays* rays,
+            const asurf_ray_vox* rv, const float* grad_in, const float* color_cache, int grad_in_is_rgb,
+            float sparsity_loss) {
+    hipLaunchKernelGGL((k_surface_bwd<B>), gd, dim3(kBlock), 0, s, g, o, G, rays->origins, rays->dirs,
+                       (long long)rays->n_rays, rv->voxel_ls, rv->vox_start_i, rv->vox_num,
+                       (long long)rv->n_vox, grad_in, color_cache, grad_in_is_rgb, sparsity_loss);
+    return 0;
+}
+
 }  // namespace
 
 extern "C" {
@@ -623,29 +685,118 @@ int asurf_profile_read(float* ms, int n) {
 
 int asurf_test_cubic_root_grad(const double* fs, const int32_t* st_ids, float* grad_fs, float* st,
                                int64_t n, int32_t use_vieta, void* stream) {
-    if (!use_vieta)
-        return fail(ASURF_E_UNSUPPORTED, "only the Vieta solver (use_vieta=True) is on the live path");
     if (n < 0 || (n > 0 && (!fs || !st_ids || !grad_fs || !st)))
         return fail(ASURF_E_INVALID, "test_cubic_root_grad: NULL tensor");
     if (n == 0) return 0;
+    if (!use_vieta) {
+        hipLaunchKernelGGL(k_test_cubic_root_grad_legacy, dim3((unsigned)((n + 127) / 128)), dim3(128), 0,
+                           static_cast<hipStream_t>(stream), fs, st_ids, grad_fs, st, (long long)n);
+        return launch_error("k_test_cubic_root_grad_legacy");
+    }
     hipLaunchKernelGGL(k_test_cubic_root_grad, dim3((unsigned)((n + 127) / 128)), dim3(128), 0,
                        static_cast<hipStream_t>(stream), fs, st_ids, grad_fs, st, (long long)n);
     return launch_error("k_test_cubic_root_grad");
 }
 
-int asurf_volume_render_surface(const asurf_grid*, const asurf_rays*, const asurf_ray_vox*,
-                                const asurf_render_options*, float*, void*) {
-    return fail(ASURF_E_UNSUPPORTED, "legacy `surface` backend: not built yet (SURVEY.md 8a-14)");
+int asurf_volume_render_surface(const asurf_grid* grid, const asurf_rays* rays,
+                                const asurf_ray_vox* ray_vox, const asurf_render_options* opt,
+                                float* rgb_out, void* stream) {
+    if (int e = check_legacy(grid, rays, ray_vox, opt)) return e;
+    if (rays->n_rays == 0) return 0;
+    if (!rgb_out) return fail(ASURF_E_INVALID, "rgb_out is NULL");
+    const KGrid g = make_kgrid_plain(grid);
+    const KOpt o = make_kopt(opt);
+    const dim3 grid_dim((unsigned)((rays->n_rays + kBlock - 1) / kBlock));
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    int rc = 0;
+ASURF_DISPATCH_B(grid->basis_dim, (leg_fwd<B_>(grid_dim, s, g, o, rays, ray_vox, rgb_out)));
+    (void)rc;
+    return launch_error("k_surface_fwd");
 }
-int asurf_volume_render_surface_backward(const asurf_grid*, const asurf_rays*, const asurf_ray_vox*,
-                                         const asurf_render_options*, const float*, const float*,
-                                         const asurf_grads*, void*) {
-    return fail(ASURF_E_UNSUPPORTED, "legacy `surface` backend: not built yet (SURVEY.md 8a-14)");
+
+namespace {
+int launch_surface_backward(const asurf_grid* grid, const asurf_rays* rays, const asurf_ray_vox* ray_vox,
+                            const asurf_render_options* opt, const float* grad_in,
+                            const float* color_cache, int grad_in_is_rgb, float sparsity_loss,
+                            const asurf_grads* grads, hipStream_t s) {
+    const KGrid g = make_kgrid_plain(grid);
+    const KOpt o = make_kopt(opt);
+    const KGrads G = make_grads(grads);
+    const dim3 grid_dim((unsigned)((rays->n_rays + kBlock - 1) / kBlock));
+    int rc = 0;
+ASURF_DISPATCH_B(grid->basis_dim, (leg_bwd<B_>(grid_dim, s, g, o, G, rays, ray_vox, grad_in, color_cache,
+                                                grad_in_is_rgb, sparsity_loss)));
+    (void)rc;
+    return launch_error("k_surface_bwd");
 }
-int asurf_volume_render_surface_fused(const asurf_grid*, const asurf_rays*, const asurf_ray_vox*,
-                                      const asurf_render_options*, const float*, float, float, float*,
-                                      const asurf_grads*, void*) {
-    return fail(ASURF_E_UNSUPPORTED, "legacy `surface` backend: not built yet (SURVEY.md 8a-14)");
+}  // namespace
+
+int asurf_volume_render_surface_backward(const asurf_grid* grid, const asurf_rays* rays,
+                                         const asurf_ray_vox* ray_vox,
+                                         const asurf_render_options* opt, const float* grad_out,
+                                         const float* color_cache, const asurf_grads* grads,
+                                         void* stream) {
+    if (int e = check_legacy(grid, rays, ray_vox, opt)) return e;
+    if (!grads) return fail(ASURF_E_INVALID, "grads is NULL");
+    if (rays->n_rays == 0) return 0;
+    if (!grad_out || !color_cache) return fail(ASURF_E_INVALID, "grad_out / color_cache is NULL");
+    return launch_surface_backward(grid, rays, ray_vox, opt, grad_out, color_cache, 0, 0.f, grads,
+                                   static_cast<hipStream_t>(stream));
+}
+
+// render_lerp_kernel_surface.cu:1325-1439.  beta_loss only reaches the background model
+// (:636-640), which this build does not render (check_grid rejects MSI layers).
+int asurf_volume_render_surface_fused(const asurf_grid* grid, const asurf_rays* rays,
+                                      const asurf_ray_vox* ray_vox,
+                                      const asurf_render_options* opt, const float* rgb_gt,
+                                      float beta_loss, float sparsity_loss, float* rgb_out,
+                                      const asurf_grads* grads, void* stream) {
+    (void)beta_loss;
+    if (int e = check_legacy(grid, rays, ray_vox, opt)) return e;
+    if (!grads) return fail(ASURF_E_INVALID, "grads is NULL");
+    if (rays->n_rays == 0) return 0;
+    if (!rgb_gt || !rgb_out) return fail(ASURF_E_INVALID, "rgb_gt / rgb_out is NULL");
+    if (int e = asurf_volume_render_surface(grid, rays, ray_vox, opt, rgb_out, stream)) return e;
+    return launch_surface_backward(grid, rays, ray_vox, opt, rgb_gt, rgb_out, 1, sparsity_loss, grads,
+                                   static_cast<hipStream_t>(stream));
+}
+
+// Voxel lists of the legacy backend from the surf_trav DDA (two passes around a host-side
+// exclusive scan of vox_num).
+int asurf_ray_voxel_count(const asurf_grid* grid, const asurf_rays* rays,
+                          const asurf_render_options* opt, int32_t skip_empty, int32_t* vox_num,
+                          void* stream) {
+    if (int e = check_grid(grid)) return e;
+    if (int e = check_rays(rays)) return e;
+    if (!opt) return fail(ASURF_E_INVALID, "opt is NULL");
+    if (rays->n_rays == 0) return 0;
+    if (!vox_num) return fail(ASURF_E_INVALID, "vox_num is NULL");
+    const KGrid g = make_kgrid_plain(grid);
+    const KOpt o = make_kopt(opt);
+    hipLaunchKernelGGL((k_voxel_lists<false>), dim3((unsigned)((rays->n_rays + kBlock - 1) / kBlock)),
+                       dim3(kBlock), 0, static_cast<hipStream_t>(stream), g, o, rays->origins, rays->dirs,
+                       (long long)rays->n_rays, (int)skip_empty, vox_num, (const int*)nullptr,
+                       (int*)nullptr, 0ll);
+    return launch_error("k_voxel_lists<count>");
+}
+
+int asurf_ray_voxel_fill(const asurf_grid* grid, const asurf_rays* rays,
+                         const asurf_render_options* opt, int32_t skip_empty,
+                         const asurf_ray_vox* ray_vox, int32_t* voxel_ls_out, void* stream) {
+    if (int e = check_grid(grid)) return e;
+    if (int e = check_rays(rays)) return e;
+    if (!opt) return fail(ASURF_E_INVALID, "opt is NULL");
+    if (!ray_vox || ray_vox->n_vox < 0) return fail(ASURF_E_INVALID, "ray_vox is NULL / n_vox < 0");
+    if (rays->n_rays == 0 || ray_vox->n_vox == 0) return 0;
+    if (!ray_vox->vox_start_i || !ray_vox->vox_num || !voxel_ls_out)
+        return fail(ASURF_E_INVALID, "vox_start_i / vox_num / voxel_ls_out is NULL");
+    const KGrid g = make_kgrid_plain(grid);
+    const KOpt o = make_kopt(opt);
+    hipLaunchKernelGGL((k_voxel_lists<true>), dim3((unsigned)((rays->n_rays + kBlock - 1) / kBlock)),
+                       dim3(kBlock), 0, static_cast<hipStream_t>(stream), g, o, rays->origins, rays->dirs,
+                       (long long)rays->n_rays, (int)skip_empty, const_cast<int32_t*>(ray_vox->vox_num),
+                       ray_vox->vox_start_i, voxel_ls_out, (long long)ray_vox->n_vox);
+    return launch_error("k_voxel_lists<fill>");
 }
 
 }  // extern "C"

@@ -19,6 +19,7 @@ __all__ = [
     "SparseGridSpec", "CameraSpec", "RaysSpec", "RayVoxIntersecSpec", "RenderOptions",
     "GridOutputGrads", "volume_render_surf_trav", "volume_render_surf_trav_backward",
     "volume_render_surf_trav_fused", "volume_render_surface", "volume_render_surface_backward",
+    "ray_voxel_lists",
     "volume_render_surface_fused", "test_cubic_root_grad", "sample_grid", "rmsprop_step", "sgd_step",
 ]
 
@@ -387,6 +388,31 @@ def volume_render_surface_fused(grid, rays, ray_vox, opt, rgb_gt, beta_loss, spa
         _L.check(_L.lib().asurf_volume_render_surface_fused(
             C.byref(g), C.byref(r), C.byref(v), C.byref(o), _ptr(rgb_gt), float(beta_loss),
             float(sparsity_loss), _ptr(rgb_out), C.byref(gg), _stream(dev)))
+
+
+def ray_voxel_lists(grid, rays, opt, skip_empty=True):
+    """(voxel_ls i32[V,3], vox_start_i i32[Q], vox_num i32[Q]) for the legacy backend, from the
+    surf_trav DDA on the GPU.  Not a reference binding: it stands in for
+    SparseGrid.find_ray_voxels_intersection (svox2.py:1515-1594), whose kaolin ray trace cannot
+    be constructed in the reference."""
+    g, r, o = _pack_grid(grid), _pack_rays(rays), _pack_opt(opt)
+    dev = grid.sh_data.device
+    q = r.n_rays
+    with torch.cuda.device(dev):
+        vox_num = torch.zeros(q, dtype=torch.int32, device=dev)
+        _L.check(_L.lib().asurf_ray_voxel_count(C.byref(g), C.byref(r), C.byref(o), int(bool(skip_empty)),
+                                                _ptr(vox_num), _stream(dev)))
+        ends = torch.cumsum(vox_num, dim=0, dtype=torch.int64)
+        total = int(ends[-1].item()) if q > 0 else 0
+        if total >= 2 ** 31:
+            raise RuntimeError("ray_voxel_lists: more than 2^31 voxels, split the ray batch")
+        vox_start = (ends - vox_num).to(torch.int32)
+        voxel_ls = torch.empty((total, 3), dtype=torch.int32, device=dev)
+        v = _L.AsurfRayVox()
+        v.voxel_ls, v.vox_start_i, v.vox_num, v.n_vox = _ptr(voxel_ls), _ptr(vox_start), _ptr(vox_num), total
+        _L.check(_L.lib().asurf_ray_voxel_fill(C.byref(g), C.byref(r), C.byref(o), int(bool(skip_empty)),
+                                               C.byref(v), _ptr(voxel_ls), _stream(dev)))
+    return voxel_ls, vox_start, vox_num
 
 
 def test_cubic_root_grad(T_fs, T_st_ids, T_grad_fs, T_st, use_vieta):

@@ -203,6 +203,34 @@ class _SurfTravRenderFunction(autograd.Function):
                 holder.grad_fake_sample_std_out if need[5] else None, None, None, None, None)
 
 
+class _SurfaceRenderFunction(autograd.Function):
+    """Autograd bridge of the legacy voxel-list backend (:432-511)."""
+
+    @staticmethod
+    def forward(ctx, data_density, data_surface, data_sh, data_basis, data_background, grid, rays,
+                ray_vox, opt, backend):
+        color = getattr(_C, f"volume_render_{backend}")(grid, rays, ray_vox, opt)
+        ctx.save_for_backward(color)
+        ctx.grid, ctx.rays, ctx.ray_vox, ctx.opt, ctx.backend = grid, rays, ray_vox, opt, backend
+        return color
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        (color_cache,) = ctx.saved_tensors
+        g = ctx.grid
+        holder = _C.GridOutputGrads()
+        holder.grad_density_out = torch.zeros_like(g.density_data.data)
+        holder.grad_surface_out = torch.zeros_like(g.surface_data.data)
+        holder.grad_sh_out = torch.zeros_like(g.sh_data.data)
+        getattr(_C, f"volume_render_{ctx.backend}_backward")(
+            g, ctx.rays, ctx.ray_vox, ctx.opt, grad_out.contiguous(), color_cache, holder)
+        ctx.grid = ctx.rays = ctx.ray_vox = ctx.opt = None
+        need = ctx.needs_input_grad
+        return (holder.grad_density_out if need[0] else None,
+                holder.grad_surface_out if need[1] else None,
+                holder.grad_sh_out if need[2] else None, None, None, None, None, None, None, None)
+
+
 class SparseGrid(nn.Module):
     """Sparse voxel grid with a per-vertex surface scalar (:560-990).  Only what the surf_trav
     hot path needs is built: SH basis, SDF/UDF surface types, no MSI background."""
@@ -364,6 +392,22 @@ class SparseGrid(nn.Module):
         if self.surface_data is None:
             raise RuntimeError("the surf_trav backend needs a surface grid (surface_type SDF/UDF)")
 
+    def ray_voxel_lists(self, rays: Rays, skip_empty: bool = True) -> RayVoxIntersecs:
+        """Per-ray voxel lists of the legacy backend (what :3415-3428 builds from
+        find_ray_voxels_intersection), from the surf_trav DDA on the GPU."""
+        voxel_ls, start, num = _C.ray_voxel_lists(self._to_cpp(), rays._to_cpp(), self.opt._to_cpp(),
+                                                  skip_empty=skip_empty)
+        return RayVoxIntersecs(voxel_ls, start, num)
+
+    def find_ray_voxels_intersection(self, t, origins, dirs):
+        """(l int64[VV,3], ray_ids int64[VV]) for GRID-space rays (:1515-1594; `t` is unused, as
+        at the reference's call sites :3421 / :3572 which pass None)."""
+        spec = self._to_cpp(grid_coords=True)
+        r = Rays(origins.float().contiguous(), dirs.float().contiguous())
+        voxel_ls, start, num = _C.ray_voxel_lists(spec, r._to_cpp(), self.opt._to_cpp(), skip_empty=False)
+        ray_ids = torch.repeat_interleave(torch.arange(num.shape[0], device=num.device), num.long())
+        return voxel_ls.long(), ray_ids
+
     def volume_render(self, rays: Rays, use_kernel: bool = True, randomize: bool = False,
                       return_raylen: bool = False, **kwargs):
         """Differentiable render of a ray batch; returns {'rgb': [Q,3]} (:3390-3474)."""
@@ -372,8 +416,12 @@ class SparseGrid(nn.Module):
                                       "the HIP path is the only implementation (no CPU fallback)")
         self._check_backend()
         assert rays.is_cuda and self.links.is_cuda
-        if self.opt.backend == "surface":
-            _next_row("8a-14", "the legacy `surface` backend's Python caller (needs kaolin in the reference too)")
+        if self.opt.backend == "surface":  # :3410-3437
+            ray_vox = self.ray_voxel_lists(rays)
+            rgb = _SurfaceRenderFunction.apply(
+                self.density_data, self.surface_data, self.sh_data, None, None, self._to_cpp(),
+                rays._to_cpp(), ray_vox._to_cpp(), self.opt._to_cpp(randomize=randomize), self.opt.backend)
+            return {"rgb": rgb}
         rgb = _SurfTravRenderFunction.apply(
             self.density_data, self.surface_data, self.sh_data, None, None, self.fake_sample_std,
             self._to_cpp(), rays._to_cpp(), self.opt._to_cpp(randomize=randomize), self.opt.backend)
@@ -398,8 +446,6 @@ class SparseGrid(nn.Module):
         if no_surface:
             _next_row("N4", "no_surface warm-up (cuvol renderer)")
         self._check_backend()
-        if self.opt.backend == "surface":
-            _next_row("8a-14", "the legacy `surface` backend's Python caller")
         grad = self._get_data_grads()
         rgb_out = torch.zeros_like(rgb_gt)
         self.sparse_grad_indexer = torch.zeros((self.density_data.size(0),), dtype=torch.bool,
@@ -409,6 +455,13 @@ class SparseGrid(nn.Module):
         holder.grad_surface_out = grad["surface_data"]
         holder.grad_sh_out = grad["sh_data"]
         holder.mask_out = self.sparse_grad_indexer
+        if self.opt.backend == "surface":  # :3560-3597
+            ray_vox = self.ray_voxel_lists(rays)
+            _C.volume_render_surface_fused(
+                self._to_cpp(), rays._to_cpp(), ray_vox._to_cpp(), self.opt._to_cpp(randomize=randomize),
+                rgb_gt, beta_loss, sparsity_loss, rgb_out, holder)
+            self.sparse_sh_grad_indexer = self.sparse_grad_indexer.clone()
+            return {"rgb": rgb_out}
         if "fake_sample_std" in grad:
             holder.grad_fake_sample_std_out = grad["fake_sample_std"]
         _C.volume_render_surf_trav_fused(

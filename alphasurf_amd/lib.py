@@ -86,7 +86,7 @@ EXPORTS = [
     "asurf_volume_render_surf_trav_fused", "asurf_volume_render_surface",
     "asurf_volume_render_surface_backward", "asurf_volume_render_surface_fused",
     "asurf_test_cubic_root_grad", "asurf_profile_enable", "asurf_profile_read",
-    "asurf_rmsprop_step", "asurf_sgd_step",
+    "asurf_rmsprop_step", "asurf_sgd_step", "asurf_ray_voxel_count", "asurf_ray_voxel_fill",
 ]
 
 _lib = None
@@ -122,6 +122,8 @@ def lib():
         fl = C.c_float
         L.asurf_rmsprop_step.argtypes = [vp, vp, vp, C.c_int64, C.c_int32, vp, vp, C.c_int64, fl, fl, fl, fl, fl, vp]
         L.asurf_sgd_step.argtypes = [vp, vp, C.c_int64, C.c_int32, vp, vp, C.c_int64, fl, fl, vp]
+        L.asurf_ray_voxel_count.argtypes = [vp, vp, vp, C.c_int32, vp, vp]
+        L.asurf_ray_voxel_fill.argtypes = [vp, vp, vp, C.c_int32, vp, vp, vp]
         if L.asurf_abi_version() != 1:
             raise RuntimeError("libasurf_hip.so ABI version mismatch")
         _lib = L

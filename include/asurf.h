@@ -216,6 +216,20 @@ int asurf_volume_render_surface_fused(const asurf_grid* grid, const asurf_rays* 
                                       float beta_loss, float sparsity_loss, float* rgb_out,
                                       const asurf_grads* grads, void* stream);
 
+/* Per-ray voxel lists for the legacy backend, produced by the surf_trav DDA
+ * (surf_trav.cu:75-197).  Stands in for SparseGrid.find_ray_voxels_intersection
+ * (svox2.py:1515-1594, callers :3421, :3572), whose kaolin SPC ray trace cannot be built in the
+ * reference.  Two passes: asurf_ray_voxel_count fills vox_num[n_rays]; the caller takes the
+ * exclusive scan (vox_start_i) and the total (n_vox), then asurf_ray_voxel_fill writes
+ * voxel_ls_out[n_vox,3].  skip_empty != 0 leaves out voxels with a missing link (the renderer
+ * skips them anyway); both passes must use the same value. */
+int asurf_ray_voxel_count(const asurf_grid* grid, const asurf_rays* rays,
+                          const asurf_render_options* opt, int32_t skip_empty, int32_t* vox_num,
+                          void* stream);
+int asurf_ray_voxel_fill(const asurf_grid* grid, const asurf_rays* rays,
+                         const asurf_render_options* opt, int32_t skip_empty,
+                         const asurf_ray_vox* ray_vox, int32_t* voxel_ls_out, void* stream);
+
 /* Tensor test_cubic_root_grad(fs f64[N,4], st_ids i32[N], grad_fs f32[N,4] in/out,
  *                             st f32[N,3] out, bool use_vieta)
  *   svox2.cpp:12, test_cuda.cu:32-122.  All pointers are device pointers. */

@@ -115,3 +115,47 @@ def render_fused(sc, origins, dirs, opts, rgb_gt, fused=None, global_n_rays=0, c
     torch.cuda.synchronize()
     out = (rgb.cpu().numpy(), grads_np(gr))
     return out + (cnt.cpu().numpy(),) if counters else out
+
+
+# ---- legacy `surface` backend ----
+def ray_vox_spec(ray_vox):
+    d = dev()
+    rv = _C.RayVoxIntersecSpec()
+    rv.voxel_ls = torch.from_numpy(np.ascontiguousarray(ray_vox[0], np.int32).reshape(-1, 3)).to(d)
+    rv.vox_start_i = torch.from_numpy(np.ascontiguousarray(ray_vox[1], np.int32)).to(d)
+    rv.vox_num = torch.from_numpy(np.ascontiguousarray(ray_vox[2], np.int32)).to(d)
+    return rv
+
+
+def voxel_lists(sc, origins, dirs, opts=None, skip_empty=False):
+    g, r, o = grid_spec(sc), rays_spec(origins, dirs), opt_spec(opts)
+    vox, start, num = _C.ray_voxel_lists(g, r, o, skip_empty=skip_empty)
+    torch.cuda.synchronize()
+    return vox.cpu().numpy(), start.cpu().numpy(), num.cpu().numpy()
+
+
+def surface_forward(sc, origins, dirs, ray_vox, opts=None):
+    g, r, o, rv = grid_spec(sc), rays_spec(origins, dirs), opt_spec(opts), ray_vox_spec(ray_vox)
+    rgb = _C.volume_render_surface(g, r, rv, o)
+    torch.cuda.synchronize()
+    return rgb.cpu().numpy()
+
+
+def surface_backward(sc, origins, dirs, ray_vox, opts, grad_out, color_cache):
+    g, r, o, rv = grid_spec(sc), rays_spec(origins, dirs), opt_spec(opts), ray_vox_spec(ray_vox)
+    gr = zero_grads(g, with_std=False)
+    _C.volume_render_surface_backward(
+        g, r, rv, o, torch.from_numpy(np.ascontiguousarray(grad_out, np.float32)).to(dev()),
+        torch.from_numpy(np.ascontiguousarray(color_cache, np.float32)).to(dev()), gr)
+    torch.cuda.synchronize()
+    return grads_np(gr)
+
+
+def surface_fused(sc, origins, dirs, ray_vox, opts, rgb_gt, beta_loss=0.0, sparsity_loss=0.0):
+    g, r, o, rv = grid_spec(sc), rays_spec(origins, dirs), opt_spec(opts), ray_vox_spec(ray_vox)
+    gr = zero_grads(g, with_std=False)
+    gt = torch.from_numpy(np.ascontiguousarray(rgb_gt, np.float32)).to(dev())
+    rgb = torch.zeros_like(gt)
+    _C.volume_render_surface_fused(g, r, rv, o, gt, beta_loss, sparsity_loss, rgb, gr)
+    torch.cuda.synchronize()
+    return rgb.cpu().numpy(), grads_np(gr)
