@@ -222,17 +222,30 @@ struct Launch {
     dim3 ray_grid;
 };
 
-// --- optional per-kernel timing (asurf_profile_enable) ---
+// --- optional per-kernel timing (asurf_profile_enable): one hipEvent after every launch ---
+constexpr int kMaxSpans = 24;
 bool g_prof_on = false;
-hipEvent_t g_ev[4] = {nullptr, nullptr, nullptr, nullptr};
-int g_ev_last = -1;  // index of the last event recorded by the last call
-bool g_fwd_in_last_call = false;
+hipEvent_t g_ev[kMaxSpans + 1] = {};
+const char* g_span_name[kMaxSpans] = {};
+int g_span_group[kMaxSpans] = {};  // 0 occupancy pass, 1 forward, 2 backward
+int g_spans = -1;                  // spans recorded by the last call (-1: none)
 
-void prof_mark(int i, hipStream_t s) {
+void prof_begin(hipStream_t s) {
+    g_spans = -1;
     if (!g_prof_on) return;
-    if (!g_ev[i]) hipEventCreate(&g_ev[i]);
-    hipEventRecord(g_ev[i], s);
-    g_ev_last = i;
+    if (!g_ev[0] && hipEventCreate(&g_ev[0]) != hipSuccess) return;
+    if (hipEventRecord(g_ev[0], s) == hipSuccess) g_spans = 0;
+}
+
+// closes the span of the kernel(s) launched since the previous mark
+void prof_after(const char* name, int group, hipStream_t s) {
+    if (!g_prof_on || g_spans < 0 || g_spans >= kMaxSpans) return;
+    const int i = g_spans + 1;
+    if (!g_ev[i] && hipEventCreate(&g_ev[i]) != hipSuccess) return;
+    if (hipEventRecord(g_ev[i], s) != hipSuccess) return;
+    g_span_name[g_spans] = name;
+    g_span_group[g_spans] = group;
+    g_spans = i;
 }
 
 int launch_error(const char* what) {
@@ -265,16 +278,14 @@ int prepare(const asurf_grid* grid, const asurf_rays* rays, const asurf_render_o
     L.coarse_in_lds = (L.ML.coarse_words * 4 <= kMaxCoarseLds) ? 1 : 0;
     L.dyn_lds = L.coarse_in_lds ? L.ML.coarse_words * 4 : 0;
     L.ray_grid = dim3((unsigned)((rays->n_rays + kBlock - 1) / kBlock));
-    g_ev_last = -1;
-    g_fwd_in_last_call = false;
-    prof_mark(0, L.stream);
+    prof_begin(L.stream);
     hipLaunchKernelGGL(k_build_masks, dim3((unsigned)L.ML.coarse_words), dim3(512), 0, L.stream, L.g,
                        opt->sigma_thresh, need_surf ? 1 : 0,
                        reinterpret_cast<unsigned long long*>(L.ws + L.ML.off_fine_work),
                        reinterpret_cast<unsigned long long*>(L.ws + L.ML.off_fine_live),
                        reinterpret_cast<unsigned int*>(L.ws + L.ML.off_coarse_work),
                        reinterpret_cast<unsigned int*>(L.ws + L.ML.off_coarse_live));
-    prof_mark(1, L.stream);
+    prof_after("k_build_masks", 0, L.stream);
     return launch_error("k_build_masks");
 }
 
@@ -330,16 +341,20 @@ int run_forward(const Launch& L, const asurf_rays* rays, float* rgb_out, int M, 
         else
             hipLaunchKernelGGL((k_walk<false>), L.ray_grid, dim3(kBlock), 0, L.stream, L.g, L.o,
                                rays->origins, rays->dirs, Q, P, record ? 1 : 0);
+        prof_after("k_walk", 1, L.stream);
         hipLaunchKernelGGL((k_geom<false>), dim3(L.ray_grid.x, kPipeC1), dim3(kBlock), 0, L.stream, L.g,
                            L.o, rays->origins, rays->dirs, Q, P);
+        prof_after("k_geom", 1, L.stream);
         hipLaunchKernelGGL((k_geom<true>), dim3((unsigned)((L.ML.sp_cap + kBlock - 1) / kBlock)),
                            dim3(kBlock), 0, L.stream, L.g, L.o, rays->origins, rays->dirs, Q, P);
+        prof_after("k_geom_spill", 1, L.stream);
         if (cache)
             hipLaunchKernelGGL((k_comp<B, true>), L.ray_grid, dim3(kBlock), 0, L.stream, L.g, L.o,
                                rays->dirs, Q, P, rgb_out, M, ca, cw, ct, cn, rv, rm, rn, kRecDepth, rf);
         else
             hipLaunchKernelGGL((k_comp<B, false>), L.ray_grid, dim3(kBlock), 0, L.stream, L.g, L.o,
                                rays->dirs, Q, P, rgb_out, M, ca, cw, ct, cn, rv, rm, rn, kRecDepth, rf);
+        prof_after("k_comp", 1, L.stream);
         if (int e = launch_error("forward pipeline")) return e;
         ray_list = P.flagged;
         n_list = P.counters;
@@ -362,8 +377,7 @@ int run_forward(const Launch& L, const asurf_rays* rays, float* rgb_out, int M, 
     }
 #undef ASURF_FWD2
 #undef ASURF_FWD
-    prof_mark(2, L.stream);
-    g_fwd_in_last_call = true;
+    prof_after(pipeline ? "k_forward_fallback" : "k_forward", 1, L.stream);
     return launch_error("k_forward");
 }
 
@@ -418,13 +432,17 @@ int run_backward(const Launch& L, const asurf_rays* rays, const KLoss& loss, con
         const long long Q = rays->n_rays;
         hipLaunchKernelGGL(k_bwd_seq, L.ray_grid, dim3(kBlock), 0, L.stream, L.o, loss, L.g.trunc_a, Q,
                            grad_in, color_cache, M, ca, cw, ct, cn, S);
+        prof_after("k_bwd_seq", 2, L.stream);
         const dim3 grid2(L.ray_grid.x, kRecDepth);
         hipLaunchKernelGGL((k_bwd_sh<B>), grid2, dim3(kBlock), 0, L.stream, L.g, G,
                            L.o.no_surf_grad_from_sh ? 0 : 1, rays->dirs, Q, S);
+        prof_after("k_bwd_sh", 2, L.stream);
         hipLaunchKernelGGL(k_bwd_geo, grid2, dim3(kBlock), 0, L.stream, L.g, L.o, loss, G, rays->origins,
                            rays->dirs, Q, S);
+        prof_after("k_bwd_geo", 2, L.stream);
     } else if (mode == 1) {
         ASURF_BWD(true, false, true);
+        prof_after("k_backward_replay", 2, L.stream);
     } else if (fused) {
         if (L.coarse_in_lds) ASURF_BWD(true, true, false);
         else ASURF_BWD(true, false, false);
@@ -433,7 +451,7 @@ int run_backward(const Launch& L, const asurf_rays* rays, const KLoss& loss, con
         else ASURF_BWD(false, false, false);
     }
 #undef ASURF_BWD
-    if (mode != 1 && mode != 3) prof_mark(3, L.stream);
+    if (mode != 1 && mode != 3) prof_after(mode == 2 ? "k_backward_fallback" : "k_backward", 2, L.stream);
     return launch_error("k_backward");
 }
 
@@ -666,21 +684,34 @@ int asurf_profile_enable(int on) {
 int asurf_profile_read(float* ms, int n) {
     if (!ms || n < 3) return fail(ASURF_E_INVALID, "asurf_profile_read needs room for 3 floats");
     ms[0] = ms[1] = ms[2] = 0.f;
-    if (!g_prof_on || g_ev_last < 1) return fail(ASURF_E_INVALID, "profiling is off or no call was made");
-    hipEventSynchronize(g_ev[g_ev_last]);
-    hipEventElapsedTime(&ms[0], g_ev[0], g_ev[1]);
-    // a backward-only call records events 0,1,3; a forward-only call 0,1,2
-    if (g_ev_last == 2) {
-        hipEventElapsedTime(&ms[1], g_ev[1], g_ev[2]);
-    } else if (g_ev_last == 3) {
-        if (g_fwd_in_last_call) {
-            hipEventElapsedTime(&ms[1], g_ev[1], g_ev[2]);
-            hipEventElapsedTime(&ms[2], g_ev[2], g_ev[3]);
-        } else {
-            hipEventElapsedTime(&ms[2], g_ev[1], g_ev[3]);
-        }
+    if (!g_prof_on || g_spans < 1) return fail(ASURF_E_INVALID, "profiling is off or no call was made");
+    if (hipEventSynchronize(g_ev[g_spans]) != hipSuccess) return fail(ASURF_E_LAUNCH, "hipEventSynchronize");
+    for (int i = 0; i < g_spans; ++i) {
+        float t = 0.f;
+        if (hipEventElapsedTime(&t, g_ev[i], g_ev[i + 1]) != hipSuccess) return fail(ASURF_E_LAUNCH, "hipEventElapsedTime");
+        ms[g_span_group[i]] += t;
     }
     return 0;
+}
+
+int asurf_profile_read_spans(char* names, size_t names_cap, float* ms, int max_spans) {
+    if (!names || !ms || max_spans < 1 || names_cap < 2)
+        return fail(ASURF_E_INVALID, "asurf_profile_read_spans: NULL buffer"), -1;
+    if (!g_prof_on || g_spans < 1) return fail(ASURF_E_INVALID, "profiling is off or no call was made"), -1;
+    if (hipEventSynchronize(g_ev[g_spans]) != hipSuccess) return fail(ASURF_E_LAUNCH, "hipEventSynchronize"), -1;
+    size_t used = 0;
+    int n = 0;
+    names[0] = 0;
+    for (int i = 0; i < g_spans && n < max_spans; ++i, ++n) {
+        float t = 0.f;
+        if (hipEventElapsedTime(&t, g_ev[i], g_ev[i + 1]) != hipSuccess)
+            return fail(ASURF_E_LAUNCH, "hipEventElapsedTime"), -1;
+        ms[n] = t;
+        const int w = snprintf(names + used, names_cap - used, "%s%s", n ? "," : "", g_span_name[i]);
+        if (w < 0 || (size_t)w >= names_cap - used) return fail(ASURF_E_INVALID, "names buffer too small"), -1;
+        used += (size_t)w;
+    }
+    return n;
 }
 
 int asurf_test_cubic_root_grad(const double* fs, const int32_t* st_ids, float* grad_fs, float* st,

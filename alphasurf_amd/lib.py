@@ -86,6 +86,7 @@ EXPORTS = [
     "asurf_volume_render_surf_trav_fused", "asurf_volume_render_surface",
     "asurf_volume_render_surface_backward", "asurf_volume_render_surface_fused",
     "asurf_test_cubic_root_grad", "asurf_profile_enable", "asurf_profile_read",
+    "asurf_profile_read_spans",
     "asurf_rmsprop_step", "asurf_sgd_step", "asurf_ray_voxel_count", "asurf_ray_voxel_fill",
 ]
 
@@ -146,6 +147,18 @@ def profile_read():
     ms = (C.c_float * 3)()
     check(lib().asurf_profile_read(ms, 3))
     return float(ms[0]), float(ms[1]), float(ms[2])
+
+
+def profile_read_spans():
+    """[(kernel name, ms)] of the last call, in launch order."""
+    names = C.create_string_buffer(1024)
+    ms = (C.c_float * 32)()
+    L = lib()
+    L.asurf_profile_read_spans.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(C.c_float), C.c_int]
+    n = L.asurf_profile_read_spans(names, 1024, ms, 32)
+    if n < 0:
+        check(1)
+    return list(zip(names.value.decode().split(","), [float(ms[i]) for i in range(n)]))
 
 
 def workspace_bytes(size, n_rays, l_dist_max_sample):

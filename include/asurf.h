@@ -251,12 +251,16 @@ int asurf_sgd_step(float* data, float* grad, int64_t n_rows, int32_t n_cols, con
                    const int64_t* indices, int64_t n_indices, float lr, float lr_last, void* stream);
 
 /* Measurement hooks (no reference counterpart; used by bench.py).  When enabled, the
- * surf_trav launchers bracket each kernel of a call with hipEvents on the call's stream.
+ * surf_trav launchers record a hipEvent on the call's stream after every kernel launch.
  * asurf_profile_read() waits for the last call and returns, in milliseconds,
- * ms[0] = occupancy-pyramid pass, ms[1] = forward kernel, ms[2] = backward kernel
- * (0 for a kernel the call did not launch).  Not graph-capturable while enabled. */
+ * ms[0] = occupancy-pyramid pass, ms[1] = sum of the forward kernels, ms[2] = sum of the
+ * backward kernels (0 for a group the call did not launch).
+ * asurf_profile_read_spans() returns the per-kernel times of the last call: the number of
+ * spans (or -1), their names as one comma-separated string and ms[i] for each.
+ * Not graph-capturable while enabled. */
 int asurf_profile_enable(int on);
 int asurf_profile_read(float* ms, int n);
+int asurf_profile_read_spans(char* names, size_t names_cap, float* ms, int max_spans);
 
 #ifdef __cplusplus
 }

@@ -1,2 +1,3 @@
 import json,sys
-d=json.load(sys.stdin); print(sys.argv[1], d["value"], d["ms_per_step"], d["roofline"]["per_kernel_ms"])
+d=json.load(sys.stdin); r=d["roofline"]
+print(sys.argv[1], d["value"], d["ms_per_step"], r["kernel"], r["frac"], r["whole_call"], r["per_kernel_ms"])
