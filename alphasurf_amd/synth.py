@@ -123,3 +123,52 @@ SYN_OPTS = dict(
 BENCH_SCENE = dict(n_spheres=16, center_range=(0.2, 0.8), radius_range=(0.08, 0.2), seed=1234)
 SYN_FUSED = dict(lambda_l2=1.0, lambda_l1=0.0, lambda_l_entropy=1e-4, lambda_conv_mode_samp=1e-6,
                  l_dist_max_sample=64, l_di_alpha_thresh=0.1, surf_sparse_alpha_thresh=0.15)
+
+
+def make_sparse_scene_torch(reso, basis_dim, device, band=3.0, dilate=2, seed=1234, level_set=(0.0,),
+                            n_spheres=8, fake_sample_std=1.0, trunc_a=1.0, center_range=(0.3, 0.7),
+                            radius_range=(0.10, 0.22)):
+    """make_sparse_scene built on the device with torch (same geometry, torch's RNG for the
+    parameters): for the 512^3 / 768^3 configurations, where the numpy version needs tens of GB
+    of host temporaries.  Returns a dict of device tensors plus the host-side scalars."""
+    import torch
+    rs = np.random.RandomState(seed)
+    centers = rs.uniform(center_range[0], center_range[1], size=(n_spheres, 3)) * reso
+    radii = rs.uniform(radius_range[0], radius_range[1], size=n_spheres) * reso
+    ax = torch.arange(reso, dtype=torch.float32, device=device)
+    sdf = torch.empty((reso, reso, reso), dtype=torch.float32, device=device)
+    for x0 in range(0, reso, 64):
+        xs = ax[x0:x0 + 64]
+        d = torch.full((xs.numel(), reso, reso), 1e9, dtype=torch.float32, device=device)
+        for c, r in zip(centers, radii):
+            dist = torch.sqrt((xs[:, None, None] - float(c[0])) ** 2 + (ax[None, :, None] - float(c[1])) ** 2 +
+                              (ax[None, None, :] - float(c[2])) ** 2) - float(r)
+            d = torch.minimum(d, dist)
+        sdf[x0:x0 + 64] = d
+    mask = sdf.abs() < band
+    for _ in range(dilate):
+        m = mask.clone()
+        m[1:] |= mask[:-1]
+        m[:-1] |= mask[1:]
+        m[:, 1:] |= mask[:, :-1]
+        m[:, :-1] |= mask[:, 1:]
+        m[:, :, 1:] |= mask[:, :, :-1]
+        m[:, :, :-1] |= mask[:, :, 1:]
+        mask = m
+    flat = mask.reshape(-1)
+    ids = torch.cumsum(flat.to(torch.int32), 0, dtype=torch.int32) - 1
+    links = torch.where(flat, ids, torch.full_like(ids, -1)).reshape(reso, reso, reso)
+    n = int(flat.sum().item())
+    gen = torch.Generator(device=device)
+    gen.manual_seed(seed + 1)
+    surface = sdf[mask].reshape(n, 1).contiguous()
+    density = (torch.randn((n, 1), generator=gen, device=device) * 0.1 + 0.5)
+    sh = torch.randn((n, 3 * basis_dim), generator=gen, device=device) * 0.1
+    sh[:, 0] = 0.5
+    return dict(
+        links=links, density=density, surface=surface, sh=sh,
+        level_set=torch.tensor(level_set, dtype=torch.float32, device=device),
+        offset=np.full(3, 0.5 * reso, np.float32), scaling=np.full(3, 0.5 * reso, np.float32),
+        basis_dim=int(basis_dim), fake_sample_std=float(fake_sample_std),
+        truncated_vol_render_a=float(trunc_a), surface_type=102,
+    )

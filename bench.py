@@ -32,6 +32,7 @@ def parse():
     ap.add_argument("--reso", type=int, default=256)
     ap.add_argument("--basis-dim", type=int, default=9)
     ap.add_argument("--width", type=int, default=800)
+    ap.add_argument("--band", type=float, default=3.0, help="half-thickness (voxels) of the active shell")
     ap.add_argument("--shuffle", action="store_true", help="training-order (shuffled) rays")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-rays", type=int, default=40000)
@@ -89,7 +90,11 @@ def main():
     # ---- synthetic workload (seeded; identical grid on every rank) ----
     R, B = args.reso, args.basis_dim
     D = 3 * B
-    sc = synth.make_sparse_scene(R, B, trunc_a=5.0, **synth.BENCH_SCENE)
+    on_device = R > 256 or args.band != 3.0   # big grids: build the scene with torch on the GPU
+    if on_device:
+        sc = synth.make_sparse_scene_torch(R, B, dev, band=args.band, trunc_a=5.0, **synth.BENCH_SCENE)
+    else:
+        sc = synth.make_sparse_scene(R, B, trunc_a=5.0, **synth.BENCH_SCENE)
     o_np, d_np = synth.pinhole_rays(synth.orbit_camera(rank % 8), args.width, args.width)
     if args.shuffle:
         perm = np.random.RandomState(11 + rank).permutation(o_np.shape[0])
@@ -98,11 +103,14 @@ def main():
     gt_np = np.random.RandomState(7 + rank).rand(Q, 3).astype(np.float32)
 
     g = _C.SparseGridSpec()
-    g.density_data = torch.from_numpy(sc["density"]).to(dev)
-    g.surface_data = torch.from_numpy(sc["surface"]).to(dev)
-    g.sh_data = torch.from_numpy(sc["sh"]).to(dev)
-    g.links = torch.from_numpy(sc["links"]).to(dev)
-    g.level_set_data = torch.from_numpy(sc["level_set"]).to(dev)
+    def to_dev(a):
+        return a if torch.is_tensor(a) else torch.from_numpy(a).to(dev)
+
+    g.density_data = to_dev(sc["density"])
+    g.surface_data = to_dev(sc["surface"])
+    g.sh_data = to_dev(sc["sh"])
+    g.links = to_dev(sc["links"])
+    g.level_set_data = to_dev(sc["level_set"])
     g._offset = torch.from_numpy(sc["offset"])
     g._scaling = torch.from_numpy(sc["scaling"])
     g.basis_dim, g.basis_type, g.surface_type = B, 1, 102
@@ -222,6 +230,8 @@ def main():
             from oracle import oracle as O
             n_cpu = min(args.cpu_rays, Q)
             idx = np.linspace(0, Q - 1, n_cpu).astype(np.int64)
+            if on_device:
+                sc = {k: (v.cpu().numpy() if torch.is_tensor(v) else v) for k, v in sc.items()}
             osc = O.make_scene(sc["links"], sc["density"], sc["surface"], sc["sh"], sc["level_set"],
                                sc["offset"], sc["scaling"], B, sc["fake_sample_std"],
                                sc["truncated_vol_render_a"])

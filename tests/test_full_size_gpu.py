@@ -1,0 +1,92 @@
+"""BASELINE.json's large configurations on the GPU box: the grid is built at full size on the
+device, the oracle checks a ray sample of it (the oracle's cost depends on the rays, not the grid),
+and size-independent properties cover the whole batch.  `pytest -m gpu`."""
+import numpy as np
+import pytest
+
+from golden_util import grad_close
+
+pytestmark = pytest.mark.gpu
+
+SYN = dict(sigma_thresh=-1e4, stop_thresh=-1e4, only_outward_intersect=True, truncated_vol_render=True,
+           trunc_vol_weight_min=1e-10, limited_fake_sample=True, fake_sample_l_dist=False, step_size=0.5)
+
+CONFIGS = {
+    # configs[2]: 512^3 sparse grid, SH deg 3
+    "cfg3_512_sh16": dict(reso=512, basis_dim=16, band=3.0, width=800, min_active=4_000_000),
+    # configs[4]: 768^3, > 40 M active voxels, SH deg 3, 1600x1600 (one GPU's share: rows of the view)
+    "cfg5_768_sh16": dict(reso=768, basis_dim=16, band=16.0, width=1600, min_active=40_000_000),
+}
+
+
+@pytest.mark.parametrize("name", list(CONFIGS))
+def test_full_size_config(oracle, name):
+    import torch
+    import hip_util
+    from alphasurf_amd import csrc_api as _C, synth
+    cfg = CONFIGS[name]
+    dev = hip_util.dev()
+    R, B = cfg["reso"], cfg["basis_dim"]
+    sc = synth.make_sparse_scene_torch(R, B, dev, band=cfg["band"], trunc_a=5.0, **synth.BENCH_SCENE)
+    n = sc["density"].shape[0]
+    assert n >= cfg["min_active"], n
+    g = _C.SparseGridSpec()
+    g.density_data, g.surface_data, g.sh_data, g.links = sc["density"], sc["surface"], sc["sh"], sc["links"]
+    g.level_set_data = sc["level_set"]
+    g._offset, g._scaling = torch.from_numpy(sc["offset"]), torch.from_numpy(sc["scaling"])
+    g.basis_dim, g.basis_type, g.surface_type = B, 1, 102
+    g.fake_sample_std, g.truncated_vol_render_a = sc["fake_sample_std"], sc["truncated_vol_render_a"]
+    opt = hip_util.opt_spec(SYN)
+
+    W = cfg["width"]
+    o_np, d_np = synth.pinhole_rays(synth.orbit_camera(1), W, W)
+    # a band of image rows through the middle of the view (every GPU's share in the 8-GPU config)
+    rows = slice((W // 2 - 100) * W, (W // 2 + 100) * W)
+    o_np, d_np = o_np[rows], d_np[rows]
+    Q = o_np.shape[0]
+    gt_np = np.random.RandomState(5).rand(Q, 3).astype(np.float32)
+    fused_kw = dict(lambda_l2=1.0, lambda_l_entropy=1e-4, lambda_conv_mode_samp=1e-6)
+
+    def run(idx):
+        r = hip_util.rays_spec(o_np[idx], d_np[idx])
+        gr = hip_util.zero_grads(g, with_std=False)
+        gt = torch.from_numpy(gt_np[idx]).to(dev)
+        rgb = torch.zeros_like(gt)
+        args = [fused_kw.get(k, dflt) for k, dflt in hip_util.FUSED_ORDER]
+        _C.volume_render_surf_trav_fused(g, r, opt, gt, *args, rgb, gr, global_n_rays=Q)
+        torch.cuda.synchronize()
+        return rgb, gr
+
+    # (1) whole batch == sum of two shards (linearity of the gradient accumulation, global normaliser)
+    all_idx = np.arange(Q)
+    rgb_all, gr_all = run(all_idx)
+    assert torch.isfinite(rgb_all).all()
+    half = Q // 2
+    rgb_a, gr_a = run(all_idx[:half])
+    rgb_b, gr_b = run(all_idx[half:])
+    assert torch.equal(torch.cat([rgb_a, rgb_b]), rgb_all)
+    for k in ("grad_sh_out", "grad_density_out", "grad_surface_out"):
+        full = getattr(gr_all, k)
+        parts = getattr(gr_a, k) + getattr(gr_b, k)
+        scale = full.abs().max().item()
+        assert scale > 0
+        assert (full - parts).abs().max().item() <= 2e-4 * scale, k
+    assert torch.equal(gr_all.mask_out, gr_a.mask_out | gr_b.mask_out)
+    # (2) the mask marks exactly the rows that received a density gradient contribution
+    touched = gr_all.grad_density_out.reshape(-1) != 0
+    assert (gr_all.mask_out | ~touched).all()
+    # (3) the oracle on a strided sample of the same rays, full-size grid
+    samp = np.linspace(0, Q - 1, 3000).astype(np.int64)
+    rgb_s, gr_s = run(samp)
+    host = {k: (v.cpu().numpy() if torch.is_tensor(v) else v) for k, v in sc.items()}
+    osc = oracle.make_scene(host["links"], host["density"], host["surface"], host["sh"], host["level_set"],
+                            host["offset"], host["scaling"], B, host["fake_sample_std"],
+                            host["truncated_vol_render_a"])
+    fused = dict(fused_kw, global_n_rays=Q)
+    rgb_o, go, st = oracle.render_fused(osc, o_np[samp], d_np[samp], SYN, gt_np[samp], fused)
+    assert st["n_samples"].sum() > 100
+    assert np.abs(rgb_s.cpu().numpy() - rgb_o).max() <= 2e-5
+    grad_close(gr_s.grad_sh_out.cpu().numpy(), go["sh"], 2e-4, "grad_sh")
+    grad_close(gr_s.grad_density_out.cpu().numpy(), go["density"], 2e-4, "grad_density")
+    grad_close(gr_s.grad_surface_out.cpu().numpy(), go["surface"], 2e-4, "grad_surface")
+    assert (gr_s.mask_out.cpu().numpy().astype(bool) == go["mask"].astype(bool)).all()
