@@ -273,9 +273,42 @@ k_bwd_sh(KGrid g, KGrads G, int want_dpos, const float* __restrict__ dirs, long 
     const bool on = cs < C::CPR;
     float gx_out = 0.f, gy_out = 0.f, gz_out = 0.f;
     unsigned long long need = need0;
+    // Neighbouring rays mostly sit in the same voxel: their contributions to the 8 SH rows are
+    // summed in registers and flushed with one atomic per (row, coefficient) when the voxel changes
+    // (wave-uniform test, so the lanes never diverge on it).
+    const int my_pv = mine ? S.v[idx] : -1;
+    float run[C::ROUNDS], val[C::ROUNDS];
+#pragma unroll
+    for (int rd = 0; rd < C::ROUNDS; ++rd) run[rd] = val[rd] = 0.f;
+    int run_pv = -1, run_sl = 0;
+    auto flush = [&]() {
+        if (run_pv < 0 || G.grad_sh == nullptr) return;
+#pragma unroll
+        for (int rd = 0; rd < C::ROUNDS; ++rd) {
+            const int c = rd * C::CPR + cs;
+            if (on && c < 8) {
+                const int link = rec_wave[run_sl].link[c];
+                atomicAdd(&G.grad_sh[(size_t)link * C::D + e], run[rd]);
+            }
+            run[rd] = 0.f;
+        }
+    };
     while (need) {
         const int sl = __ffsll((long long)need) - 1;
         need &= need - 1;
+        const int pv = bcast_i(my_pv, sl);
+        if (pv != run_pv) {
+            flush();
+            run_pv = pv;
+            run_sl = sl;
+            if (want_dpos) {  // the voxel's SH rows, kept for every sample of the run
+#pragma unroll
+                for (int rd = 0; rd < C::ROUNDS; ++rd) {
+                    const int c = rd * C::CPR + cs;
+                    if (on && c < 8) val[rd] = g.sh[(size_t)rec_wave[sl].link[c] * C::D + e];
+                }
+            }
+        }
         const float px = bcast_f(pos[0], sl), py = bcast_f(pos[1], sl), pz = bcast_f(pos[2], sl);
         const float g0 = bcast_f(gch[0], sl), g1 = bcast_f(gch[1], sl), g2 = bcast_f(gch[2], sl);
         // fake samples carry no d/dpos (surf_trav.cu:2722)
@@ -287,16 +320,14 @@ k_bwd_sh(KGrid g, KGrads G, int want_dpos, const float* __restrict__ dirs, long 
         for (int rd = 0; rd < C::ROUNDS; ++rd) {
             const int c = rd * C::CPR + cs;
             if (on && c < 8) {
-                const int link = rec_wave[sl].link[c];
                 const float wx = (c & 4) ? px : 1.f - px;
                 const float wy = (c & 2) ? py : 1.f - py;
                 const float wz = (c & 1) ? pz : 1.f - pz;
-                if (G.grad_sh != nullptr) atomicAdd(&G.grad_sh[(size_t)link * C::D + e], wx * wy * wz * cg);
+                run[rd] = fmaf(wx * wy * wz, cg, run[rd]);
                 if (dpos) {
-                    const float val = g.sh[(size_t)link * C::D + e];
-                    ax = fmaf(((c & 4) ? wy : -wy) * wz, val, ax);
-                    ay = fmaf(((c & 2) ? wx : -wx) * wz, val, ay);
-                    az = fmaf(((c & 1) ? wx : -wx) * wy, val, az);
+                    ax = fmaf(((c & 4) ? wy : -wy) * wz, val[rd], ax);
+                    ay = fmaf(((c & 2) ? wx : -wx) * wz, val[rd], ay);
+                    az = fmaf(((c & 1) ? wx : -wx) * wy, val[rd], az);
                 }
             }
         }
@@ -309,6 +340,7 @@ k_bwd_sh(KGrid g, KGrads G, int want_dpos, const float* __restrict__ dirs, long 
             }
         }
     }
+    flush();
     if (mine) {
         S.gx[idx] = gx_out;
         S.gy[idx] = gy_out;

@@ -122,6 +122,7 @@ struct Walk {
     // compiler index them in scratch / kernarg memory inside the DDA loop
     float ox, oy, oz, dx, dy, dz, t_leave;
     int lim0, lim1, lim2;
+    int noskip_key;      // brick whose skip attempt failed (walk_skip_brick)
     // register cache of the occupancy pyramid
     int cur_key;         // packed brick coordinates
     int cur_brick;       // linear brick index
@@ -159,6 +160,7 @@ __device__ __forceinline__ void walk_init(const KGrid& g, const Ray& r, Walk& w)
     w.vx = w.vy = w.vz = 0;
     w.t_far = 0.f;
     w.cur_key = -1;
+    w.noskip_key = -1;
     w.cur_brick = 0;
     w.cur_flag = 0;
     w.cur_lx = -1;
@@ -223,6 +225,95 @@ __device__ __forceinline__ bool walk_test(const KGrid& g, const unsigned int* ld
         w.cur_word = g.fine[(size_t)w.cur_brick * 8 + lx];
     }
     return (w.cur_word >> (((w.vy & 7) << 3) | (w.vz & 7))) & 1ull;
+}
+
+// Hierarchical walk step, exact.  One body serves two cell sizes so that the lanes of a wave do
+// not diverge: the cell is the voxel about to be entered, or -- when its 8^3 brick holds no
+// flagged voxel -- the whole brick.  The walk processes plane crossings in (time, axis) order and
+// every crossing time is the same float expression plane_time(index) however it is reached, so:
+//   * the cell is left through the axis with the smallest exit time T (ties: lowest axis, as in
+//     walk_step); for a voxel cell these are exactly walk_step's far-plane times;
+//   * for a brick cell the voxel index on the other two axes at T is floor(o + T d), PROVIDED
+//     that position is not within 1/64 of a voxel plane: the float error of o + T d and of the
+//     plane times is < 1e-3 voxel at grid sizes <= 1024, so which crossings precede T is decided
+//     without ambiguity.  Otherwise, and near the end of the ray (where the backward's step_size
+//     quirk looks at individual voxels), the brick is walked voxel by voxel.
+// Returns 0: no voxel visited (brick jump, or a jump attempt that was refused -- state unchanged),
+//         1: voxel (vx,vy,vz) visited, not flagged, 2: visited and flagged.
+template <bool LDS>
+__device__ __forceinline__ int walk_hier(const KGrid& g, const unsigned int* lds_coarse, Walk& w,
+                                         float step_size, float tmax, bool allow_jump) {
+    const int nx = w.nx, ny = w.ny, nz = w.nz;
+    const int key = ((nx >> 3) << 20) | ((ny >> 3) << 10) | (nz >> 3);
+    if (key != w.cur_key) {
+        w.cur_key = key;
+        const int bz = nz >> 3;
+        const int bxy = (nx >> 3) * g.nb[1] + (ny >> 3);
+        w.cur_brick = bxy * g.nb[2] + bz;
+        const int wi = bxy * g.nwz + (bz >> 5);
+        unsigned word;
+        if constexpr (LDS) word = lds_coarse[wi];
+        else word = g.coarse[wi];
+        w.cur_flag = (word >> (bz & 31)) & 1u;
+        w.cur_lx = -1;
+    }
+    const bool jump = allow_jump && !w.cur_flag && (key != w.noskip_key);
+    const int m = jump ? 7 : 0;
+    const int sx = w.sx, sy = w.sy, sz = w.sz;
+    const int l0 = w.lim0, l1 = w.lim1, l2 = w.lim2;
+    const float ox = w.ox, oy = w.oy, oz = w.oz, dx = w.dx, dy = w.dy, dz = w.dz;
+    // last voxel of the cell in the direction of travel, per axis, and the time it is left
+    const int ex = (sx > 0) ? min(nx | m, l0 - 1) : (nx & ~m);
+    const int ey = (sy > 0) ? min(ny | m, l1 - 1) : (ny & ~m);
+    const int ez = (sz > 0) ? min(nz | m, l2 - 1) : (nz & ~m);
+    const float Tx = plane_time(ex, sx, ox, dx);
+    const float Ty = plane_time(ey, sy, oy, dy);
+    const float Tz = plane_time(ez, sz, oz, dz);
+    const float T = fminf(fminf(Tx, Ty), Tz);
+    const bool a0 = (T == Tx);
+    const bool a1 = !a0 && (T == Ty);
+    const bool a2 = !a0 && !a1;
+    int cx = nx, cy = ny, cz = nz;
+    if (jump) {
+        const float px = fmaf(T, dx, ox), py = fmaf(T, dy, oy), pz = fmaf(T, dz, oz);
+        const float fx = floorf(px), fy = floorf(py), fz = floorf(pz);
+        const float kEps = 1.f / 64.f;
+        const bool mx = a0 || ((px - fx) > kEps && (px - fx) < 1.f - kEps);
+        const bool my = a1 || ((py - fy) > kEps && (py - fy) < 1.f - kEps);
+        const bool mz = a2 || ((pz - fz) > kEps && (pz - fz) < 1.f - kEps);
+        cx = (int)fx;
+        cy = (int)fy;
+        cz = (int)fz;
+        // the other axes stay inside the brick and never move backwards
+        const bool rx = a0 || (((cx ^ nx) & ~7) == 0 && (cx - nx) * sx >= 0);
+        const bool ry = a1 || (((cy ^ ny) & ~7) == 0 && (cy - ny) * sy >= 0);
+        const bool rz = a2 || (((cz ^ nz) & ~7) == 0 && (cz - nz) * sz >= 0);
+        const bool straight = fminf(fminf(fabsf(dx), fabsf(dy)), fabsf(dz)) > 1e-5f;
+        const bool ok = mx && my && mz && rx && ry && rz && straight && (T <= tmax) && !(T + step_size > tmax);
+        if (!ok) {
+            w.noskip_key = key;
+            return 0;
+        }
+    }
+    w.vx = nx;
+    w.vy = ny;
+    w.vz = nz;
+    const int n_exit = a0 ? ex + sx : (a1 ? ey + sy : ez + sz);
+    const int lim = a0 ? l0 : (a1 ? l1 : l2);
+    const bool leaves = (n_exit < 0) || (n_exit >= lim);
+    w.t_far = T;
+    w.t = leaves ? w.t_leave : T;
+    w.nx = a0 ? n_exit : cx;
+    w.ny = a1 ? n_exit : cy;
+    w.nz = a2 ? n_exit : cz;
+    if (jump) return 0;
+    if (!w.cur_flag) return 1;
+    const int lx = nx & 7;
+    if (lx != w.cur_lx) {
+        w.cur_lx = lx;
+        w.cur_word = g.fine[(size_t)w.cur_brick * 8 + lx];
+    }
+    return 1 + (int)((w.cur_word >> (((ny & 7) << 3) | (nz & 7))) & 1ull);
 }
 
 __device__ __forceinline__ bool live_test(const KGrid& g, const Walk& w) {
@@ -387,19 +478,31 @@ __device__ __forceinline__ void coop_shade_fwd(const KGrid& g, unsigned long lon
     const int ch = e / B;
     const int k = e - ch * B;
     const bool on = cs < C::CPR;
+    // neighbouring rays mostly sit in the same voxel: its SH rows stay in registers until the
+    // voxel (identified by the row id of its first corner) changes -- a wave-uniform test
+    const int my_first = rec_wave[lane].link[0];
+    int held = -1;
+    float val[C::ROUNDS];
+#pragma unroll
+    for (int rd = 0; rd < C::ROUNDS; ++rd) val[rd] = 0.f;
     while (need) {
         const int r = __ffsll((long long)need) - 1;
         need &= need - 1;
         const float px = bcast_f(pos[0], r), py = bcast_f(pos[1], r), pz = bcast_f(pos[2], r);
+        const int first = bcast_i(my_first, r);
+        if (first != held) {
+            held = first;
+#pragma unroll
+            for (int rd = 0; rd < C::ROUNDS; ++rd) {
+                const int c = rd * C::CPR + cs;
+                if (on && c < 8) val[rd] = g.sh[(size_t)rec_wave[r].link[c] * C::D + e];
+            }
+        }
         float acc = 0.f;
 #pragma unroll
         for (int rd = 0; rd < C::ROUNDS; ++rd) {
             const int c = rd * C::CPR + cs;
-            if (on && c < 8) {
-                const int link = rec_wave[r].link[c];
-                const float val = g.sh[(size_t)link * C::D + e];
-                acc = fmaf(corner_w(c, px, py, pz), val, acc);
-            }
+            if (on && c < 8) acc = fmaf(corner_w(c, px, py, pz), val[rd], acc);
         }
         acc = on ? acc * sph_wave[r * kSphPad + k] : 0.f;
         const float s0 = wave_sum(ch == 0 ? acc : 0.f);

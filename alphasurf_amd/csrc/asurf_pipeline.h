@@ -105,14 +105,14 @@ k_walk(KGrid g, KOpt o, const float* __restrict__ origins, const float* __restri
         Walk w;
         walk_init(g, r, w);
         bool active = true;
+        const bool jump = !(o.debug & 8);
         while (active) {
-            walk_step(g, r, w);
-            const bool hit = walk_test<CLDS>(g, s_coarse, w);
+            const int kind = walk_hier<CLDS>(g, s_coarse, w, o.step_size, r.tmax, jump);
             active = (w.t <= r.tmax);
-            if (hit) {
+            if (kind == 2) {
                 if (cnt < P.C1) P.items[(size_t)cnt * Q + q] = pack_voxel(w.vx, w.vy, w.vz);
                 ++cnt;
-            } else if (want_cut && active && (w.t + o.step_size > r.tmax) && cutv == 0x7fffffff) {
+            } else if (kind == 1 && want_cut && active && (w.t + o.step_size > r.tmax) && cutv == 0x7fffffff) {
                 if (!links_present(g, w)) cutv = cnt;  // surf_trav.cu:1935-1936
             }
         }
@@ -134,9 +134,9 @@ k_walk(KGrid g, KOpt o, const float* __restrict__ origins, const float* __restri
                 walk_init(g, r, w);
                 bool active = true;
                 int k = 0;
+                const bool jump = !(o.debug & 8);
                 while (active) {
-                    walk_step(g, r, w);
-                    const bool hit = walk_test<CLDS>(g, s_coarse, w);
+                    const bool hit = walk_hier<CLDS>(g, s_coarse, w, o.step_size, r.tmax, jump) == 2;
                     active = (w.t <= r.tmax);
                     if (hit) {
                         if (k >= P.C1) {

@@ -306,3 +306,43 @@ def test_cubic_root_grad_kernel(hip, oracle):
     g = T_g.cpu().numpy()
     scale = np.maximum(np.abs(go), 1.0)
     assert (np.abs(g - go) / scale).max() < 1e-3
+
+
+def test_brick_skipping_is_exact(hip, monkeypatch):
+    """k_walk jumps over empty 8^3 bricks; the work-voxel lists must be those of the per-voxel
+    walk.  RGB is a deterministic function of that list, so it must match bit for bit -- on
+    random rays and on rays built to graze voxel planes, brick corners and lattice points."""
+    from alphasurf_amd import synth
+    rs = np.random.RandomState(11)
+    for reso, seed in ((48, 5), (96, 6), (130, 7)):
+        sc = synth.make_sparse_scene(reso, 4, seed=seed, band=2.0, dilate=1)
+        o1, d1 = synth.random_rays(6000, seed + 1)
+        # world coordinates of lattice points / brick corners (grid = world * reso/2 + reso/2)
+        def world(p):
+            return (np.asarray(p, np.float64) - reso / 2) / (reso / 2)
+        n = 3000
+        tgt = rs.randint(0, reso, size=(n, 3)).astype(np.float64)
+        tgt[: n // 3] = (tgt[: n // 3] // 8) * 8                     # brick corners
+        src = rs.randint(-reso, 2 * reso, size=(n, 3)).astype(np.float64)
+        src[n // 2:] += rs.rand(n - n // 2, 3)                       # half of them from integer origins
+        keep = np.linalg.norm(tgt - src, axis=1) > 1
+        o2 = world(src[keep]).astype(np.float32)
+        d2 = (tgt[keep] - src[keep])
+        d2 = (d2 / np.linalg.norm(d2, axis=1, keepdims=True)).astype(np.float32)
+        # axis-parallel and plane-parallel rays
+        o3 = world(rs.randint(0, reso, size=(600, 3)) + np.array([-2.0 * reso, 0.25, 0.5])).astype(np.float32)
+        d3 = np.tile(np.array([[1.0, 0.0, 0.0]], np.float32), (600, 1))
+        d3[300:] = np.array([0.6, 0.8, 0.0], np.float32)
+        o = np.concatenate([o1, o2, o3]).astype(np.float32)
+        d = np.concatenate([d1, d2, d3]).astype(np.float32)
+        gt = rs.rand(o.shape[0], 3).astype(np.float32)
+        opts = dict(OPTION_SETS["syn_yaml"], step_size=0.5)
+        fused = dict(lambda_l2=1.0, lambda_l_entropy=1e-3)
+        monkeypatch.setenv("ASURF_DEBUG", "8")        # per-voxel walk only
+        rgb_ref, g_ref = hip.render_fused(sc, o, d, opts, gt, fused)
+        monkeypatch.delenv("ASURF_DEBUG")
+        rgb, g = hip.render_fused(sc, o, d, opts, gt, fused)
+        assert np.array_equal(rgb, rgb_ref), f"reso {reso}: {np.abs(rgb - rgb_ref).max()}"
+        assert (g["mask"] == g_ref["mask"]).all()
+        for k in ("sh", "density", "surface"):
+            grad_close(g[k], g_ref[k], 1e-5, f"reso {reso} grad_{k}")
