@@ -42,7 +42,7 @@ struct MaskLayout {
     size_t off_cache_a, off_cache_w, off_cache_t, off_cache_n;
     size_t off_rec_v, off_rec_m, off_rec_n, off_rec_neff, off_rec_sws, off_rec_f;
     size_t off_p_items, off_p_citem, off_p_nitems, off_p_cut, off_p_flagged, off_p_counters, off_p_pool;
-    size_t off_p_spbase, off_p_spill;
+    size_t off_p_spbase, off_p_spill, off_p_list, off_rec_list;
     int pool_shard_cap, sp_cap;
     size_t total;
 };
@@ -113,8 +113,12 @@ MaskLayout layout_for(const int32_t size[3], int64_t n_rays, int32_t M) {
     L.sp_cap = (int)(4 * nr) + 256;  // spilled work voxels (beyond kPipeC1 per ray), all rays together
     L.off_p_spill = off;             // sp_items | sp_citem | sp_ray
     off = align_up(off + (size_t)L.sp_cap * 3 * 4, 256);
-    L.off_p_counters = off;  // n_flagged, spill cursor, kPoolShards pool cursors
-    off = align_up(off + (2 + kPoolShards) * 4, 256);
+    L.off_p_list = off;      // dense list of occupied table cells (k_walk -> k_geom)
+    off = align_up(off + iplane, 256);
+    L.off_rec_list = off;    // dense list of visited records (k_bwd_seq -> k_bwd_geo)
+    off = align_up(off + rplane, 256);
+    L.off_p_counters = off;  // n_flagged, spill cursor, kPoolShards pool cursors, 2 list lengths
+    off = align_up(off + kCtrTotal * 4, 256);
     L.pool_shard_cap = (int)((8 * nr + kPoolShards - 1) / kPoolShards) + 64;
     L.off_p_pool = off;
     off = align_up(off + (size_t)L.pool_shard_cap * kPoolShards * sizeof(CandRec), 256);
@@ -293,10 +297,12 @@ int prepare(const asurf_grid* grid, const asurf_rays* rays, const asurf_render_o
 // exact V_t/V_a/S counters (a ray stopped by stop_thresh must not be walked further),
 // stop_thresh > 1 (the reference then stops at the first voxel that passes the gates even if
 // it holds no sample), or more level sets than a record encodes.
-bool use_pipeline(const asurf_grid* grid, const asurf_render_options* opt, const uint64_t* counters) {
+bool use_pipeline(const asurf_grid* grid, const asurf_rays* rays, const asurf_render_options* opt,
+                  const uint64_t* counters) {
     const char* off = getenv("ASURF_NO_PIPELINE");
     if (off && atoi(off)) return false;
     return counters == nullptr && !(opt->stop_thresh > 1.f) && grid->level_set_num <= 32 &&
+           rays->n_rays < (1ll << kListRayBits) &&
            grid->size[0] <= 1024 && grid->size[1] <= 1024 && grid->size[2] <= 1024;
 }
 
@@ -333,7 +339,8 @@ int run_forward(const Launch& L, const asurf_rays* rays, float* rgb_out, int M, 
         P.pool = reinterpret_cast<CandRec*>(L.ws + L.ML.off_p_pool);
         P.shard_cap = L.ML.pool_shard_cap;
         P.C1 = kPipeC1;
-        if (hipMemsetAsync(P.counters, 0, (2 + kPoolShards) * sizeof(int), L.stream) != hipSuccess)
+        P.list = reinterpret_cast<unsigned*>(L.ws + L.ML.off_p_list);
+        if (hipMemsetAsync(P.counters, 0, kCtrTotal * sizeof(int), L.stream) != hipSuccess)
             return fail(ASURF_E_LAUNCH, "hipMemsetAsync failed");
         if (L.coarse_in_lds)
             hipLaunchKernelGGL((k_walk<true>), L.ray_grid, dim3(kBlock), L.dyn_lds, L.stream, L.g, L.o,
@@ -342,11 +349,11 @@ int run_forward(const Launch& L, const asurf_rays* rays, float* rgb_out, int M, 
             hipLaunchKernelGGL((k_walk<false>), L.ray_grid, dim3(kBlock), 0, L.stream, L.g, L.o,
                                rays->origins, rays->dirs, Q, P, record ? 1 : 0);
         prof_after("k_walk", 1, L.stream);
-        hipLaunchKernelGGL((k_geom<false>), dim3(L.ray_grid.x, kPipeC1), dim3(kBlock), 0, L.stream, L.g,
+        hipLaunchKernelGGL((k_geom<false>), dim3(kListBlocks), dim3(kBlock), 0, L.stream, L.g,
                            L.o, rays->origins, rays->dirs, Q, P);
         prof_after("k_geom", 1, L.stream);
-        hipLaunchKernelGGL((k_geom<true>), dim3((unsigned)((L.ML.sp_cap + kBlock - 1) / kBlock)),
-                           dim3(kBlock), 0, L.stream, L.g, L.o, rays->origins, rays->dirs, Q, P);
+        hipLaunchKernelGGL((k_geom<true>), dim3(256), dim3(kBlock), 0, L.stream, L.g, L.o, rays->origins,
+                           rays->dirs, Q, P);
         prof_after("k_geom_spill", 1, L.stream);
         if (cache)
             hipLaunchKernelGGL((k_comp<B, true>), L.ray_grid, dim3(kBlock), 0, L.stream, L.g, L.o,
@@ -426,10 +433,14 @@ int run_backward(const Launch& L, const asurf_rays* rays, const KLoss& loss, con
         S.gx = f + 14 * plane;
         S.gy = f + 15 * plane;
         S.gz = f + 16 * plane;
+        S.list = reinterpret_cast<unsigned*>(L.ws + L.ML.off_rec_list);
+        S.n_list = reinterpret_cast<int*>(L.ws + L.ML.off_p_counters) + kCtrList + 1;
         S.n_eff = reinterpret_cast<int*>(L.ws + L.ML.off_rec_neff);
         S.sws = reinterpret_cast<float*>(L.ws + L.ML.off_rec_sws);
         S.R = kRecDepth;
         const long long Q = rays->n_rays;
+        if (hipMemsetAsync(S.n_list, 0, sizeof(int), L.stream) != hipSuccess)
+            return fail(ASURF_E_LAUNCH, "hipMemsetAsync failed");
         hipLaunchKernelGGL(k_bwd_seq, L.ray_grid, dim3(kBlock), 0, L.stream, L.o, loss, L.g.trunc_a, Q,
                            grad_in, color_cache, M, ca, cw, ct, cn, S);
         prof_after("k_bwd_seq", 2, L.stream);
@@ -437,7 +448,7 @@ int run_backward(const Launch& L, const asurf_rays* rays, const KLoss& loss, con
         hipLaunchKernelGGL((k_bwd_sh<B>), grid2, dim3(kBlock), 0, L.stream, L.g, G,
                            L.o.no_surf_grad_from_sh ? 0 : 1, rays->dirs, Q, S);
         prof_after("k_bwd_sh", 2, L.stream);
-        hipLaunchKernelGGL(k_bwd_geo, grid2, dim3(kBlock), 0, L.stream, L.g, L.o, loss, G, rays->origins,
+        hipLaunchKernelGGL(k_bwd_geo, dim3(kListBlocks), dim3(kBlock), 0, L.stream, L.g, L.o, loss, G, rays->origins,
                            rays->dirs, Q, S);
         prof_after("k_bwd_geo", 2, L.stream);
     } else if (mode == 1) {
@@ -554,7 +565,7 @@ int asurf_volume_render_surf_trav(const asurf_grid* grid, const asurf_rays* rays
     if (rays->n_rays == 0) return 0;
     if (!rgb_out) return fail(ASURF_E_INVALID, "rgb_out is NULL");
     int rc = 0;
-    const bool pipe = use_pipeline(grid, opt, counters);
+    const bool pipe = use_pipeline(grid, rays, opt, counters);
     ASURF_DISPATCH_B(grid->basis_dim, run_forward<B_>(L, rays, rgb_out, 0, false, false, counters, pipe));
     return rc;
 }
@@ -622,12 +633,13 @@ int asurf_volume_render_surf_trav_fused(const asurf_grid* grid, const asurf_rays
     const char* norec = getenv("ASURF_NO_REPLAY");
     const bool replay = !(norec && atoi(norec)) && grid->level_set_num <= 32 &&
                         (opt->stop_thresh <= 0.f || opt->stop_thresh >= 2e-8f);
-    const bool pipe = use_pipeline(grid, opt, counters);
+    const bool pipe = use_pipeline(grid, rays, opt, counters);
     ASURF_DISPATCH_B(grid->basis_dim, run_forward<B_>(L, rays, rgb_out, M, true, replay, counters, pipe));
     if (rc) return rc;
     if (replay) {
         const char* nosplit = getenv("ASURF_NO_SPLIT_BWD");
-        const int replay_mode = (nosplit && atoi(nosplit)) ? 1 : 3;
+        const int replay_mode =
+            ((nosplit && atoi(nosplit)) || rays->n_rays >= (1ll << kListRayBits)) ? 1 : 3;
         ASURF_DISPATCH_B(grid->basis_dim,
                          run_backward<B_>(L, rays, loss, G, fused->rgb_gt, rgb_out, M, true, replay_mode));
         if (rc) return rc;

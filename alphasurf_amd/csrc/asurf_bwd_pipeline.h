@@ -18,6 +18,7 @@
 // Grid of the last two: (ceil(Q/256), R): block row r handles record r of 256 consecutive rays.
 #pragma once
 #include "asurf_kernels.h"
+#include "asurf_pipeline.h"
 
 namespace asurf {
 
@@ -45,23 +46,24 @@ struct SampleRec {  // planes [R][Q]
     float* gy;
     float* gz;
     int* n;      // [Q] records of the ray (< 0: overflowed, ray belongs to the walking kernel)
+    unsigned* list;  // dense list of visited (record, ray) cells: record << 27 | ray (k_bwd_seq)
+    int* n_list;     // its length
     int* n_eff;  // [Q] records the backward actually visits (stop_thresh)
     float* sws;  // [Q] clamped sum of the cached weights (sparsity term)
     int R;
 };
 
 // ------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(kBlock)
-k_bwd_seq(KOpt o, KLoss L, float trunc_a, long long Q, const float* __restrict__ rgb_gt,
-          const float* __restrict__ rgb_out, int M, const float* __restrict__ cache_a,
-          const float* __restrict__ cache_w, const float* __restrict__ cache_t,
-          const int* __restrict__ cache_n, SampleRec S) {
-    const long long q = (long long)blockIdx.x * kBlock + threadIdx.x;
-    if (q >= Q) return;
+// one ray of k_bwd_seq; returns the number of records the backward visits
+__device__ inline int bwd_seq_ray(const KOpt& o, const KLoss& L, float trunc_a, long long Q, long long q,
+                                  const float* __restrict__ rgb_gt, const float* __restrict__ rgb_out, int M,
+                                  const float* __restrict__ cache_a, const float* __restrict__ cache_w,
+                                  const float* __restrict__ cache_t, const int* __restrict__ cache_n,
+                                  const SampleRec& S) {
     const int n_rec = S.n[q];
     if (n_rec <= 0) {
         S.n_eff[q] = 0;
-        return;
+        return 0;
     }
     float gout[3];
     float accum;
@@ -219,6 +221,43 @@ k_bwd_seq(KOpt o, KLoss L, float trunc_a, long long Q, const float* __restrict__
         }
     }
     S.n_eff[q] = min(r, n_rec);
+    return min(r, n_rec);
+}
+
+__global__ void __launch_bounds__(kBlock)
+k_bwd_seq(KOpt o, KLoss L, float trunc_a, long long Q, const float* __restrict__ rgb_gt,
+          const float* __restrict__ rgb_out, int M, const float* __restrict__ cache_a,
+          const float* __restrict__ cache_w, const float* __restrict__ cache_t,
+          const int* __restrict__ cache_n, SampleRec S) {
+    const long long q = (long long)blockIdx.x * kBlock + threadIdx.x;
+    int nt = 0;
+    if (q < Q) nt = bwd_seq_ray(o, L, trunc_a, Q, q, rgb_gt, rgb_out, M, cache_a, cache_w, cache_t, cache_n, S);
+    // dense list of the (record, ray) cells the backward visits, record-major within the wave
+    int wave_total;
+    wave_excl_scan(nt, &wave_total);
+    // one allocation per block (a single counter serialises ten thousand per-wave atomics)
+    __shared__ int s_tot[kBlock / 64 + 1];
+    if ((threadIdx.x & 63) == 0) s_tot[threadIdx.x >> 6] = wave_total;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int sum = 0;
+        for (int w = 0; w < kBlock / 64; ++w) {
+            const int t = s_tot[w];
+            s_tot[w] = sum;
+            sum += t;
+        }
+        s_tot[kBlock / 64] = sum > 0 ? atomicAdd(S.n_list, sum) : 0;
+    }
+    __syncthreads();
+    if (wave_total > 0) {
+        int base0 = s_tot[kBlock / 64] + s_tot[threadIdx.x >> 6];
+        const unsigned long long below = (1ull << (threadIdx.x & 63)) - 1ull;
+        for (int j = 0; __any(nt > j); ++j) {
+            const unsigned long long m = __ballot(nt > j);
+            if (nt > j) S.list[base0 + __popcll(m & below)] = ((unsigned)j << kListRayBits) | (unsigned)q;
+            base0 += __popcll(m);
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------
@@ -348,14 +387,30 @@ k_bwd_sh(KGrid g, KGrads G, int want_dpos, const float* __restrict__ dirs, long 
     }
 }
 
+__device__ __forceinline__ void acc8(float* dst, const float* w) {
+#pragma unroll
+    for (int c = 0; c < 8; ++c) dst[c] += w[c];
+}
+
 // ------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(kBlock)
 k_bwd_geo(KGrid g, KOpt o, KLoss L, KGrads G, const float* __restrict__ origins,
           const float* __restrict__ dirs, long long Q, SampleRec S) {
-    const int r_i = blockIdx.y;
-    const long long q = (long long)blockIdx.x * kBlock + threadIdx.x;
-    if (q >= Q) return;
-    if (r_i >= S.n_eff[q]) return;
+  const int n_list = *S.n_list;
+  const int lane = threadIdx.x & 63;
+  const int wave_id = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+  for (int base = wave_id * 64; base < n_list; base += (int)gridDim.x * kBlock) {
+    const int i = base + lane;
+    const bool mine = i < n_list;
+    // per-sample contributions to the 8 corner rows of the density and the surface gradient
+    float gd[8] = {0, 0, 0, 0, 0, 0, 0, 0}, gs[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    int lk8[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    int key = -1 - lane;  // lanes without a sample never join a run
+    float gstd_acc = 0.f;
+    if (mine) {
+    const unsigned cell = S.list[i];
+    const long long q = (long long)(cell & ((1u << kListRayBits) - 1u));
+    const int r_i = (int)(cell >> kListRayBits);
     const size_t idx = (size_t)r_i * Q + q;
     const int meta = S.m[idx];
     const bool fake = meta & 1;
@@ -370,7 +425,10 @@ k_bwd_geo(KGrid g, KOpt o, KLoss L, KGrads G, const float* __restrict__ origins,
     }
     setup_ray(g, o, r);
     Vox v;
-    load_voxel(g, r, S.v[idx], v);
+    key = S.v[idx];
+    load_voxel(g, r, key, v);
+#pragma unroll
+    for (int c = 0; c < 8; ++c) lk8[c] = v.lk[c];
     const float raw_alpha = S.raw[idx];
     const float weight = S.w[idx];
     const float sws = S.sws[q];
@@ -395,11 +453,9 @@ k_bwd_geo(KGrid g, KOpt o, KLoss L, KGrads G, const float* __restrict__ origins,
     if (!fake) {
         const float lvf = g.level_set[li];
         double fs[4] = {v.fs[0] - (double)lvf, v.fs[1], v.fs[2], v.fs[3]};
-        double st[3] = {-1, -1, -1};
-        const int root_type = solve_cubic_vieta(fs[0], fs[1], fs[2], fs[3], st);
-        const double stv = (st_id == 0) ? st[0] : (st_id == 1) ? st[1] : st[2];
-        float pos[3];
-        root_position(r, v, stv, pos);
+        // the forward stored the sample position; only the branch of the root gradient is needed
+        const int root_type = classify_cubic_vieta(fs[0], fs[1], fs[2], fs[3]);
+        const float pos[3] = {S.px[idx], S.py[idx], S.pz[idx]};
         if (L.sparsity_loss > 0.f && raw_alpha > 0.f) cgr = sparsity_term(cgr, alpha);
         if (L.lambda_inwards_norm_loss > 0.f) inwards(pos, cgr);
         const float curr_grad_alpha = cgr * trunc_reweight;
@@ -407,7 +463,7 @@ k_bwd_geo(KGrid g, KOpt o, KLoss L, KGrads G, const float* __restrict__ origins,
         {
             float cw[8];
             corner_weights(pos, curr_grad_raw_alpha, cw);
-            scatter8(G.grad_density, G.mask, v.lk, cw);
+            acc8(gd, cw);
         }
         if (L.lambda_l_di > 0.f && alpha < L.l_di_alpha_thresh)
             curr_grad_raw_alpha += L.lambda_l_di * (-1.f) * alpha_act_grad(alpha, o.alpha_activation_type);
@@ -422,11 +478,11 @@ k_bwd_geo(KGrid g, KOpt o, KLoss L, KGrads G, const float* __restrict__ origins,
                               (float)((double)v.new_origin[1] - (double)v.vy),
                               (float)((double)v.new_origin[2] - (double)v.vz)};
         surface_cubic_grad(nof, r.d, grad_fs, gsurf);
-        scatter8(G.grad_surface, G.mask, v.lk, gsurf);
+        acc8(gs, gsurf);
         if (alpha < L.surf_sparse_alpha_thresh) {  // :2436-2445
             float cw[8];
             corner_weights(pos, L.lambda_inplace_surf_sparse, cw);
-            scatter8(G.grad_surface, G.mask, v.lk, cw);
+            acc8(gs, cw);
         }
     } else {  // fake sample (:2460-2866)
         float pos[3];
@@ -442,7 +498,7 @@ k_bwd_geo(KGrid g, KOpt o, KLoss L, KGrads G, const float* __restrict__ origins,
         {
             float cw[8];
             corner_weights(pos, curr_grad_raw_alpha, cw);
-            scatter8(G.grad_density, G.mask, v.lk, cw);
+            acc8(gd, cw);
         }
         const float grad_fake_dist =
             cgr * (-alpha * trunc_reweight * dist * reweight / sqrf(g.fake_sample_std));
@@ -464,13 +520,43 @@ k_bwd_geo(KGrid g, KOpt o, KLoss L, KGrads G, const float* __restrict__ origins,
                 }
             }
         }
-        scatter8(G.grad_surface, G.mask, v.lk, gsurf);
+        acc8(gs, gsurf);
         if (G.grad_fake_sample_std != nullptr) {
             const float gstd = cgr * alpha * sqrf(dist) * reweight * trunc_reweight /
                                (g.fake_sample_std * g.fake_sample_std * g.fake_sample_std);
-            atomicAdd(G.grad_fake_sample_std, gstd);
+            gstd_acc += gstd;
         }
     }
+    }  // mine
+    // Neighbouring list entries are neighbouring rays, mostly in the same voxel: runs of equal
+    // voxels are summed across lanes (segmented doubling over contiguous lanes) and only the
+    // first lane of a run touches memory -- the [N,1] planes cost one L2 transaction per
+    // scattered atomic, so fewer atomics is what counts.
+    const int key_up = __shfl_up(key, 1);
+    const bool head = (lane == 0) || (key_up != key);
+    // run number = heads at or below this lane: monotone, so equal numbers at distance d mean
+    // every lane in between belongs to the same run (a voxel may come back in a later run)
+    const int run = __popcll(__ballot(head) & ((2ull << lane) - 1ull));
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int k2 = __shfl_down(run, d);
+        const bool take = (lane + d < 64) && (k2 == run);
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            const float a = __shfl_down(gd[c], d), b2 = __shfl_down(gs[c], d);
+            gd[c] += take ? a : 0.f;
+            gs[c] += take ? b2 : 0.f;
+        }
+    }
+    if (mine && head) {
+        scatter8(G.grad_density, G.mask, lk8, gd);
+        scatter8(G.grad_surface, G.mask, lk8, gs);
+    }
+    if (G.grad_fake_sample_std != nullptr) {
+        const float tot = wave_sum(gstd_acc);
+        if (lane == 0 && tot != 0.f) atomicAdd(G.grad_fake_sample_std, tot);
+    }
+  }
 }
 
 }  // namespace asurf

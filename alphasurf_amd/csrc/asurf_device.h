@@ -319,9 +319,13 @@ __device__ inline int solve_cubic_vieta(double f0, double f1, double f2, double 
     if (sqrd(R) < cubd(Q)) {
         const double theta = acos(R / sqrt(cubd(Q)));
         const double m2sq = -2. * sqrt(Q);
-        st[0] = m2sq * cos(theta / 3.) - b / 3.;
-        st[1] = m2sq * cos((theta - 2. * kPi) / 3.) - b / 3.;
-        st[2] = m2sq * cos((theta + 2. * kPi) / 3.) - b / 3.;
+        // cos((theta -+ 2 pi) / 3) from one sincos: cos(x -+ 2pi/3) = -cos(x)/2 +- sqrt(3)/2 sin(x)
+        double s3, c3;
+        sincos(theta / 3., &s3, &c3);
+        const double h = 0.86602540378443864676 * s3;
+        st[0] = m2sq * c3 - b / 3.;
+        st[1] = m2sq * (-0.5 * c3 + h) - b / 3.;
+        st[2] = m2sq * (-0.5 * c3 - h) - b / 3.;
         return CUBIC_THREE_R;
     }
     const double sgn = (R > 0.) ? 1. : -1.;  // cuda_util.cuh:145
@@ -329,6 +333,24 @@ __device__ inline int solve_cubic_vieta(double f0, double f1, double f2, double 
     const double Bq = (A == 0.) ? 0. : Q / A;
     st[0] = (A + Bq) - b / 3.;
     return CUBIC_ONE_R_;
+}
+
+// The root type solve_cubic_vieta would report, without evaluating the cubic's roots (the replay
+// backward knows the sample position already and only needs the branch of the gradient).
+__device__ inline int classify_cubic_vieta(double f0, double f1, double f2, double f3) {
+    const double eps = 1e-10;
+    if (fabs(f3) < eps) {
+        if (fabs(f2) < eps) return (fabs(f1) < eps) ? CUBIC_NO_ROOT : CUBIC_LINEAR;
+        const double D = sqrd(f1) - 4.0 * f2 * f0;
+        if (!(D > 0)) return CUBIC_NO_ROOT;
+        const double sD = sqrt(D);
+        const double r0 = (-f1 - sD) / (2 * f2), r1 = (-f1 + sD) / (2 * f2);
+        return (fabs(r0 - r1) < eps) ? CUBIC_POLY_ONE_R : CUBIC_POLY;
+    }
+    const double b = f2 / f3, c = f1 / f3, d = f0 / f3;
+    const double Q = (sqrd(b) - 3. * c) / 9.;
+    const double R = (2. * cubd(b) - 9. * b * c + 27. * d) / 54.;
+    return (sqrd(R) < cubd(Q)) ? CUBIC_THREE_R : CUBIC_ONE_R_;
 }
 
 // calc_cubic_root_grad_vieta, render_util.cuh:1206-1415: g[k] holds dL/d(root) on entry
@@ -384,19 +406,31 @@ __device__ inline void cubic_root_grad_vieta(int type, int st_id, const double* 
     const double db[4] = {0., 0., 1. / f3, -f2 / sqrd(f3)};
     const double dst_db = -1. / 3.;
     if (type == CUBIC_THREE_R) {
-        const double theta = acos(R / sqrt(cubd(Q)));
-        const double dth_dQ = 3. * R / (2. * Q * sqrt(1. - sqrd(R) / cubd(Q)) * sqrt(cubd(Q)));
-        const double dth_dR = -1 / (sqrt(1 - sqrd(R) / cubd(Q)) * sqrt(cubd(Q)));
+        const double sqQ3 = sqrt(cubd(Q));
+        const double theta = acos(R / sqQ3);
+        const double rad = sqrt(1. - sqrd(R) / cubd(Q));
+        const double dth_dQ = 3. * R / (2. * Q * rad * sqQ3);
+        const double dth_dR = -1 / (rad * sqQ3);
+        // one sincos of theta/3; the shifted angles through cos/sin(pi/3), cos/sin(pi/6)
+        double s3, c3;
+        sincos(theta / 3., &s3, &c3);
+        const double kH = 0.86602540378443864676;  // sqrt(3)/2
+        const double sqQ = sqrt(Q);
+        double cs, sn;  // the (cos-like, sin-like) pair each root's derivative uses
         double dst_dQ, dst_dth;
         if (st_id == 0) {
-            dst_dQ = -cos(theta / 3.) / sqrt(Q);
-            dst_dth = 2. * sqrt(Q) * sin(theta / 3.) / 3.;
+            dst_dQ = -c3 / sqQ;
+            dst_dth = 2. * sqQ * s3 / 3.;
         } else if (st_id == 1) {
-            dst_dQ = cos(theta / 3. + kPi / 3.) / sqrt(Q);
-            dst_dth = -2. * sqrt(Q) * sin(theta / 3. + kPi / 3.) / 3.;
+            cs = 0.5 * c3 - kH * s3;  // cos(theta/3 + pi/3)
+            sn = 0.5 * s3 + kH * c3;  // sin(theta/3 + pi/3)
+            dst_dQ = cs / sqQ;
+            dst_dth = -2. * sqQ * sn / 3.;
         } else {
-            dst_dQ = sin(theta / 3. + kPi / 6.) / sqrt(Q);
-            dst_dth = 2. * sqrt(Q) * cos(theta / 3. + kPi / 6.) / 3.;
+            sn = kH * s3 + 0.5 * c3;  // sin(theta/3 + pi/6)
+            cs = kH * c3 - 0.5 * s3;  // cos(theta/3 + pi/6)
+            dst_dQ = sn / sqQ;
+            dst_dth = 2. * sqQ * cs / 3.;
         }
 #pragma unroll
         for (int k = 0; k < 4; ++k)

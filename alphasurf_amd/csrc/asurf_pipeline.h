@@ -44,6 +44,13 @@ __device__ __forceinline__ void cand_put(CandRec& dst, const CandRec& src, bool 
 // The candidate pool is cut into shards with their own cursors so that the allocating
 // atomics of k_geom do not serialise on one address.
 constexpr int kPoolShards = 256;
+constexpr int kCtrList = 2 + kPoolShards;
+constexpr int kCtrTotal = kCtrList + 2;
+constexpr int kListRayBits = 27;  // rays per call < 2^27 for the list-driven kernels
+// The kernels that work through a dense list are launched with a fixed number of blocks and
+// stride over it: the list length is only known on the device, and tens of thousands of
+// blocks that exit at once still cost their dispatch.
+constexpr int kListBlocks = 2048;
 
 struct PipeBuf {
     int* items;      // [C1][Q] packed work voxels
@@ -55,7 +62,9 @@ struct PipeBuf {
     int* sp_citem;   // [sp_cap]
     int* sp_ray;     // [sp_cap] owning ray
     int* flagged;    // [Q] compacted ids of the rays handed back
-    int* counters;   // [0] n_flagged, [1] spill cursor, [2 .. 2+kPoolShards) pool cursors
+    int* counters;   // [0] n_flagged, [1] spill cursor, [2 .. 2+kPoolShards) pool cursors,
+                     // [kCtrList] entries in `list`, [kCtrList + 1] entries in the backward's list
+    unsigned* list;  // dense list of the occupied (slot, ray) cells of `items`: slot << 27 | ray
     CandRec* pool;
     int shard_cap;   // records per pool shard
     int sp_cap;
@@ -157,11 +166,29 @@ k_walk(KGrid g, KOpt o, const float* __restrict__ origins, const float* __restri
         P.n_items[q] = cnt;
         P.cut[q] = cutv;
     }
+    // dense list of this wave's table cells, slot-major so that neighbouring list entries are
+    // neighbouring rays at the same depth (k_geom works one entry per lane)
+    {
+        const int nt = (valid && cnt > 0) ? min(cnt, P.C1) : 0;
+        int wave_total;
+        wave_excl_scan(nt, &wave_total);
+        if (wave_total > 0) {
+            int base0 = 0;
+            if ((tid & 63) == 0) base0 = atomicAdd(&P.counters[kCtrList], wave_total);
+            base0 = __shfl(base0, 0);
+            const unsigned long long below = (1ull << (tid & 63)) - 1ull;
+            for (int j = 0; __any(nt > j); ++j) {
+                const unsigned long long m = __ballot(nt > j);
+                if (nt > j) P.list[base0 + __popcll(m & below)] = ((unsigned)j << kListRayBits) | (unsigned)q;
+                base0 += __popcll(m);
+            }
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------
-// SPILL = false: grid (ceil(Q/256), C1), block row s handles table slot s of 256 rays.
-// SPILL = true : 1-D grid over the spill list.
+// One work voxel per lane, taken from a dense list: SPILL = false the list of table cells written
+// by k_walk, SPILL = true the spill list.  kListBlocks blocks stride over it.
 #ifndef ASURF_GEOM_WAVES
 #define ASURF_GEOM_WAVES 3
 #endif
@@ -169,127 +196,131 @@ template <bool SPILL>
 __global__ void __launch_bounds__(kBlock, ASURF_GEOM_WAVES)
 k_geom(KGrid g, KOpt o, const float* __restrict__ origins, const float* __restrict__ dirs,
        long long Q, PipeBuf P) {
-    long long q;
-    int packed_voxel = 0;
-    long long entry = 0;
-    bool mine;
-    if constexpr (SPILL) {
-        entry = (long long)blockIdx.x * kBlock + threadIdx.x;
-        const int n_sp = min(P.counters[1], P.sp_cap);
-        mine = entry < n_sp;
-        q = mine ? P.sp_ray[entry] : -1;
-        mine = (q >= 0) && (P.n_items[q] >= 0);
-        if (q < 0) q = 0;
-        if (mine) packed_voxel = P.sp_items[entry];
-    } else {
-        const int s = blockIdx.y;
-        q = (long long)blockIdx.x * kBlock + threadIdx.x;
-        mine = (q < Q) && (s < min(P.n_items[q], P.C1));  // n_items < 0: ray handed back
-        entry = (long long)s * Q + q;
-        if (mine) packed_voxel = P.items[entry];
-    }
-    if (!__any(mine)) return;
-    CandRec c0, c1, c2;
-    c0.px = c0.py = c0.pz = c0.ts = c0.raw = c0.ext = 0.f;
-    c0.meta = c0.pad = 0;
-    c1 = c0;
-    c2 = c0;
-    int nc = 0;
-    bool overflow = false;
-    if (mine) {
-        Ray r;
-#pragma unroll
-        for (int k = 0; k < 3; ++k) {
-            r.o[k] = origins[3 * q + k];
-            r.d[k] = dirs[3 * q + k];
+    const int n_list = SPILL ? min(P.counters[1], P.sp_cap) : P.counters[kCtrList];
+    const int lane = threadIdx.x & 63;
+    const unsigned wave_id = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+    const int stride = (int)gridDim.x * kBlock;
+    unsigned turn = 0;
+    for (int base = (int)wave_id * 64; base < n_list; base += stride, ++turn) {
+        const int i = base + lane;
+        long long q = 0;
+        long long entry = 0;
+        int packed_voxel = 0;
+        bool mine = i < n_list;
+        if constexpr (SPILL) {
+            entry = i;
+            const int qq = mine ? P.sp_ray[i] : -1;
+            mine = (qq >= 0) && (P.n_items[qq] >= 0);
+            q = (qq >= 0) ? qq : 0;
+            if (mine) packed_voxel = P.sp_items[entry];
+        } else {
+            const unsigned e = mine ? P.list[i] : 0u;
+            q = (long long)(e & ((1u << kListRayBits) - 1u));
+            entry = (long long)(e >> kListRayBits) * Q + q;
+            mine = mine && (P.n_items[q] >= 0);  // < 0: ray handed back to the one-kernel path
+            if (mine) packed_voxel = P.items[entry];
         }
-        setup_ray(g, o, r);
-        Vox v;
-        load_voxel(g, r, packed_voxel, v);
-        bool vox_has_sample = false, vox_has_surf = false;
-        for (int li = 0; li < g.level_set_num; ++li) {  // surf_trav.cu:273-379 up to the sigma gate
-            const float lvf = g.level_set[li];
-            if (lvf < v.smin || lvf > v.smax) continue;
-            vox_has_surf = true;
-            double st[3] = {-1, -1, -1};
-            solve_cubic_vieta(v.fs[0] - (double)lvf, v.fs[1], v.fs[2], v.fs[3], st);
+        CandRec c0, c1, c2;
+        c0.px = c0.py = c0.pz = c0.ts = c0.raw = c0.ext = 0.f;
+        c0.meta = c0.pad = 0;
+        c1 = c0;
+        c2 = c0;
+        int nc = 0;
+        bool overflow = false;
+        if (mine) {
+            Ray r;
 #pragma unroll
-            for (int j = 0; j < 3; ++j) {
-                if (!(st[j] > 0)) continue;
+            for (int k = 0; k < 3; ++k) {
+                r.o[k] = origins[3 * q + k];
+                r.d[k] = dirs[3 * q + k];
+            }
+            setup_ray(g, o, r);
+            Vox v;
+            load_voxel(g, r, packed_voxel, v);
+            bool vox_has_sample = false, vox_has_surf = false;
+            for (int li = 0; li < g.level_set_num; ++li) {  // surf_trav.cu:273-379 up to the sigma gate
+                const float lvf = g.level_set[li];
+                if (lvf < v.smin || lvf > v.smax) continue;
+                vox_has_surf = true;
+                double st[3] = {-1, -1, -1};
+                solve_cubic_vieta(v.fs[0] - (double)lvf, v.fs[1], v.fs[2], v.fs[3], st);
+#pragma unroll
+                for (int j = 0; j < 3; ++j) {
+                    if (!(st[j] > 0)) continue;
+                    float pos[3];
+                    if (!root_position(r, v, st[j], pos)) continue;
+                    vox_has_sample = true;
+                    if (o.only_outward_intersect) {
+                        float sg[3];
+                        field_grad(v.surf, pos, sg);
+                        const float ndd = -(sg[0] * r.d[0] + sg[1] * r.d[1] + sg[2] * r.d[2]);
+                        if (ndd >= 0.f) continue;
+                    }
+                    if (nc < 3) {
+                        CandRec cr;
+                        cr.px = pos[0];
+                        cr.py = pos[1];
+                        cr.pz = pos[2];
+                        cr.ts = (float)((double)v.t_close + st[j]);
+                        cr.raw = trilerp8(v.dens, pos);
+                        cr.ext = 0.f;
+                        cr.meta = (li << 3) | (j << 1);
+                        cr.pad = 0;
+                        cand_put(c0, cr, nc == 0);
+                        cand_put(c1, cr, nc == 1);
+                        cand_put(c2, cr, nc == 2);
+                        ++nc;
+                    } else {
+                        overflow = true;
+                    }
+                }
+            }
+            // fake sample (surf_trav.cu:423-503): everything that does not depend on earlier samples
+            if (o.surf_fake_sample && !vox_has_sample && (!o.limited_fake_sample || vox_has_surf) &&
+                ((v.t_far - v.t_close) > o.surf_fake_sample_min_vox_len)) {
                 float pos[3];
-                if (!root_position(r, v, st[j], pos)) continue;
-                vox_has_sample = true;
-                if (o.only_outward_intersect) {
-                    float sg[3];
-                    field_grad(v.surf, pos, sg);
-                    const float ndd = -(sg[0] * r.d[0] + sg[1] * r.d[1] + sg[2] * r.d[2]);
-                    if (ndd >= 0.f) continue;
-                }
-                if (nc < 3) {
-                    CandRec cr;
-                    cr.px = pos[0];
-                    cr.py = pos[1];
-                    cr.pz = pos[2];
-                    cr.ts = (float)((double)v.t_close + st[j]);
-                    cr.raw = trilerp8(v.dens, pos);
-                    cr.ext = 0.f;
-                    cr.meta = (li << 3) | (j << 1);
-                    cr.pad = 0;
-                    cand_put(c0, cr, nc == 0);
-                    cand_put(c1, cr, nc == 1);
-                    cand_put(c2, cr, nc == 2);
-                    ++nc;
-                } else {
-                    overflow = true;
+                fake_position(r, v, pos);
+                const float raw = trilerp8(v.dens, pos);
+                if (raw > o.sigma_thresh) {
+                    double miu, sd;
+                    c0.px = pos[0];
+                    c0.py = pos[1];
+                    c0.pz = pos[2];
+                    c0.ts = (v.t_far + v.t_close) / 2.f;
+                    c0.raw = raw;
+                    c0.ext = fake_distance(g, o, v, pos, &miu, &sd);
+                    c0.meta = 1;
+                    c0.pad = 0;
+                    nc = 1;
                 }
             }
+            if (overflow) nc = 0;
         }
-        // fake sample (surf_trav.cu:423-503): everything that does not depend on earlier samples
-        if (o.surf_fake_sample && !vox_has_sample && (!o.limited_fake_sample || vox_has_surf) &&
-            ((v.t_far - v.t_close) > o.surf_fake_sample_min_vox_len)) {
-            float pos[3];
-            fake_position(r, v, pos);
-            const float raw = trilerp8(v.dens, pos);
-            if (raw > o.sigma_thresh) {
-                double miu, sd;
-                c0.px = pos[0];
-                c0.py = pos[1];
-                c0.pz = pos[2];
-                c0.ts = (v.t_far + v.t_close) / 2.f;
-                c0.raw = raw;
-                c0.ext = fake_distance(g, o, v, pos, &miu, &sd);
-                c0.meta = 1;
-                c0.pad = 0;
-                nc = 1;
-            }
+        // one pool allocation per wave: exclusive prefix of the lanes' counts + a single atomic
+        int total;
+        const int pre = wave_excl_scan(nc, &total);
+        const int shard = (int)((wave_id + turn * 61u + (SPILL ? 101u : 0u)) % kPoolShards);
+        int base0 = 0;
+        if (total > 0) {
+            if (lane == 0) base0 = atomicAdd(&P.counters[2 + shard], total);
+            base0 = __shfl(base0, 0);
         }
-        if (overflow) nc = 0;
+        if (!mine) continue;
+        int packed = 0;
+        const int rel = base0 + pre;
+        if (overflow || (nc > 0 && rel + nc > P.shard_cap)) {
+            // hand the ray back once (other voxels of it may still run; k_comp ignores the ray)
+            if (atomicExch(&P.n_items[q], -1) >= 0) P.flagged[atomicAdd(&P.counters[0], 1)] = (int)q;
+        } else if (nc > 0) {
+            const int at = shard * P.shard_cap + rel;
+            P.pool[at] = c0;
+            if (nc > 1) P.pool[at + 1] = c1;
+            if (nc > 2) P.pool[at + 2] = c2;
+            packed = (at << 2) | nc;
+        }
+        if constexpr (SPILL) P.sp_citem[entry] = packed;
+        else P.citem[entry] = packed;
     }
-    // one pool allocation per wave: exclusive prefix of the lanes' counts + a single atomic
-    int total;
-    const int pre = wave_excl_scan(nc, &total);
-    const int shard =
-        (int)((blockIdx.x + blockIdx.y * 37u + (threadIdx.x >> 6) * 11u + (SPILL ? 101u : 0u)) % kPoolShards);
-    int base0 = 0;
-    if (total > 0) {
-        if ((threadIdx.x & 63) == 0) base0 = atomicAdd(&P.counters[2 + shard], total);
-        base0 = __shfl(base0, 0);
-    }
-    if (!mine) return;
-    int packed = 0;
-    const int rel = base0 + pre;
-    if (overflow || (nc > 0 && rel + nc > P.shard_cap)) {
-        // hand the ray back once (other voxels of it may still run; k_comp ignores the ray)
-        if (atomicExch(&P.n_items[q], -1) >= 0) P.flagged[atomicAdd(&P.counters[0], 1)] = (int)q;
-    } else if (nc > 0) {
-        const int base = shard * P.shard_cap + rel;
-        P.pool[base] = c0;
-        if (nc > 1) P.pool[base + 1] = c1;
-        if (nc > 2) P.pool[base + 2] = c2;
-        packed = (base << 2) | nc;
-    }
-    if constexpr (SPILL) P.sp_citem[entry] = packed;
-    else P.citem[entry] = packed;
 }
 
 // ------------------------------------------------------------------------------------
