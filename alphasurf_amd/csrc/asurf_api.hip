@@ -444,8 +444,7 @@ int run_backward(const Launch& L, const asurf_rays* rays, const KLoss& loss, con
         hipLaunchKernelGGL(k_bwd_seq, L.ray_grid, dim3(kBlock), 0, L.stream, L.o, loss, L.g.trunc_a, Q,
                            grad_in, color_cache, M, ca, cw, ct, cn, S);
         prof_after("k_bwd_seq", 2, L.stream);
-        const dim3 grid2(L.ray_grid.x, kRecDepth);
-        hipLaunchKernelGGL((k_bwd_sh<B>), grid2, dim3(kBlock), 0, L.stream, L.g, G,
+        hipLaunchKernelGGL((k_bwd_sh<B>), dim3(kListBlocks), dim3(kBlock), 0, L.stream, L.g, G,
                            L.o.no_surf_grad_from_sh ? 0 : 1, rays->dirs, Q, S);
         prof_after("k_bwd_sh", 2, L.stream);
         hipLaunchKernelGGL(k_bwd_geo, dim3(kListBlocks), dim3(kBlock), 0, L.stream, L.g, L.o, loss, G, rays->origins,

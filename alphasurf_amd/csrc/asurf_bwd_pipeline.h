@@ -269,14 +269,19 @@ k_bwd_sh(KGrid g, KGrads G, int want_dpos, const float* __restrict__ dirs, long 
     __shared__ LaneRec s_rec[kBlock];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    const int r = blockIdx.y;
-    const long long q = (long long)blockIdx.x * kBlock + tid;
-    const bool mine = (q < Q) && (r < S.n_eff[q]);
+    const int n_list = *S.n_list;
+    const int wave_id = blockIdx.x * (kBlock / 64) + (tid >> 6);
+  // one dense chunk of 64 list entries per wave and turn (see k_bwd_geo)
+  for (int base = wave_id * 64; base < n_list; base += (int)gridDim.x * kBlock) {
+    const bool mine = base + lane < n_list;
+    const unsigned cell = mine ? S.list[base + lane] : 0u;
+    const long long q = (long long)(cell & ((1u << kListRayBits) - 1u));
+    const int r = (int)(cell >> kListRayBits);
     const unsigned long long need0 = __ballot(mine);
-    if (!need0) return;
-    const size_t idx = (size_t)r * Q + (mine ? q : 0);
+    const size_t idx = (size_t)r * Q + q;
     float pos[3] = {0.f, 0.f, 0.f}, gch[3] = {0.f, 0.f, 0.f};
     bool real = false;
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // the previous turn's readers are done
     if (mine) {
         const int pv = S.v[idx];
         const int vx = pv >> 20, vy = (pv >> 10) & 1023, vz = pv & 1023;
@@ -385,6 +390,7 @@ k_bwd_sh(KGrid g, KGrads G, int want_dpos, const float* __restrict__ dirs, long 
         S.gy[idx] = gy_out;
         S.gz[idx] = gz_out;
     }
+  }
 }
 
 __device__ __forceinline__ void acc8(float* dst, const float* w) {

@@ -89,10 +89,22 @@ __device__ __forceinline__ int bcast_i(int v, int lane) { return __builtin_amdgc
 __device__ __forceinline__ float bcast_f(float v, int lane) {
     return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), lane));
 }
+// Sum over the 64 lanes, returned to every lane.  DPP row shifts + the two row broadcasts leave
+// the total in lane 63 (six VALU adds, no LDS crossbar as __shfl_xor's ds_bpermute would use); a
+// lane whose DPP source is outside its row, or whose row is masked off, adds 0.  All 64 lanes must
+// be active.
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m);
-    return v;
+#define ASURF_DPP_ADD(ctrl, row_mask)                                                                  \
+    v += __builtin_bit_cast(                                                                           \
+        float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), ctrl, row_mask, 0xf, false))
+    ASURF_DPP_ADD(0x111, 0xf);  // row_shr:1
+    ASURF_DPP_ADD(0x112, 0xf);  // row_shr:2
+    ASURF_DPP_ADD(0x114, 0xf);  // row_shr:4
+    ASURF_DPP_ADD(0x118, 0xf);  // row_shr:8  -> lane 15 of every row holds the row's sum
+    ASURF_DPP_ADD(0x142, 0xa);  // row_bcast:15 into rows 1 and 3
+    ASURF_DPP_ADD(0x143, 0xc);  // row_bcast:31 into rows 2 and 3 -> lane 63 holds the total
+#undef ASURF_DPP_ADD
+    return bcast_f(v, 63);
 }
 
 // SH basis at the world-space view direction: render_util.cuh:405-436 (1/4/9 terms);
