@@ -122,7 +122,8 @@ struct Walk {
     // compiler index them in scratch / kernarg memory inside the DDA loop
     float ox, oy, oz, dx, dy, dz, t_leave;
     int lim0, lim1, lim2;
-    int noskip_key;      // brick whose skip attempt failed (walk_skip_brick)
+    int noskip_key;      // brick whose jump attempt was refused (walk_hier)
+    bool straight;       // no direction component is ~0 (brick jumps allowed)
     // register cache of the occupancy pyramid
     int cur_key;         // packed brick coordinates
     int cur_brick;       // linear brick index
@@ -161,6 +162,7 @@ __device__ __forceinline__ void walk_init(const KGrid& g, const Ray& r, Walk& w)
     w.t_far = 0.f;
     w.cur_key = -1;
     w.noskip_key = -1;
+    w.straight = fminf(fminf(fabsf(w.dx), fabsf(w.dy)), fabsf(w.dz)) > 1e-5f;
     w.cur_brick = 0;
     w.cur_flag = 0;
     w.cur_lx = -1;
@@ -257,7 +259,7 @@ __device__ __forceinline__ int walk_hier(const KGrid& g, const unsigned int* lds
         w.cur_flag = (word >> (bz & 31)) & 1u;
         w.cur_lx = -1;
     }
-    const bool jump = allow_jump && !w.cur_flag && (key != w.noskip_key);
+    const bool jump = allow_jump && w.straight && !w.cur_flag && (key != w.noskip_key);
     const int m = jump ? 7 : 0;
     const int sx = w.sx, sy = w.sy, sz = w.sz;
     const int l0 = w.lim0, l1 = w.lim1, l2 = w.lim2;
@@ -284,12 +286,9 @@ __device__ __forceinline__ int walk_hier(const KGrid& g, const unsigned int* lds
         cx = (int)fx;
         cy = (int)fy;
         cz = (int)fz;
-        // the other axes stay inside the brick and never move backwards
-        const bool rx = a0 || (((cx ^ nx) & ~7) == 0 && (cx - nx) * sx >= 0);
-        const bool ry = a1 || (((cy ^ ny) & ~7) == 0 && (cy - ny) * sy >= 0);
-        const bool rz = a2 || (((cz ^ nz) & ~7) == 0 && (cz - nz) * sz >= 0);
-        const bool straight = fminf(fminf(fabsf(dx), fabsf(dy)), fabsf(dz)) > 1e-5f;
-        const bool ok = mx && my && mz && rx && ry && rz && straight && (T <= tmax) && !(T + step_size > tmax);
+        // (with the margins met the other axes are inside the brick and have not moved backwards:
+        // at T the ray is still inside the brick on them, and it is 1/64 away from every plane)
+        const bool ok = mx && my && mz && (T <= tmax) && !(T + step_size > tmax);
         if (!ok) {
             w.noskip_key = key;
             return 0;
