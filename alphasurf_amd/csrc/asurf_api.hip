@@ -18,6 +18,7 @@
 #include "asurf_pipeline.h"
 #include "asurf_bwd_pipeline.h"
 #include "asurf_legacy.h"
+#include "asurf_reg.h"
 
 namespace {
 
@@ -839,6 +840,117 @@ int asurf_ray_voxel_fill(const asurf_grid* grid, const asurf_rays* rays,
                        (long long)rays->n_rays, (int)skip_empty, const_cast<int32_t*>(ray_vox->vox_num),
                        ray_vox->vox_start_i, voxel_ls_out, (long long)ray_vox->n_vox);
     return launch_error("k_voxel_lists<fill>");
+}
+
+// ---- regularisers (asurf_reg.h) ----
+namespace {
+int reg_grid(const int32_t* links, const int32_t size[3], RegGrid& G) {
+    if (!links || !size) return fail(ASURF_E_INVALID, "links / size is NULL");
+    for (int i = 0; i < 3; ++i)
+        if (size[i] < 1) return fail(ASURF_E_INVALID, "links.shape[%d] = %d", i, size[i]);
+    if ((int64_t)size[0] * size[1] * size[2] >= (1ll << 31)) return fail(ASURF_E_INVALID, "links has >= 2^31 elements");
+    G.links = links;
+    for (int i = 0; i < 3; ++i) G.size[i] = size[i];
+    G.offx = size[1] * size[2];
+    G.offy = size[2];
+    return 0;
+}
+unsigned reg_blocks(long long Q) { return (unsigned)((Q + 255) / 256); }
+}  // namespace
+
+int asurf_tv_grad_sparse(const int32_t* links, const int32_t size[3], const float* data, int32_t n_cols,
+                         const int32_t* rand_cells, int64_t n_cells, uint8_t* mask_out,
+                         int32_t start_dim, int32_t end_dim, float scale, int32_t ignore_edge,
+                         int32_t ignore_last_z, float* grad_data, void* stream) {
+    RegGrid G;
+    if (int e = reg_grid(links, size, G)) return e;
+    if (n_cells < 0 || start_dim < 0 || end_dim > n_cols || end_dim <= start_dim)
+        return fail(ASURF_E_INVALID, "tv_grad_sparse: bad n_cells / dim range");
+    if (n_cells == 0) return 0;
+    if (!data || !rand_cells || !grad_data) return fail(ASURF_E_INVALID, "tv_grad_sparse: NULL tensor");
+    const long long Q = (long long)n_cells * (end_dim - start_dim);
+    hipLaunchKernelGGL((k_tv_grad_sparse<false>), dim3(reg_blocks(Q)), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), G, data, (const float*)nullptr, (int)n_cols, 0,
+                       rand_cells, (int)start_dim, (int)end_dim, scale / (float)(int)n_cells, Q,
+                       (int)ignore_edge, 0.f, (int)ignore_last_z, 0, mask_out, grad_data);
+    return launch_error("k_tv_grad_sparse");
+}
+
+int asurf_surf_tv_grad_sparse(const int32_t* links, const int32_t size[3], const float* data,
+                              int32_t n_cols, const float* density_data, int32_t density_cols,
+                              const int32_t* rand_cells, int64_t n_cells, uint8_t* mask_out,
+                              int32_t start_dim, int32_t end_dim, float scale, int32_t ignore_edge,
+                              float edge_value, int32_t ignore_last_z, int32_t alpha_dependency,
+                              float* grad_data, void* stream) {
+    RegGrid G;
+    if (int e = reg_grid(links, size, G)) return e;
+    if (n_cells < 0 || start_dim < 0 || end_dim > n_cols || end_dim <= start_dim)
+        return fail(ASURF_E_INVALID, "surf_tv_grad_sparse: bad n_cells / dim range");
+    if (n_cells == 0) return 0;
+    if (!data || !rand_cells || !grad_data) return fail(ASURF_E_INVALID, "surf_tv_grad_sparse: NULL tensor");
+    if (alpha_dependency && (!density_data || end_dim > density_cols))
+        return fail(ASURF_E_INVALID, "surf_tv_grad_sparse: density_data missing / too narrow");
+    const long long Q = (long long)n_cells * (end_dim - start_dim);
+    hipLaunchKernelGGL((k_tv_grad_sparse<true>), dim3(reg_blocks(Q)), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), G, data, density_data, (int)n_cols,
+                       (int)density_cols, rand_cells, (int)start_dim, (int)end_dim,
+                       scale / (float)(int)n_cells, Q, (int)ignore_edge, edge_value, (int)ignore_last_z,
+                       (int)alpha_dependency, mask_out, grad_data);
+    return launch_error("k_surf_tv_grad_sparse");
+}
+
+int asurf_surface_normal_grad_sparse(const int32_t* links, const int32_t size[3],
+                                     const float* surface_data, const int32_t* rand_cells,
+                                     int64_t n_cells, uint8_t* mask_out, float lv_set, float scale,
+                                     int32_t con_check, int32_t ignore_empty, int32_t use_l1,
+                                     float* grad_data, void* stream) {
+    RegGrid G;
+    if (int e = reg_grid(links, size, G)) return e;
+    if (n_cells < 0) return fail(ASURF_E_INVALID, "surface_normal_grad_sparse: n_cells < 0");
+    if (n_cells == 0) return 0;
+    if (!surface_data || !rand_cells || !grad_data)
+        return fail(ASURF_E_INVALID, "surface_normal_grad_sparse: NULL tensor");
+    hipLaunchKernelGGL(k_surface_normal_grad_sparse, dim3(reg_blocks(n_cells)), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), G, surface_data, rand_cells, lv_set,
+                       scale / (float)(int)n_cells, (long long)n_cells, (int)con_check, (int)ignore_empty,
+                       (int)use_l1, mask_out, grad_data);
+    return launch_error("k_surface_normal_grad_sparse");
+}
+
+int asurf_alpha_surf_sparsify_grad_sparse(const int32_t* links, const int32_t size[3],
+                                          const float* alpha_data, const float* surf_data,
+                                          const int32_t* rand_cells, int64_t n_cells, uint8_t* mask_out,
+                                          float scale_alpha, float scale_surf, int32_t surf_sparse_decrease,
+                                          float surf_sparse_thresh, float alpha_bound, float surf_bound,
+                                          float* grad_alpha, float* grad_surf, void* stream) {
+    RegGrid G;
+    if (int e = reg_grid(links, size, G)) return e;
+    if (n_cells < 0) return fail(ASURF_E_INVALID, "alpha_surf_sparsify_grad_sparse: n_cells < 0");
+    if (n_cells == 0) return 0;
+    if (!alpha_data || !surf_data || !rand_cells || !grad_alpha || !grad_surf)
+        return fail(ASURF_E_INVALID, "alpha_surf_sparsify_grad_sparse: NULL tensor");
+    hipLaunchKernelGGL(k_alpha_surf_sparsify, dim3(reg_blocks(n_cells)), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), G, alpha_data, surf_data, rand_cells, scale_alpha,
+                       scale_surf, (int)surf_sparse_decrease, surf_sparse_thresh, alpha_bound, surf_bound,
+                       (long long)n_cells, mask_out, grad_alpha, grad_surf);
+    return launch_error("k_alpha_surf_sparsify");
+}
+
+int asurf_surface_eikonal_grad_sparse(const int32_t* links, const int32_t size[3],
+                                      const float* surface_data, const int32_t* rand_cells,
+                                      int64_t n_cells, uint8_t* mask_out, float scale, float h,
+                                      float* grad_data, float* loss_out, void* stream) {
+    RegGrid G;
+    if (int e = reg_grid(links, size, G)) return e;
+    if (n_cells < 0 || !(h > 0.f)) return fail(ASURF_E_INVALID, "surface_eikonal_grad_sparse: n_cells < 0 or h <= 0");
+    if (n_cells == 0) return 0;
+    if (!surface_data || !rand_cells || !grad_data)
+        return fail(ASURF_E_INVALID, "surface_eikonal_grad_sparse: NULL tensor");
+    hipLaunchKernelGGL(k_surface_eikonal_grad_sparse, dim3(std::min(reg_blocks(n_cells), 1024u)), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), G, surface_data, rand_cells,
+                       scale / (float)(int)n_cells, 1.f / (h * h), (long long)n_cells, mask_out, grad_data,
+                       loss_out);
+    return launch_error("k_surface_eikonal_grad_sparse");
 }
 
 }  // extern "C"

@@ -1,0 +1,292 @@
+// Per-iteration regularisers of the surface grid: one thread per
+// (listed cell, channel), forward-difference stencils on the link grid, gradients added straight
+// into the parameter gradients with atomics, touched rows marked in mask_out.
+//   k_tv_grad_sparse               loss_kernel.cu:739-808   (TV on raw opacity / any [N,C] plane)
+//   k_surf_tv_grad_sparse          loss_kernel.cu:810-895   (TV on the surface scalar)
+//   k_surface_normal_grad_sparse   loss_kernel.cu:398-436 + render_util.cuh:1823-2130
+//   k_alpha_surf_sparsify          loss_kernel.cu:665-738
+//   k_surface_eikonal_grad_sparse  the reference evaluates this loss with PyTorch autograd
+//                                  (svox2.py:5433-5472); same forward differences, analytic gradient
+// All of them are streaming kernels over rand_cells: HBM-bound, no reuse to stage.
+#pragma once
+#include "asurf_device.h"
+
+namespace asurf {
+
+struct RegGrid {
+    const int32_t* __restrict__ links;
+    int size[3];
+    int offx, offy;
+};
+
+__device__ __forceinline__ void reg_decode(const RegGrid& G, int xyz, int& x, int& y, int& z) {
+    z = xyz % G.size[2];
+    const int xy = xyz / G.size[2];
+    y = xy % G.size[1];
+    x = xy / G.size[1];
+}
+
+__device__ __forceinline__ void reg_add(float* grad, uint8_t* mask, int lnk, int C, int idx, float val,
+                                        float idelta) {
+    if (lnk >= 0 && val != 0.f) {
+        atomicAdd(&grad[(size_t)lnk * C + idx], val * idelta);
+        if (mask != nullptr) mask[lnk] = 1;
+    }
+}
+
+// SURF = false: tv_grad_sparse_kernel; SURF = true: surf_tv_grad_sparse_kernel (edge_value for
+// missing neighbours, optional boost where all four raw opacities are low).
+template <bool SURF>
+__global__ void __launch_bounds__(256)
+k_tv_grad_sparse(RegGrid G, const float* __restrict__ data, const float* __restrict__ density, int C,
+                 int density_C, const int32_t* __restrict__ rand_cells, int start_dim, int end_dim,
+                 float scale, long long Q, int ignore_edge, float edge_value, int ignore_last_z,
+                 int alpha_dependency, uint8_t* __restrict__ mask_out, float* __restrict__ grad_data) {
+    const long long tid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (tid >= Q) return;
+    const int nd = end_dim - start_dim;
+    const int idx = (int)(tid % nd) + start_dim;
+    int x, y, z;
+    reg_decode(G, rand_cells[tid / nd], x, y, z);
+    const int32_t* lp = G.links + ((size_t)x * G.offx + (size_t)y * G.offy + z);
+    if (ignore_edge && *lp == 0) return;
+    const float sc0 = G.size[0] * (1.f / 256.f), sc1 = G.size[1] * (1.f / 256.f),
+                sc2 = G.size[2] * (1.f / 256.f);  // calculate_ray_scale, :23-59
+    // a neighbour outside the grid counts as link 0, as in the reference (:765-770)
+    const int l000 = lp[0];
+    const int l001 = ((z + 1 < G.size[2]) && (!ignore_last_z || z != G.size[2] - 2)) ? lp[1] : 0;
+    const int l010 = (y + 1 < G.size[1]) ? lp[G.offy] : 0;
+    const int l100 = (x + 1 < G.size[0]) ? lp[G.offx] : 0;
+    if (ignore_last_z && z == G.size[2] - 2) return;
+    const float dflt = SURF ? edge_value : 0.f;
+    const float v000 = l000 >= 0 ? data[(size_t)l000 * C + idx] : dflt;
+    const float null_val = ignore_edge ? v000 : dflt;
+    const float v001 = l001 >= 0 ? data[(size_t)l001 * C + idx] : null_val;
+    const float v010 = l010 >= 0 ? data[(size_t)l010 * C + idx] : null_val;
+    const float v100 = l100 >= 0 ? data[(size_t)l100 * C + idx] : null_val;
+    float dx = v100 - v000, dy = v010 - v000, dz = v001 - v000;
+    float idelta = scale * rsqrtf(1e-9f + dx * dx + dy * dy + dz * dz);
+    if constexpr (SURF) {
+        if (alpha_dependency) {  // :866-875
+            const float a0 = l000 >= 0 ? density[(size_t)l000 * density_C + idx] : 0.f;
+            const float a1 = l001 >= 0 ? density[(size_t)l001 * density_C + idx] : 0.f;
+            const float a2 = l010 >= 0 ? density[(size_t)l010 * density_C + idx] : 0.f;
+            const float a3 = l100 >= 0 ? density[(size_t)l100 * density_C + idx] : 0.f;
+            const float mx = fmaxf(a0, fmaxf(a1, fmaxf(a2, a3)));
+            if (mx < 0.1f) idelta /= fmaxf(mx * 10, 1e-1f);
+        }
+    }
+    dx *= sc0;
+    dy *= sc1;
+    dz *= sc2;
+    reg_add(grad_data, mask_out, l000, C, idx, -(dx + dy + dz), idelta);
+    reg_add(grad_data, mask_out, l001, C, idx, dz, idelta);
+    reg_add(grad_data, mask_out, l010, C, idx, dy, idelta);
+    reg_add(grad_data, mask_out, l100, C, idx, dx, idelta);
+}
+
+// ---- surface normal smoothness -------------------------------------------------------------
+struct RegCell {  // the 8 corner rows of a cell and their surface values
+    int lk[8];
+    float s[8];
+    bool exist;
+};
+
+__device__ __forceinline__ void reg_cell(const RegGrid& G, const float* __restrict__ surface, int x, int y,
+                                         int z, RegCell& c) {
+    c.exist = (x < G.size[0] - 1) && (y < G.size[1] - 1) && (z < G.size[2] - 1);
+    if (!c.exist) return;
+    const int32_t* p = G.links + ((size_t)x * G.offx + (size_t)y * G.offy + z);
+    c.lk[0] = p[0];
+    c.lk[1] = p[1];
+    c.lk[2] = p[G.offy];
+    c.lk[3] = p[G.offy + 1];
+    c.lk[4] = p[G.offx];
+    c.lk[5] = p[G.offx + 1];
+    c.lk[6] = p[G.offx + G.offy];
+    c.lk[7] = p[G.offx + G.offy + 1];
+    int any = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) any |= c.lk[i];
+    c.exist = any >= 0;
+    if (!c.exist) return;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) c.s[i] = surface[c.lk[i]];
+}
+
+// unnormalised normal: mean forward difference over the cell's faces (__CALC_DX/DY/DZ)
+__device__ __forceinline__ void reg_normal(const RegCell& c, float* n) {
+    n[0] = ((c.s[4] + c.s[5] + c.s[6] + c.s[7]) - (c.s[0] + c.s[1] + c.s[2] + c.s[3])) / 4;
+    n[1] = ((c.s[2] + c.s[3] + c.s[6] + c.s[7]) - (c.s[0] + c.s[1] + c.s[4] + c.s[5])) / 4;
+    n[2] = ((c.s[1] + c.s[3] + c.s[5] + c.s[7]) - (c.s[0] + c.s[2] + c.s[4] + c.s[6])) / 4;
+}
+
+__device__ __forceinline__ bool reg_all_one_side(const float* s, int n, float lv) {
+    bool le = true, ge = true;
+    for (int i = 0; i < n; ++i) {
+        le = le && (s[i] <= lv);
+        ge = ge && (s[i] >= lv);
+    }
+    return le || ge;
+}
+
+// d(normal component a) / d(corner): +-1/4 by the corner's bit on that axis (_split_add_surface_norm_grad)
+__device__ __forceinline__ void reg_split_add(const RegCell& c, const float* gn, float scale,
+                                              uint8_t* mask, float* grad) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const float g = ((i & 4) ? 0.25f : -0.25f) * gn[0] + ((i & 2) ? 0.25f : -0.25f) * gn[1] +
+                        ((i & 1) ? 0.25f : -0.25f) * gn[2];
+        const float val = scale * g;
+        if (val != 0.f) {
+            atomicAdd(&grad[c.lk[i]], val);
+            if (mask != nullptr) mask[c.lk[i]] = 1;
+        }
+    }
+}
+
+__global__ void __launch_bounds__(256)
+k_surface_normal_grad_sparse(RegGrid G, const float* __restrict__ surface,
+                             const int32_t* __restrict__ rand_cells, float lv_set, float scale, long long Q,
+                             int con_check, int ignore_empty, int use_l1, uint8_t* __restrict__ mask_out,
+                             float* __restrict__ grad_data) {
+    const long long tid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (tid >= Q) return;
+    int x, y, z;
+    reg_decode(G, rand_cells[tid], x, y, z);
+    RegCell c0;
+    reg_cell(G, surface, x, y, z, c0);
+    if (!c0.exist) return;
+    const bool empty0 = ignore_empty ? reg_all_one_side(c0.s, 8, lv_set) : false;
+    float n0[3];
+    reg_normal(c0, n0);
+    // neighbours along x (i = 0), y (1), z (2); the face shared with c0 decides connectivity
+    RegCell cn[3];
+    bool use[3];
+    int count = 0;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        reg_cell(G, surface, x + (i == 0), y + (i == 1), z + (i == 2), cn[i]);
+        bool ok = cn[i].exist;
+        if (ok && con_check) {
+            const int bit = 4 >> i;  // corners of cn[i] on its low face along axis i
+            float f[4];
+            int k = 0;
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                if (!(j & bit)) f[k++] = cn[i].s[j];
+            ok = !reg_all_one_side(f, 4, lv_set);
+        }
+        if (ok && ignore_empty) ok = !empty0 || !reg_all_one_side(cn[i].s, 8, lv_set);
+        use[i] = ok;
+        count += ok ? 1 : 0;
+    }
+    if (count == 0) return;
+    const float N0 = sqrtf(1e-9f + n0[0] * n0[0] + n0[1] * n0[1] + n0[2] * n0[2]);  // _NORM3
+    const float sc = scale * 1.f / count;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        if (!use[i]) continue;
+        float n1[3];
+        reg_normal(cn[i], n1);
+        const float N1 = sqrtf(1e-9f + n1[0] * n1[0] + n1[1] * n1[1] + n1[2] * n1[2]);
+        float w[3];  // dLoss / d(L_b), L = n0/N0 - n1/N1
+#pragma unroll
+        for (int b = 0; b < 3; ++b) {
+            const float L = n0[b] / N0 - n1[b] / N1;
+            w[b] = use_l1 ? ((L > 0.f) ? 1.f : (L == 0.f ? 0.f : -1.f)) : 2.f * L;
+        }
+        float d0[3], d1[3];
+        const float i0 = 1.f / (N0 * N0 * N0), i1 = 1.f / (N1 * N1 * N1);
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+            for (int b = 0; b < 3; ++b) {
+                s0 += w[b] * (((a == b) ? 1.f / N0 : 0.f) - n0[a] * n0[b] * i0);
+                s1 += w[b] * (((a == b) ? -1.f / N1 : 0.f) + n1[a] * n1[b] * i1);
+            }
+            d0[a] = s0;
+            d1[a] = s1;
+        }
+        reg_split_add(c0, d0, sc, mask_out, grad_data);
+        reg_split_add(cn[i], d1, sc, mask_out, grad_data);
+    }
+}
+
+// ---- log-alpha / surface sparsification, loss_kernel.cu:665-738 ------------------------------
+__global__ void __launch_bounds__(256)
+k_alpha_surf_sparsify(RegGrid G, const float* __restrict__ alpha, const float* __restrict__ surf,
+                      const int32_t* __restrict__ rand_cells, float scale_alpha, float scale_surf,
+                      int surf_decrease, float surf_thresh, float alpha_bound, float surf_bound, long long Q,
+                      uint8_t* __restrict__ mask_out, float* __restrict__ grad_alpha,
+                      float* __restrict__ grad_surf) {
+    const long long tid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (tid >= Q) return;
+    int x, y, z;
+    reg_decode(G, rand_cells[tid], x, y, z);
+    const int l = G.links[(size_t)x * G.offx + (size_t)y * G.offy + z];
+    if (l < 0) return;
+    if (mask_out != nullptr) mask_out[l] = 1;
+    const float a = alpha[l];
+    const float safe = 1.f / fmaxf(a, 1e-8f);
+    if (a > alpha_bound) atomicAdd(&grad_alpha[l], scale_alpha * safe);
+    const float s = surf[l];
+    const bool reg = surf_decrease ? (s > surf_bound) : (s < surf_bound);
+    if (reg && a < surf_thresh) atomicAdd(&grad_surf[l], surf_decrease ? (scale_surf * safe) : (-scale_surf * safe));
+}
+
+// ---- eikonal: scaling / n_cells * sum (1 - |forward difference / h|^2)^2, svox2.py:5433-5472 ---
+__global__ void __launch_bounds__(256)
+k_surface_eikonal_grad_sparse(RegGrid G, const float* __restrict__ surface,
+                              const int32_t* __restrict__ rand_cells, float scale, float inv_h2, long long Q,
+                              uint8_t* __restrict__ mask_out, float* __restrict__ grad_data,
+                              float* __restrict__ loss_out) {
+    float loss = 0.f;
+    // grid-stride: the loss is reduced per block and added with ONE atomic per block (a single
+    // address serialises its atomics; one per wave of a 1.3 M-cell launch costs more than the kernel)
+    for (long long tid = (long long)blockIdx.x * blockDim.x + threadIdx.x; tid < Q;
+         tid += (long long)gridDim.x * blockDim.x) {
+        int x, y, z;
+        reg_decode(G, rand_cells[tid], x, y, z);
+        const int32_t* lp = G.links + ((size_t)x * G.offx + (size_t)y * G.offy + z);
+        const int l000 = lp[0];
+        if (l000 >= 0) {
+            // a missing neighbour takes the centre value: zero difference, no gradient
+            const int l100 = (x + 1 < G.size[0]) ? lp[G.offx] : -1;
+            const int l010 = (y + 1 < G.size[1]) ? lp[G.offy] : -1;
+            const int l001 = (z + 1 < G.size[2]) ? lp[1] : -1;
+            const float s0 = surface[l000];
+            const float dx = (l100 >= 0 ? surface[l100] : s0) - s0;
+            const float dy = (l010 >= 0 ? surface[l010] : s0) - s0;
+            const float dz = (l001 >= 0 ? surface[l001] : s0) - s0;
+            const float g2 = (dx * dx + dy * dy + dz * dz) * inv_h2;
+            loss += scale * (1.f - g2) * (1.f - g2);
+            const float k = -4.f * scale * (1.f - g2) * inv_h2;  // d loss / d(difference) / difference
+            const float gx = k * dx, gy = k * dy, gz = k * dz;
+            if (gx != 0.f) atomicAdd(&grad_data[l100], gx);
+            if (gy != 0.f) atomicAdd(&grad_data[l010], gy);
+            if (gz != 0.f) atomicAdd(&grad_data[l001], gz);
+            const float gc = -(gx + gy + gz);
+            if (gc != 0.f) atomicAdd(&grad_data[l000], gc);
+            if (mask_out != nullptr) {
+                mask_out[l000] = 1;
+                if (gx != 0.f) mask_out[l100] = 1;
+                if (gy != 0.f) mask_out[l010] = 1;
+                if (gz != 0.f) mask_out[l001] = 1;
+            }
+        }
+    }
+    if (loss_out != nullptr) {
+        __shared__ float s_part[256 / 64];
+        const float tot = wave_sum(loss);
+        if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6] = tot;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const float b = (s_part[0] + s_part[1]) + (s_part[2] + s_part[3]);
+            if (b != 0.f) atomicAdd(loss_out, b);
+        }
+    }
+}
+
+}  // namespace asurf

@@ -19,7 +19,8 @@ __all__ = [
     "SparseGridSpec", "CameraSpec", "RaysSpec", "RayVoxIntersecSpec", "RenderOptions",
     "GridOutputGrads", "volume_render_surf_trav", "volume_render_surf_trav_backward",
     "volume_render_surf_trav_fused", "volume_render_surface", "volume_render_surface_backward",
-    "ray_voxel_lists",
+    "ray_voxel_lists", "tv_grad_sparse", "surf_tv_grad_sparse", "surface_normal_grad_sparse",
+    "alpha_surf_sparsify_grad_sparse", "surface_eikonal_grad_sparse",
     "volume_render_surface_fused", "test_cubic_root_grad", "sample_grid", "rmsprop_step", "sgd_step",
 ]
 
@@ -479,6 +480,126 @@ def sgd_step(data, grad, indexer, lr, lr_last):
     with torch.cuda.device(data.device):
         _L.check(_L.lib().asurf_sgd_step(_ptr(data), _ptr(grad), data.shape[0], data.shape[1], mask, idx,
                                          n_idx, float(lr), float(lr_last), _stream(data.device)))
+
+
+# ---- per-iteration regularisers (loss_kernel.cu) ----
+def _mask_ptr(mask_out):
+    """The reference passes an empty tensor for "no indexer" (svox2.py:6295-6299)."""
+    if mask_out is None or mask_out.numel() == 0:
+        return None
+    _check_input(mask_out, "mask_out", torch.bool)
+    return _ptr(mask_out)
+
+
+def _links_args(links):
+    _check_input(links, "links", torch.int32)
+    if links.dim() != 3:
+        raise RuntimeError("links must be 3-D")
+    return _ptr(links), (C.c_int32 * 3)(*links.shape)
+
+
+def _check_cells(rand_cells):
+    _check_input(rand_cells, "rand_cells", torch.int32)
+    if rand_cells.dim() != 1:
+        raise RuntimeError("rand_cells must be 1-D")
+
+
+def tv_grad_sparse(links, data, rand_cells, mask_out, start_dim, end_dim, scale, use_logalpha,
+                   logalpha_delta, ignore_edge, ignore_last_z, ndc_coeffx, ndc_coeffy, grad_data):
+    """void tv_grad_sparse(...) -- loss_kernel.cu:1327-1373 (ndc coefficients are unused there too)."""
+    if use_logalpha:
+        raise RuntimeError("tv_grad_sparse: logalpha is no longer supported (svox2.py:4966)")
+    lp, size = _links_args(links)
+    _check_input(data, "data", torch.float32)
+    _check_input(grad_data, "grad_data", torch.float32)
+    _check_cells(rand_cells)
+    if data.dim() != 2 or grad_data.shape != data.shape:
+        raise RuntimeError("data / grad_data must be 2-D and of equal shape")
+    dev = data.device
+    with torch.cuda.device(dev):
+        _L.check(_L.lib().asurf_tv_grad_sparse(lp, size, _ptr(data), data.shape[1], _ptr(rand_cells),
+                                               rand_cells.shape[0], _mask_ptr(mask_out), int(start_dim),
+                                               int(end_dim), float(scale), int(bool(ignore_edge)),
+                                               int(bool(ignore_last_z)), _ptr(grad_data), _stream(dev)))
+
+
+def surf_tv_grad_sparse(links, data, density_data, rand_cells, mask_out, start_dim, end_dim, scale,
+                        ignore_edge, edge_value, ignore_last_z, ndc_coeffx, ndc_coeffy, alpha_dependency,
+                        grad_data):
+    """void surf_tv_grad_sparse(...) -- loss_kernel.cu:1375-1427."""
+    lp, size = _links_args(links)
+    _check_input(data, "data", torch.float32)
+    _check_input(density_data, "density_data", torch.float32)
+    _check_input(grad_data, "grad_data", torch.float32)
+    _check_cells(rand_cells)
+    if data.dim() != 2 or grad_data.shape != data.shape or density_data.dim() != 2:
+        raise RuntimeError("data / density_data / grad_data must be 2-D")
+    dev = data.device
+    with torch.cuda.device(dev):
+        _L.check(_L.lib().asurf_surf_tv_grad_sparse(
+            lp, size, _ptr(data), data.shape[1], _ptr(density_data), density_data.shape[1],
+            _ptr(rand_cells), rand_cells.shape[0], _mask_ptr(mask_out), int(start_dim), int(end_dim),
+            float(scale), int(bool(ignore_edge)), float(edge_value), int(bool(ignore_last_z)),
+            int(bool(alpha_dependency)), _ptr(grad_data), _stream(dev)))
+
+
+def surface_normal_grad_sparse(links, data, rand_cells, mask_out, lv_set, start_dim, end_dim, scale,
+                               eikonal_scale, ndc_coeffx, ndc_coeffy, con_check, ignore_empty, use_l1,
+                               grad_data):
+    """void surface_normal_grad_sparse(...) -- loss_kernel.cu:1572-1622 (the kernel works on column 0
+    of an [N,1] plane whatever start_dim/end_dim say, render_util.cuh:1889-1890; eikonal_scale is
+    accepted and ignored there)."""
+    lp, size = _links_args(links)
+    _check_input(data, "data", torch.float32)
+    _check_input(grad_data, "grad_data", torch.float32)
+    _check_cells(rand_cells)
+    if data.dim() != 2 or data.shape[1] != 1 or grad_data.shape != data.shape:
+        raise RuntimeError("surface data / grad must be [N,1]")
+    dev = data.device
+    with torch.cuda.device(dev):
+        _L.check(_L.lib().asurf_surface_normal_grad_sparse(
+            lp, size, _ptr(data), _ptr(rand_cells), rand_cells.shape[0], _mask_ptr(mask_out), float(lv_set),
+            float(scale), int(bool(con_check)), int(bool(ignore_empty)), int(bool(use_l1)), _ptr(grad_data),
+            _stream(dev)))
+
+
+def alpha_surf_sparsify_grad_sparse(links, alpha_data, surf_data, rand_cells, mask_out, scale_alpha,
+                                    scale_surf, surf_sparse_decrease, surf_sparse_thresh, alpha_bound,
+                                    surf_bound, grad_alpha, grad_surf):
+    """void alpha_surf_sparsify_grad_sparse(...) -- loss_kernel.cu:1512-1570."""
+    lp, size = _links_args(links)
+    for t, nm in ((alpha_data, "alpha_data"), (surf_data, "surf_data"), (grad_alpha, "grad_alpha"),
+                  (grad_surf, "grad_surf")):
+        _check_input(t, nm, torch.float32)
+        if t.dim() != 2 or t.shape[1] != 1:
+            raise RuntimeError(f"{nm} must be [N,1]")
+    _check_cells(rand_cells)
+    dev = alpha_data.device
+    with torch.cuda.device(dev):
+        _L.check(_L.lib().asurf_alpha_surf_sparsify_grad_sparse(
+            lp, size, _ptr(alpha_data), _ptr(surf_data), _ptr(rand_cells), rand_cells.shape[0],
+            _mask_ptr(mask_out), float(scale_alpha), float(scale_surf), int(bool(surf_sparse_decrease)),
+            float(surf_sparse_thresh), float(alpha_bound), float(surf_bound), _ptr(grad_alpha),
+            _ptr(grad_surf), _stream(dev)))
+
+
+def surface_eikonal_grad_sparse(links, data, rand_cells, mask_out, scale, h, grad_data):
+    """Eikonal loss scale / n * sum (1 - |forward difference / h|^2)^2 and its gradient.  Not a
+    reference binding: the reference evaluates it with autograd (svox2.py:5433-5472) and its kernel
+    branch raises NotImplementedError (:5753-5766).  Returns the loss as a 0-dim device tensor."""
+    lp, size = _links_args(links)
+    _check_input(data, "data", torch.float32)
+    _check_input(grad_data, "grad_data", torch.float32)
+    _check_cells(rand_cells)
+    if data.dim() != 2 or data.shape[1] != 1 or grad_data.shape != data.shape:
+        raise RuntimeError("surface data / grad must be [N,1]")
+    dev = data.device
+    with torch.cuda.device(dev):
+        loss = torch.zeros((), dtype=torch.float32, device=dev)
+        _L.check(_L.lib().asurf_surface_eikonal_grad_sparse(
+            lp, size, _ptr(data), _ptr(rand_cells), rand_cells.shape[0], _mask_ptr(mask_out), float(scale),
+            float(h), _ptr(grad_data), _ptr(loss), _stream(dev)))
+    return loss
 
 
 def sample_grid(*args, **kwargs):

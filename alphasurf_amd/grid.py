@@ -488,6 +488,159 @@ class SparseGrid(nn.Module):
                  for s in range(0, camera.height * camera.width, batch_size)]
         return torch.cat(parts, dim=0).view(camera.height, camera.width, -1)
 
+    # ---- per-iteration regularisers (:4947-5165, 5686-5766 -> loss_kernel.cu) ----
+    def _get_sparse_grad_indexer(self):
+        """:6295-6299"""
+        if self.sparse_grad_indexer is None:
+            return torch.empty((0,), dtype=torch.bool, device=self.density_data.device)
+        return self.sparse_grad_indexer
+
+    def _get_sparse_sh_grad_indexer(self):
+        if self.sparse_sh_grad_indexer is None:
+            return torch.empty((0,), dtype=torch.bool, device=self.density_data.device)
+        return self.sparse_sh_grad_indexer
+
+    def _get_h(self):
+        """:3228-3232"""
+        return 2.0 * float(self.radius.mean()) / float(self._grid_size().mean())
+
+    def _get_rand_cells(self, sparse_frac: float, force: bool = False, contiguous: bool = True):
+        """:6335-6352: a random (contiguous, wrapping) block of flat cell indices, or None = all cells."""
+        if sparse_frac < 1.0 or force:
+            assert self.sparse_grad_indexer is None or self.sparse_grad_indexer.dtype == torch.bool, \
+                "please call sparse loss after rendering and before gradient updates"
+            grid_size = self.links.numel()
+            sparse_num = max(int(sparse_frac * grid_size), 1)
+            if contiguous:
+                start = np.random.randint(0, grid_size)
+                arr = torch.arange(start, start + sparse_num, dtype=torch.int32, device=self.links.device)
+                if start > grid_size - sparse_num:
+                    arr[grid_size - sparse_num - start:] -= grid_size
+                return arr
+            return torch.randint(0, grid_size, (sparse_num,), dtype=torch.int32, device=self.links.device)
+        return None
+
+    def _get_rand_cells_non_empty(self, sparse_frac: float, frac_of_remaining: bool = True,
+                                  contiguous: bool = True):
+        """:6354-6376: the same over the cells whose first corner exists."""
+        grid_size = self.links.numel()
+        non_empty_ids = torch.where(self.links.view(-1) >= 0)[0].int()
+        if sparse_frac >= 1.0:
+            return non_empty_ids
+        non_empty_num = len(non_empty_ids)
+        if frac_of_remaining:
+            sparse_num = int(non_empty_num * sparse_frac)
+        else:
+            sparse_num = min(int(sparse_frac * grid_size), int(non_empty_num))
+        if contiguous:
+            start = np.random.randint(0, non_empty_num - sparse_num + 1)
+            return non_empty_ids[start:start + sparse_num].contiguous()
+        return non_empty_ids[torch.randint(0, non_empty_num, (sparse_num,), dtype=torch.long,
+                                           device=self.links.device)]
+
+    def _get_data_to_links(self):
+        """:6378-6382"""
+        d2l = getattr(self, "_data_to_links", None)
+        if d2l is None or d2l.numel() != self.density_data.numel():
+            d2l = torch.arange(self.links.numel(), dtype=torch.int, device=self.links.device)[self.links.view(-1) >= 0]
+            self._data_to_links = d2l
+        return d2l
+
+    def inplace_tv_grad(self, grad: torch.Tensor, scaling: float = 1.0, sparse_frac: float = 0.01,
+                        logalpha: bool = False, logalpha_delta: float = 2.0, ndc_coeffs=(-1.0, -1.0),
+                        contiguous: bool = True):
+        """TV of the raw opacity added into `grad` (:4947-4987)."""
+        assert self.density_data.is_cuda and grad.is_cuda, "the HIP extension is required for total variation"
+        assert not logalpha, "No longer supported"
+        rand_cells = self._get_rand_cells(sparse_frac, contiguous=contiguous)
+        if rand_cells is None:
+            _next_row("N2", "dense tv_grad (sparse_frac >= 1)")
+        if rand_cells.size(0) > 0:
+            _C.tv_grad_sparse(self.links, self.density_data, rand_cells, self._get_sparse_grad_indexer(), 0, 1,
+                              scaling, logalpha, logalpha_delta, False, self.opt.last_sample_opaque,
+                              ndc_coeffs[0], ndc_coeffs[1], grad)
+
+    def inplace_tv_color_grad(self, grad: torch.Tensor, start_dim: int = 0, end_dim: Optional[int] = None,
+                              scaling: float = 1.0, sparse_frac: float = 0.01, logalpha: bool = False,
+                              logalpha_delta: float = 2.0, ndc_coeffs=(-1.0, -1.0), contiguous: bool = True):
+        """TV of SH coefficients [start_dim, end_dim) added into `grad` (:5768-5825)."""
+        assert self.sh_data.is_cuda and grad.is_cuda, "the HIP extension is required for total variation"
+        assert not logalpha, "No longer supported"
+        n = self.sh_data.size(1)
+        end_dim = n if end_dim is None else (end_dim + n if end_dim < 0 else end_dim)
+        start_dim = start_dim + n if start_dim < 0 else start_dim
+        rand_cells = self._get_rand_cells(sparse_frac, contiguous=contiguous)
+        if rand_cells is None:
+            _next_row("N2", "dense tv_grad (sparse_frac >= 1)")
+        if rand_cells.size(0) > 0:
+            _C.tv_grad_sparse(self.links, self.sh_data, rand_cells, self._get_sparse_sh_grad_indexer(),
+                              start_dim, end_dim, scaling, logalpha, logalpha_delta, True, False,
+                              ndc_coeffs[0], ndc_coeffs[1], grad)
+
+    def inplace_tv_surface_grad(self, grad: torch.Tensor, scaling: float = 1.0, sparse_frac: float = 0.01,
+                                ndc_coeffs=(-1.0, -1.0), alpha_dependency: bool = True,
+                                ignore_edge: bool = True, edge_value: float = -1.0, contiguous: bool = True):
+        """TV of the surface scalar added into `grad` (:5121-5163)."""
+        assert self.surface_data.is_cuda and grad.is_cuda, "the HIP extension is required for total variation"
+        rand_cells = self._get_rand_cells_non_empty(sparse_frac, contiguous=contiguous)
+        if rand_cells.size(0) > 0:
+            _C.surf_tv_grad_sparse(self.links, self.surface_data, self.density_data, rand_cells,
+                                   self._get_sparse_grad_indexer(), 0, 1, scaling, ignore_edge, edge_value,
+                                   False, ndc_coeffs[0], ndc_coeffs[1], alpha_dependency, grad)
+
+    def inplace_surface_normal_grad(self, grad: torch.Tensor, scaling: float = 1.0, sparse_frac: float = 0.01,
+                                    ndc_coeffs=(-1.0, -1.0), contiguous: bool = True, use_kernel: bool = True,
+                                    connectivity_check: bool = True, ignore_empty: bool = False,
+                                    use_l1: bool = False, **kwargs):
+        """Smoothness of the surface normal between neighbouring cells (:5686-5731)."""
+        if self.surface_data is None:
+            return
+        if not use_kernel:
+            raise NotImplementedError("the PyTorch debugging path is not part of this build (no CPU fallback)")
+        assert self.surface_data.is_cuda and grad.is_cuda, "the HIP extension is required"
+        rand_cells = self._get_rand_cells_non_empty(sparse_frac, contiguous=contiguous)
+        if rand_cells.size(0) > 0:
+            _C.surface_normal_grad_sparse(self.links, self.surface_data, rand_cells,
+                                          self._get_sparse_grad_indexer(), 0.0, 0, 1, scaling, 0.0,
+                                          ndc_coeffs[0], ndc_coeffs[1], connectivity_check, ignore_empty,
+                                          use_l1, grad)
+
+    def inplace_surface_eikonal_grad(self, grad: torch.Tensor, scaling: float = 1.0, sparse_frac: float = 0.01,
+                                     contiguous: bool = True, use_kernel: bool = True, **kwargs):
+        """Eikonal loss; returns its value (:5733-5766).  The reference runs it through autograd
+        (`use_kernel=False`, opt.py:1004-1009), which accumulates into surface_data.grad and leaves the
+        sparse indexer alone; so does this (whatever `use_kernel` says: there is one implementation)."""
+        if self.surface_data is None:
+            return
+        rand_cells = self._get_rand_cells_non_empty(sparse_frac, contiguous=contiguous)
+        target = self._get_data_grads()["surface_data"]
+        if rand_cells.size(0) == 0:
+            return torch.zeros((), device=self.surface_data.device)
+        return _C.surface_eikonal_grad_sparse(self.links, self.surface_data, rand_cells, None, scaling,
+                                              self._get_h(), target)
+
+    def inplace_alpha_surf_sparsify_grad(self, grad_alpha: torch.Tensor, grad_surf: torch.Tensor,
+                                         scaling_alpha: float = 1.0, scaling_surf: float = 1.0,
+                                         sparse_frac: float = 0.01, surf_sparse_decrease: bool = True,
+                                         surf_sparse_thresh: float = 0.01, alpha_sparsify_bound: float = 1e-6,
+                                         surf_sparsify_bound: float = -1, only_trained_cells: bool = False,
+                                         trained_cells_mask: torch.Tensor = None, contiguous: bool = True):
+        """log-alpha / surface sparsification (:5053-5119)."""
+        assert self.density_data.is_cuda, "the HIP extension is required"
+        if only_trained_cells:
+            rand_cells = self._get_data_to_links()[trained_cells_mask].to(self.density_data.device)
+        else:
+            rand_cells = self._get_rand_cells_non_empty(sparse_frac, contiguous=contiguous)
+        if self.opt.alpha_activation_type == CONSTANTS["SIGMOID_FN"]:
+            surf_sparse_thresh = float(np.log(surf_sparse_thresh / (1.0 - surf_sparse_thresh)))
+            alpha_sparsify_bound = float(np.log(alpha_sparsify_bound / (1.0 - alpha_sparsify_bound)))
+        if rand_cells.size(0) > 0:
+            _C.alpha_surf_sparsify_grad_sparse(self.links, self.density_data, self.surface_data,
+                                               rand_cells.contiguous(), self._get_sparse_grad_indexer(),
+                                               scaling_alpha, scaling_surf, surf_sparse_decrease,
+                                               surf_sparse_thresh, alpha_sparsify_bound, surf_sparsify_bound,
+                                               grad_alpha, grad_surf)
+
     # ---- optimizers (:5972-6140 -> optim_kernel.cu:14-265) ----
     def _maybe_convert_sparse_grad_indexer(self, sh=False, bg=False):
         """Mask -> index list when under 1/8 of the rows were touched (:6314-6333)."""
@@ -592,6 +745,8 @@ def _add_next_rows():
     }
     for row, names in rows.items():
         for name in names:
+            if name in SparseGrid.__dict__:
+                continue  # built
             def stub(self, *a, _n=name, _r=row, **k):
                 _next_row(_r, f"SparseGrid.{_n}")
             stub.__name__ = name

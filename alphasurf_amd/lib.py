@@ -88,6 +88,8 @@ EXPORTS = [
     "asurf_test_cubic_root_grad", "asurf_profile_enable", "asurf_profile_read",
     "asurf_profile_read_spans",
     "asurf_rmsprop_step", "asurf_sgd_step", "asurf_ray_voxel_count", "asurf_ray_voxel_fill",
+    "asurf_tv_grad_sparse", "asurf_surf_tv_grad_sparse", "asurf_surface_normal_grad_sparse",
+    "asurf_alpha_surf_sparsify_grad_sparse", "asurf_surface_eikonal_grad_sparse",
 ]
 
 _lib = None
@@ -125,6 +127,14 @@ def lib():
         L.asurf_sgd_step.argtypes = [vp, vp, C.c_int64, C.c_int32, vp, vp, C.c_int64, fl, fl, vp]
         L.asurf_ray_voxel_count.argtypes = [vp, vp, vp, C.c_int32, vp, vp]
         L.asurf_ray_voxel_fill.argtypes = [vp, vp, vp, C.c_int32, vp, vp, vp]
+        i32, i64 = C.c_int32, C.c_int64
+        L.asurf_tv_grad_sparse.argtypes = [vp, vp, vp, i32, vp, i64, vp, i32, i32, fl, i32, i32, vp, vp]
+        L.asurf_surf_tv_grad_sparse.argtypes = [vp, vp, vp, i32, vp, i32, vp, i64, vp, i32, i32, fl, i32, fl,
+                                                i32, i32, vp, vp]
+        L.asurf_surface_normal_grad_sparse.argtypes = [vp, vp, vp, vp, i64, vp, fl, fl, i32, i32, i32, vp, vp]
+        L.asurf_alpha_surf_sparsify_grad_sparse.argtypes = [vp, vp, vp, vp, vp, i64, vp, fl, fl, i32, fl, fl,
+                                                            fl, vp, vp, vp]
+        L.asurf_surface_eikonal_grad_sparse.argtypes = [vp, vp, vp, vp, i64, vp, fl, fl, vp, vp, vp]
         if L.asurf_abi_version() != 1:
             raise RuntimeError("libasurf_hip.so ABI version mismatch")
         _lib = L

@@ -250,6 +250,43 @@ int asurf_rmsprop_step(float* data, float* rms, float* grad, int64_t n_rows, int
 int asurf_sgd_step(float* data, float* grad, int64_t n_rows, int32_t n_cols, const uint8_t* mask,
                    const int64_t* indices, int64_t n_indices, float lr, float lr_last, void* stream);
 
+/* Per-iteration regularisers.  `links` is the int32[size0,size1,size2]
+ * link grid, `rand_cells` a device list of n_cells flat cell indices (svox2.py:6335-6383),
+ * `mask_out` the bool[N] sparse_grad_indexer or NULL; gradients are ADDED to grad_*.
+ * `scale` is the caller's weight: the launchers divide it by n_cells as the reference's do.
+ *   tv_grad_sparse                  svox2.cpp (REG tv_grad_sparse), loss_kernel.cu:739-808, 1327-1373
+ *   surf_tv_grad_sparse             loss_kernel.cu:810-895, 1375-1427
+ *   surface_normal_grad_sparse      loss_kernel.cu:398-436, 1572-1622; render_util.cuh:1823-2130
+ *   alpha_surf_sparsify_grad_sparse loss_kernel.cu:665-738, 1512-1570 (scales used as given)
+ *   surface_eikonal_grad_sparse     the reference evaluates this loss with PyTorch autograd
+ *                                   (svox2.py:5433-5472, called from opt.py:1002-1009); *loss_out
+ *                                   (device float, may be NULL) is incremented by the loss value. */
+int asurf_tv_grad_sparse(const int32_t* links, const int32_t size[3], const float* data, int32_t n_cols,
+                         const int32_t* rand_cells, int64_t n_cells, uint8_t* mask_out,
+                         int32_t start_dim, int32_t end_dim, float scale, int32_t ignore_edge,
+                         int32_t ignore_last_z, float* grad_data, void* stream);
+int asurf_surf_tv_grad_sparse(const int32_t* links, const int32_t size[3], const float* data,
+                              int32_t n_cols, const float* density_data, int32_t density_cols,
+                              const int32_t* rand_cells, int64_t n_cells, uint8_t* mask_out,
+                              int32_t start_dim, int32_t end_dim, float scale, int32_t ignore_edge,
+                              float edge_value, int32_t ignore_last_z, int32_t alpha_dependency,
+                              float* grad_data, void* stream);
+int asurf_surface_normal_grad_sparse(const int32_t* links, const int32_t size[3],
+                                     const float* surface_data, const int32_t* rand_cells,
+                                     int64_t n_cells, uint8_t* mask_out, float lv_set, float scale,
+                                     int32_t con_check, int32_t ignore_empty, int32_t use_l1,
+                                     float* grad_data, void* stream);
+int asurf_alpha_surf_sparsify_grad_sparse(const int32_t* links, const int32_t size[3],
+                                          const float* alpha_data, const float* surf_data,
+                                          const int32_t* rand_cells, int64_t n_cells, uint8_t* mask_out,
+                                          float scale_alpha, float scale_surf, int32_t surf_sparse_decrease,
+                                          float surf_sparse_thresh, float alpha_bound, float surf_bound,
+                                          float* grad_alpha, float* grad_surf, void* stream);
+int asurf_surface_eikonal_grad_sparse(const int32_t* links, const int32_t size[3],
+                                      const float* surface_data, const int32_t* rand_cells,
+                                      int64_t n_cells, uint8_t* mask_out, float scale, float h,
+                                      float* grad_data, float* loss_out, void* stream);
+
 /* Measurement hooks (no reference counterpart; used by bench.py).  When enabled, the
  * surf_trav launchers record a hipEvent on the call's stream after every kernel launch.
  * asurf_profile_read() waits for the last call and returns, in milliseconds,

@@ -360,3 +360,74 @@ def num_threads():
 
 def set_num_threads(n):
     lib().oracle_set_num_threads(C.c_int(int(n)))
+
+
+# ---- per-iteration regularisers (asurf_oracle_reg.cpp) ----
+def _links_size(links):
+    links = np.ascontiguousarray(links, np.int32)
+    return links, (C.c_int32 * 3)(*links.shape)
+
+
+def tv_grad_sparse(links, data, rand_cells, scale, start_dim=0, end_dim=None, ignore_edge=False,
+                   ignore_last_z=False, mask=None, grad=None, surf=False, density=None, edge_value=0.0,
+                   alpha_dependency=False):
+    """tv_grad_sparse (surf=False) / surf_tv_grad_sparse (surf=True); returns (grad, mask)."""
+    links, size = _links_size(links)
+    data = np.ascontiguousarray(data, np.float32)
+    rc = np.ascontiguousarray(rand_cells, np.int32)
+    end_dim = data.shape[1] if end_dim is None else end_dim
+    grad = np.zeros_like(data) if grad is None else grad
+    mask = np.zeros(data.shape[0], np.uint8) if mask is None else mask
+    dens = np.ascontiguousarray(density, np.float32) if density is not None else None
+    f = lib().oracle_tv_grad_sparse
+    f.argtypes = [c_i, c_i, c_f, C.c_int32, c_f, C.c_int32, c_i, C.c_int64, c_u8, C.c_int32, C.c_int32,
+                  C.c_float, C.c_int32, C.c_float, C.c_int32, C.c_int32, C.c_int32, c_f]
+    _check(f(_i(links), size, _f(data), data.shape[1], _f(dens) if dens is not None else None,
+             dens.shape[1] if dens is not None else 0, _i(rc), rc.shape[0], _u8(mask), start_dim, end_dim,
+             scale, int(ignore_edge), edge_value, int(ignore_last_z), int(surf), int(alpha_dependency),
+             _f(grad)), "tv_grad_sparse")
+    return grad, mask
+
+
+def surface_normal_grad_sparse(links, surface, rand_cells, scale, lv_set=0.0, con_check=True,
+                               ignore_empty=False, use_l1=False, mask=None, grad=None):
+    links, size = _links_size(links)
+    surface = np.ascontiguousarray(surface, np.float32)
+    rc = np.ascontiguousarray(rand_cells, np.int32)
+    grad = np.zeros_like(surface) if grad is None else grad
+    mask = np.zeros(surface.shape[0], np.uint8) if mask is None else mask
+    f = lib().oracle_surface_normal_grad_sparse
+    f.argtypes = [c_i, c_i, c_f, c_i, C.c_int64, c_u8, C.c_float, C.c_float, C.c_int32, C.c_int32, C.c_int32, c_f]
+    _check(f(_i(links), size, _f(surface), _i(rc), rc.shape[0], _u8(mask), lv_set, scale, int(con_check),
+             int(ignore_empty), int(use_l1), _f(grad)), "surface_normal_grad_sparse")
+    return grad, mask
+
+
+def alpha_surf_sparsify_grad_sparse(links, alpha, surf, rand_cells, scale_alpha, scale_surf, surf_decrease,
+                                    surf_thresh, alpha_bound, surf_bound):
+    links, size = _links_size(links)
+    alpha = np.ascontiguousarray(alpha, np.float32)
+    surf = np.ascontiguousarray(surf, np.float32)
+    rc = np.ascontiguousarray(rand_cells, np.int32)
+    ga, gs = np.zeros_like(alpha), np.zeros_like(surf)
+    mask = np.zeros(alpha.shape[0], np.uint8)
+    f = lib().oracle_alpha_surf_sparsify_grad_sparse
+    f.argtypes = [c_i, c_i, c_f, c_f, c_i, C.c_int64, c_u8, C.c_float, C.c_float, C.c_int32, C.c_float,
+                  C.c_float, C.c_float, c_f, c_f]
+    _check(f(_i(links), size, _f(alpha), _f(surf), _i(rc), rc.shape[0], _u8(mask), scale_alpha, scale_surf,
+             int(surf_decrease), surf_thresh, alpha_bound, surf_bound, _f(ga), _f(gs)), "alpha_surf_sparsify")
+    return ga, gs, mask
+
+
+def surface_eikonal_grad_sparse(links, surface, rand_cells, scale, h, with_mask=False):
+    links, size = _links_size(links)
+    surface = np.ascontiguousarray(surface, np.float32)
+    rc = np.ascontiguousarray(rand_cells, np.int32)
+    grad = np.zeros_like(surface)
+    mask = np.zeros(surface.shape[0], np.uint8)
+    loss = C.c_double(0)
+    f = lib().oracle_surface_eikonal_grad_sparse
+    f.argtypes = [c_i, c_i, c_f, c_i, C.c_int64, c_u8, C.c_float, C.c_float, c_f, C.POINTER(C.c_double)]
+    _check(f(_i(links), size, _f(surface), _i(rc), rc.shape[0], _u8(mask) if with_mask else None, scale, h,
+             _f(grad), C.byref(loss)), "surface_eikonal_grad_sparse")
+    return grad, float(loss.value), mask

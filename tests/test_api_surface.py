@@ -69,7 +69,9 @@ def test_svox2_alias_presents_the_reference_names():
     for name in ["SparseGridSpec", "CameraSpec", "RaysSpec", "RayVoxIntersecSpec", "RenderOptions",
                  "GridOutputGrads", "volume_render_surf_trav", "volume_render_surf_trav_backward",
                  "volume_render_surf_trav_fused", "volume_render_surface", "volume_render_surface_backward",
-                 "volume_render_surface_fused", "test_cubic_root_grad", "sample_grid", "rmsprop_step", "sgd_step"]:
+                 "volume_render_surface_fused", "test_cubic_root_grad", "sample_grid", "rmsprop_step", "sgd_step",
+                 "tv_grad_sparse", "surf_tv_grad_sparse", "surface_normal_grad_sparse",
+                 "alpha_surf_sparsify_grad_sparse"]:
         assert name in _C.__dict__, name   # svox2.py dispatches through _C.__dict__[...]
     # every attribute / method opt.py touches on the grid for the hot path (tier P0) exists
     g = svox2.SparseGrid(reso=8, basis_dim=4, surface_type=svox2.SURFACE_TYPE_SDF, surface_init="sphere",
@@ -88,7 +90,19 @@ def test_svox2_alias_presents_the_reference_names():
         assert hasattr(g.opt, field), field
     # out-of-scope entry points fail loudly and say where they belong
     with pytest.raises(NotImplementedError, match="N2"):
-        g.inplace_tv_grad(None)
+        g.inplace_tv_lumisphere_grad(None)
+    with pytest.raises(NotImplementedError, match="N3"):
+        g.volume_render_depth_image(None)
+    # the N2 regularisers of the live config are built (tests/test_reg_gpu.py)
+    for name in ["inplace_tv_grad", "inplace_tv_surface_grad", "inplace_surface_normal_grad",
+                 "inplace_surface_eikonal_grad", "inplace_alpha_surf_sparsify_grad", "inplace_tv_color_grad",
+                 "_get_rand_cells", "_get_rand_cells_non_empty", "_get_sparse_grad_indexer"]:
+        assert name in svox2.SparseGrid.__dict__ and "_next_row" not in getattr(svox2.SparseGrid, name).__code__.co_names[:1], name
+    cells = g._get_rand_cells(0.1)
+    assert cells.dtype == torch.int32 and cells.numel() == max(int(0.1 * g.links.numel()), 1)
+    assert int(cells.max()) < g.links.numel() and int(cells.min()) >= 0
+    ne = g._get_rand_cells_non_empty(0.5)
+    assert (g.links.view(-1)[ne.long()] >= 0).all()
     with pytest.raises(NotImplementedError):
         g.volume_render(svox2.Rays(torch.zeros(1, 3), torch.ones(1, 3)), use_kernel=False)
 
