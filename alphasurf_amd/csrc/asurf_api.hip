@@ -19,6 +19,7 @@
 #include "asurf_bwd_pipeline.h"
 #include "asurf_legacy.h"
 #include "asurf_reg.h"
+#include "asurf_eval.h"
 
 namespace {
 
@@ -261,13 +262,14 @@ int launch_error(const char* what) {
 
 // Common prologue: validation, workspace carve-up and the occupancy-pyramid pass.
 int prepare(const asurf_grid* grid, const asurf_rays* rays, const asurf_render_options* opt,
-            int32_t M, void* workspace, size_t workspace_bytes, void* stream, Launch& L) {
+            int32_t M, void* workspace, size_t workspace_bytes, void* stream, Launch& L,
+            bool masks_only = false) {
     if (int e = check_grid(grid)) return e;
     if (int e = check_rays(rays)) return e;
     if (!opt) return fail(ASURF_E_INVALID, "render options are NULL");
     if (opt->alpha_activation_type != ASURF_SIGMOID_FN && opt->alpha_activation_type != ASURF_EXP_FN)
         return fail(ASURF_E_INVALID, "alpha_activation_type must be 0 (sigmoid) or 1 (exp)");
-    L.ML = layout_for(grid->size, rays->n_rays, M);
+    L.ML = layout_for(grid->size, masks_only ? 0 : rays->n_rays, M);  // masks_only: no per-ray tables
     if (!workspace || workspace_bytes < L.ML.total)
         return fail(ASURF_E_WORKSPACE, "workspace of %zu bytes needed, got %zu", L.ML.total,
                     workspace ? workspace_bytes : (size_t)0);
@@ -543,6 +545,17 @@ int leg_bwd(dim3 gd, hipStream_t s, const KGrid& g, const KOpt& o, const KGrads&
                        (long long)rays->n_rays, rv->voxel_ls, rv->vox_start_i, rv->vox_num,
                        (long long)rv->n_vox, grad_in, color_cache, grad_in_is_rgb, sparsity_loss);
     return 0;
+}
+
+template <int MODE>
+int launch_eval(const Launch& L, const asurf_rays* rays, float param, int max_sample, float* out0, float* out1) {
+    if (L.coarse_in_lds)
+        hipLaunchKernelGGL((k_eval<MODE, true>), L.ray_grid, dim3(kBlock), L.dyn_lds, L.stream, L.g, L.o,
+                           rays->origins, rays->dirs, (long long)rays->n_rays, param, max_sample, out0, out1);
+    else
+        hipLaunchKernelGGL((k_eval<MODE, false>), L.ray_grid, dim3(kBlock), 0, L.stream, L.g, L.o,
+                           rays->origins, rays->dirs, (long long)rays->n_rays, param, max_sample, out0, out1);
+    return launch_error("k_eval");
 }
 
 }  // namespace
@@ -951,6 +964,34 @@ int asurf_surface_eikonal_grad_sparse(const int32_t* links, const int32_t size[3
                        scale / (float)(int)n_cells, 1.f / (h * h), (long long)n_cells, mask_out, grad_data,
                        loss_out);
     return launch_error("k_surface_eikonal_grad_sparse");
+}
+
+// ---- evaluation renders (asurf_eval.h) ----
+int asurf_render_eval_surf_trav(const asurf_grid* grid, const asurf_rays* rays,
+                                const asurf_render_options* opt, int32_t mode, float param,
+                                int32_t max_sample, float* out0, float* out1, void* workspace,
+                                size_t workspace_bytes, void* stream) {
+    if (mode < 0 || mode > 5) return fail(ASURF_E_INVALID, "render_eval: mode %d", mode);
+    if (!opt) return fail(ASURF_E_INVALID, "render options are NULL");
+    // no density gate, no fake samples: the walk needs links + a level set in range only
+    asurf_render_options eo = *opt;
+    eo.sigma_thresh = -INFINITY;
+    eo.surf_fake_sample = 0;
+    Launch L;
+    if (int e = prepare(grid, rays, &eo, 0, workspace, workspace_bytes, stream, L, true)) return e;
+    if (grid->size[0] > 1024 || grid->size[1] > 1024 || grid->size[2] > 1024)
+        return fail(ASURF_E_INVALID, "render_eval: grid sizes above 1024 are not supported");
+    if (rays->n_rays == 0) return 0;
+    if (!out0 || (mode == 5 && (!out1 || max_sample < 1)))
+        return fail(ASURF_E_INVALID, "render_eval: output tensor missing / max_sample < 1");
+    switch (mode) {
+        case 0: return launch_eval<EVAL_EXPECTED>(L, rays, param, max_sample, out0, out1);
+        case 1: return launch_eval<EVAL_MODE_DEPTH>(L, rays, param, max_sample, out0, out1);
+        case 2: return launch_eval<EVAL_FIRST_DEPTH>(L, rays, param, max_sample, out0, out1);
+        case 3: return launch_eval<EVAL_FIRST_ALPHA>(L, rays, param, max_sample, out0, out1);
+        case 4: return launch_eval<EVAL_NORMAL>(L, rays, param, max_sample, out0, out1);
+        default: return launch_eval<EVAL_EXTRACT>(L, rays, param, max_sample, out0, out1);
+    }
 }
 
 }  // extern "C"

@@ -1,0 +1,129 @@
+// Evaluation renders: the traversal + cubic core of the hot path
+// without colour, density gate, truncation window or fake samples.  surf_trav.cu:564-1705, kernels
+// :3457-3580.  One ray per lane; the walk is the hierarchical exact DDA of the training path over
+// the per-call occupancy pyramid (links present + a level set inside the voxel's value range).
+#pragma once
+#include "asurf_kernels.h"
+
+namespace asurf {
+
+enum EvalMode {
+    EVAL_EXPECTED = 0,      // expected termination depth                      out0[Q]
+    EVAL_MODE_DEPTH = 1,    // depth of the max-weight sample, 0 unless sum w > param
+    EVAL_FIRST_DEPTH = 2,   // depth of the first sample with alpha > param
+    EVAL_FIRST_ALPHA = 3,   // alpha of the first sample with alpha > param
+    EVAL_NORMAL = 4,        // surface-field gradient at the first sample with alpha > 0   out0[Q,3]
+    EVAL_EXTRACT = 5,       // up to max_sample (depth, alpha) pairs with alpha > param    out0,out1[Q,max_sample]
+};
+
+template <int MODE, bool CLDS>
+__global__ void __launch_bounds__(kBlock)
+k_eval(KGrid g, KOpt o, const float* __restrict__ origins, const float* __restrict__ dirs, long long Q,
+       float param, int max_sample, float* __restrict__ out0, float* __restrict__ out1) {
+    extern __shared__ unsigned int s_coarse[];
+    const int tid = threadIdx.x;
+    if constexpr (CLDS) {
+        for (int i = tid; i < g.coarse_words; i += kBlock) s_coarse[i] = g.coarse[i];
+        __syncthreads();
+    }
+    const long long q = (long long)blockIdx.x * kBlock + tid;
+    if (q >= Q) return;
+    Ray r;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        r.o[k] = origins[3 * q + k];
+        r.d[k] = dirs[3 * q + k];
+    }
+    // world_step / step_size = 1 / |dir * scaling| (render_util.cuh:536-547)
+    const float ds0 = r.d[0] * g.scaling[0], ds1 = r.d[1] * g.scaling[1], ds2 = r.d[2] * g.scaling[2];
+    const float world_step = (1.f / sqrtf(ds0 * ds0 + ds1 * ds1 + ds2 * ds2)) * o.step_size;
+    setup_ray(g, o, r);
+    constexpr int NOUT = (MODE == EVAL_NORMAL) ? 3 : 1;
+    float* my0 = out0 + (size_t)q * (MODE == EVAL_EXTRACT ? max_sample : NOUT);
+    float* my1 = (MODE == EVAL_EXTRACT) ? out1 + (size_t)q * max_sample : nullptr;
+    if (r.tmin > r.tmax) {
+        if constexpr (MODE == EVAL_EXTRACT) {
+            my0[0] = 0.f;  // the rows arrive zeroed (surf_trav.cu:4066-4067)
+        } else {
+#pragma unroll
+            for (int i = 0; i < NOUT; ++i) my0[i] = 0.f;
+        }
+        return;
+    }
+    float outv = 0.f, weight_acc = 0.f, max_weight = -1.f, log_transmit = 0.f;
+    float res[3] = {0.f, 0.f, 0.f};
+    int sample_id = 0;
+    bool done = false;
+    Walk w;
+    walk_init(g, r, w);
+    bool active = true;
+    while (active && !done) {
+        const int kind = walk_hier<CLDS>(g, s_coarse, w, o.step_size, r.tmax, true);
+        active = (w.t <= r.tmax);
+        if (kind != 2) continue;
+        Vox v;
+        load_voxel(g, r, pack_voxel(w.vx, w.vy, w.vz), v);
+        for (int li = 0; li < g.level_set_num && !done; ++li) {
+            const float lvf = g.level_set[li];
+            if (lvf < v.smin || lvf > v.smax) continue;
+            double st[3] = {-1, -1, -1};
+            solve_cubic_vieta(v.fs[0] - (double)lvf, v.fs[1], v.fs[2], v.fs[3], st);
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                if (done || !(st[j] > 0)) continue;
+                float pos[3];
+                if (!root_position(r, v, st[j], pos)) continue;
+                const float alpha = alpha_act(trilerp8(v.dens, pos), o.alpha_activation_type);
+                const double depth = (st[j] + (double)v.t_close) / (double)o.step_size * (double)world_step;
+                if constexpr (MODE == EVAL_EXPECTED || MODE == EVAL_MODE_DEPTH) {
+                    const float pcnt = -1 * logf(1 - alpha);
+                    const float weight = expf(log_transmit) * (1.f - expf(-pcnt));
+                    log_transmit -= pcnt;
+                    if constexpr (MODE == EVAL_EXPECTED) {
+                        outv = (float)((double)outv + (double)weight * depth);
+                    } else {
+                        weight_acc += weight;
+                        if (weight > max_weight) {
+                            max_weight = weight;
+                            outv = (float)depth;
+                        }
+                    }
+                } else if constexpr (MODE == EVAL_FIRST_DEPTH) {
+                    if (alpha > param) {
+                        res[0] = (float)depth;
+                        done = true;
+                    }
+                } else if constexpr (MODE == EVAL_FIRST_ALPHA) {
+                    if (alpha > param) {
+                        res[0] = alpha;
+                        done = true;
+                    }
+                } else if constexpr (MODE == EVAL_NORMAL) {
+                    if (alpha > 0) {
+                        field_grad(v.surf, pos, res);
+                        done = true;
+                    }
+                } else {
+                    if (alpha > param) {
+                        my0[sample_id] = (float)depth;
+                        my1[sample_id] = alpha;
+                        if (++sample_id >= max_sample) done = true;
+                    }
+                }
+            }
+        }
+        if constexpr (MODE == EVAL_EXPECTED || MODE == EVAL_MODE_DEPTH) {
+            if (expf(log_transmit) < o.stop_thresh) break;  // once per visited voxel, :786-789
+        }
+    }
+    if constexpr (MODE == EVAL_EXPECTED) my0[0] = outv;
+    else if constexpr (MODE == EVAL_MODE_DEPTH) my0[0] = (weight_acc > param) ? outv : 0.f;
+    else if constexpr (MODE == EVAL_FIRST_DEPTH || MODE == EVAL_FIRST_ALPHA) my0[0] = res[0];
+    else if constexpr (MODE == EVAL_NORMAL) {
+        my0[0] = res[0];
+        my0[1] = res[1];
+        my0[2] = res[2];
+    }
+}
+
+}  // namespace asurf

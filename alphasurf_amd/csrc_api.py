@@ -21,6 +21,9 @@ __all__ = [
     "volume_render_surf_trav_fused", "volume_render_surface", "volume_render_surface_backward",
     "ray_voxel_lists", "tv_grad_sparse", "surf_tv_grad_sparse", "surface_normal_grad_sparse",
     "alpha_surf_sparsify_grad_sparse", "surface_eikonal_grad_sparse",
+    "volume_render_expected_term_surf_trav", "volume_render_mode_term_surf_trav",
+    "volume_render_sigma_thresh_surf_trav", "volume_render_alpha_surf_trav", "render_normal_surf_trav",
+    "extract_pts_surf_trav",
     "volume_render_surface_fused", "test_cubic_root_grad", "sample_grid", "rmsprop_step", "sgd_step",
 ]
 
@@ -600,6 +603,61 @@ def surface_eikonal_grad_sparse(links, data, rand_cells, mask_out, scale, h, gra
             lp, size, _ptr(data), _ptr(rand_cells), rand_cells.shape[0], _mask_ptr(mask_out), float(scale),
             float(h), _ptr(grad_data), _ptr(loss), _stream(dev)))
     return loss
+
+
+# ---- evaluation renders (surf_trav.cu:3944-4081) ----
+def _render_eval(grid, rays, opt, mode, param, max_sample=1):
+    g, r, o = _pack_grid(grid), _pack_rays(rays), _pack_opt(opt)
+    dev = grid.sh_data.device
+    q = r.n_rays
+    with torch.cuda.device(dev):
+        if mode == 4:
+            out0 = torch.empty((q, 3), dtype=torch.float32, device=dev)
+            out1 = None
+        elif mode == 5:
+            out0 = torch.zeros((q, max_sample), dtype=torch.float32, device=dev)
+            out1 = torch.zeros((q, max_sample), dtype=torch.float32, device=dev)
+        else:
+            out0 = torch.empty((q,), dtype=torch.float32, device=dev)
+            out1 = None
+        nb = _L.workspace_bytes(grid.links.shape, 0, 0)
+        ws = _workspace(dev, nb)
+        _L.check(_L.lib().asurf_render_eval_surf_trav(
+            C.byref(g), C.byref(r), C.byref(o), int(mode), float(param), int(max_sample), _ptr(out0),
+            _ptr(out1) if out1 is not None else None, _ptr(ws), nb, _stream(dev)))
+    return out0, out1
+
+
+def volume_render_expected_term_surf_trav(grid, rays, opt):
+    """Tensor[Q]: expected termination depth along the ray (world length) -- surf_trav.cu:3944-3962."""
+    return _render_eval(grid, rays, opt, 0, 0.0)[0]
+
+
+def volume_render_mode_term_surf_trav(grid, rays, opt, weight_thresh):
+    """Tensor[Q]: depth of the max-weight sample, 0 unless the weights sum above weight_thresh -- :3964-3983."""
+    return _render_eval(grid, rays, opt, 1, weight_thresh)[0]
+
+
+def volume_render_sigma_thresh_surf_trav(grid, rays, opt, sigma_thresh):
+    """Tensor[Q]: depth of the first sample whose alpha exceeds sigma_thresh -- :3985-4006."""
+    return _render_eval(grid, rays, opt, 2, sigma_thresh)[0]
+
+
+def volume_render_alpha_surf_trav(grid, rays, opt, sigma_thresh):
+    """Tensor[Q]: alpha of the first sample whose alpha exceeds sigma_thresh -- :4008-4029."""
+    return _render_eval(grid, rays, opt, 3, sigma_thresh)[0]
+
+
+def render_normal_surf_trav(grid, rays, opt):
+    """Tensor[Q,3]: gradient of the surface field at the first sample with alpha > 0 -- :4031-4051."""
+    return _render_eval(grid, rays, opt, 4, 0.0)[0]
+
+
+def extract_pts_surf_trav(grid, rays, opt, max_sample, alpha_thresh):
+    """(depths[Q,max_sample], alphas[Q,max_sample]) of the samples with alpha > alpha_thresh -- :4053-4081."""
+    if int(max_sample) < 1:
+        raise RuntimeError("extract_pts_surf_trav: max_sample must be >= 1")
+    return _render_eval(grid, rays, opt, 5, alpha_thresh, int(max_sample))
 
 
 def sample_grid(*args, **kwargs):

@@ -488,6 +488,81 @@ class SparseGrid(nn.Module):
                  for s in range(0, camera.height * camera.width, batch_size)]
         return torch.cat(parts, dim=0).view(camera.height, camera.width, -1)
 
+    # ---- evaluation renders (:3693-3961 -> surf_trav.cu:3944-4081) ----
+    def _eval_backend(self, kwargs):
+        if kwargs.get("no_surface", False):
+            _next_row("N4", "no_surface evaluation renders (cuvol renderer)")
+        self._check_backend()
+        if self.opt.backend != "surf_trav":
+            _next_row("N3", f"evaluation renders of backend {self.opt.backend!r}")
+
+    def volume_render_depth(self, rays: Rays, sigma_thresh: Optional[float] = None, depth_type="mean",
+                            weight_thresh: float = 0.0, **kwargs):
+        """Depth along each ray (absolute length, not z-depth): expected termination, the max-weight
+        sample (`depth_type='mode'`), or the first sample above `sigma_thresh` (:3693-3763)."""
+        self._eval_backend(kwargs)
+        g, r, o = self._to_cpp(), rays._to_cpp(), self.opt._to_cpp()
+        if sigma_thresh is None:
+            if depth_type == "mode":
+                return _C.volume_render_mode_term_surf_trav(g, r, o, weight_thresh)
+            return _C.volume_render_expected_term_surf_trav(g, r, o)
+        return _C.volume_render_sigma_thresh_surf_trav(g, r, o, sigma_thresh)
+
+    def volume_render_normal(self, rays: Rays, **kwargs):
+        """:3765-3784"""
+        self._eval_backend(kwargs)
+        return _C.render_normal_surf_trav(self._to_cpp(), rays._to_cpp(), self.opt._to_cpp())
+
+    def volume_render_alpha_map(self, rays: Rays, thresh: float, **kwargs):
+        """:3786-3806"""
+        self._eval_backend(kwargs)
+        return _C.volume_render_alpha_surf_trav(self._to_cpp(), rays._to_cpp(), self.opt._to_cpp(), thresh)
+
+    def _image_batches(self, camera: Camera, batch_size: int, fn):
+        rays = camera.gen_rays()
+        return torch.cat([fn(rays[s:s + batch_size]) for s in range(0, camera.height * camera.width, batch_size)],
+                         dim=0)
+
+    def volume_render_depth_image(self, camera: Camera, sigma_thresh: Optional[float] = None,
+                                  batch_size: int = 5000, **kwargs):
+        """:3808-3826"""
+        out = self._image_batches(camera, batch_size, lambda r: self.volume_render_depth(r, sigma_thresh, **kwargs))
+        return out.view(camera.height, camera.width)
+
+    def volume_render_normal_image(self, camera: Camera, batch_size: int = 5000, **kwargs):
+        """:3828-3845"""
+        out = self._image_batches(camera, batch_size, lambda r: self.volume_render_normal(r, **kwargs))
+        return out.view(camera.height, camera.width, 3)
+
+    def volume_render_alpha_image(self, camera: Camera, thresh: float = -1, batch_size: int = 5000, **kwargs):
+        """:3847-3864"""
+        out = self._image_batches(camera, batch_size, lambda r: self.volume_render_alpha_map(r, thresh, **kwargs))
+        return out.view(camera.height, camera.width, 1)
+
+    def volume_render_extract_pts(self, camera: Camera, sigma_thresh: Optional[float] = None,
+                                  batch_size: int = 5000, depth_type="mean", **kwargs):
+        """One 3-D point per ray that has a depth (:3866-3912)."""
+        rays = camera.gen_rays()
+        depth = self._image_batches(
+            camera, batch_size, lambda r: self.volume_render_depth(r, sigma_thresh, depth_type=depth_type, **kwargs))
+        pts = rays.origins + rays.dirs * depth[:, None]
+        return pts[(depth != 0.0) & (~torch.isnan(depth))]
+
+    def volume_render_extract_pts_with_alpha(self, camera: Camera, sigma_thresh: Optional[float] = None,
+                                             batch_size: int = 5000, max_sample: int = 20, **kwargs):
+        """Every intersection with alpha above `sigma_thresh`, up to max_sample per ray (:3914-3961)."""
+        self._eval_backend(kwargs)
+        rays = camera.gen_rays()
+        all_pts, all_alpha = [], []
+        for s in range(0, camera.height * camera.width, batch_size):
+            rb = rays[s:s + batch_size]
+            depths, alphas = _C.extract_pts_surf_trav(self._to_cpp(), rb._to_cpp(), self.opt._to_cpp(), max_sample,
+                                                      sigma_thresh)
+            mask = depths != 0.0
+            all_alpha.append(alphas[mask])
+            all_pts.append((rb.origins[:, None, :] + rb.dirs[:, None, :] * depths[..., None])[mask])
+        return torch.cat(all_pts, dim=0), torch.cat(all_alpha, dim=0)
+
     # ---- per-iteration regularisers (:4947-5165, 5686-5766 -> loss_kernel.cu) ----
     def _get_sparse_grad_indexer(self):
         """:6295-6299"""

@@ -90,6 +90,7 @@ EXPORTS = [
     "asurf_rmsprop_step", "asurf_sgd_step", "asurf_ray_voxel_count", "asurf_ray_voxel_fill",
     "asurf_tv_grad_sparse", "asurf_surf_tv_grad_sparse", "asurf_surface_normal_grad_sparse",
     "asurf_alpha_surf_sparsify_grad_sparse", "asurf_surface_eikonal_grad_sparse",
+    "asurf_render_eval_surf_trav",
 ]
 
 _lib = None
@@ -135,6 +136,7 @@ def lib():
         L.asurf_alpha_surf_sparsify_grad_sparse.argtypes = [vp, vp, vp, vp, vp, i64, vp, fl, fl, i32, fl, fl,
                                                             fl, vp, vp, vp]
         L.asurf_surface_eikonal_grad_sparse.argtypes = [vp, vp, vp, vp, i64, vp, fl, fl, vp, vp, vp]
+        L.asurf_render_eval_surf_trav.argtypes = [vp, vp, vp, i32, fl, i32, vp, vp, vp, C.c_size_t, vp]
         if L.asurf_abi_version() != 1:
             raise RuntimeError("libasurf_hip.so ABI version mismatch")
         _lib = L

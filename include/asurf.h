@@ -250,6 +250,21 @@ int asurf_rmsprop_step(float* data, float* rms, float* grad, int64_t n_rows, int
 int asurf_sgd_step(float* data, float* grad, int64_t n_rows, int32_t n_cols, const uint8_t* mask,
                    const int64_t* indices, int64_t n_indices, float lr, float lr_last, void* stream);
 
+/* Evaluation renders: traversal + cubic core without colour, density
+ * gate, window or fake samples.  `workspace` as for the training calls (asurf_workspace_bytes with
+ * l_dist_max_sample = 0).  mode / param / outputs:
+ *   0 volume_render_expected_term_surf_trav  svox2.cpp REG, surf_trav.cu:564-794, 3944-3962   out0[Q]
+ *   1 volume_render_mode_term_surf_trav      :796-1000, 3964-3983   param = weight_thresh     out0[Q]
+ *   2 volume_render_sigma_thresh_surf_trav   :1003-1168, 3985-4006  param = alpha threshold   out0[Q]
+ *   3 volume_render_alpha_surf_trav          :1170-1335, 4008-4029  param = alpha threshold   out0[Q]
+ *   4 render_normal_surf_trav                :1339-1531, 4031-4051                            out0[Q,3]
+ *   5 extract_pts_surf_trav                  :1536-1705, 4053-4081  param = alpha_thresh;
+ *       out0 = depths, out1 = alphas, both [Q,max_sample] and ZEROED by the caller. */
+int asurf_render_eval_surf_trav(const asurf_grid* grid, const asurf_rays* rays,
+                                const asurf_render_options* opt, int32_t mode, float param,
+                                int32_t max_sample, float* out0, float* out1, void* workspace,
+                                size_t workspace_bytes, void* stream);
+
 /* Per-iteration regularisers.  `links` is the int32[size0,size1,size2]
  * link grid, `rand_cells` a device list of n_cells flat cell indices (svox2.py:6335-6383),
  * `mask_out` the bool[N] sparse_grad_indexer or NULL; gradients are ADDED to grad_*.

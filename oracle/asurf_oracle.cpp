@@ -1523,6 +1523,99 @@ int legacy_check(const oracle_grid* g, const oracle_rays* r, const oracle_ray_vo
     return 0;
 }
 
+
+// ---------------------------------------------------------------------------------
+// Evaluation renders: the traversal + cubic core without colour,
+// sigma gate, window or fake samples.  surf_trav.cu:564-1705.
+//   mode 0 expected termination depth (:564-794)      out0[Q]
+//   mode 1 depth of the max-weight sample, 0 unless sum w > param (:796-1000)
+//   mode 2 depth of the first sample with alpha > param (:1003-1168)
+//   mode 3 alpha of the first sample with alpha > param (:1170-1335)
+//   mode 4 surface-field gradient at the first sample with alpha > 0 (:1339-1531)  out0[Q,3]
+//   mode 5 up to max_sample (depth, alpha) pairs with alpha > param (:1536-1705)   out0,out1[Q,max_sample]
+// ---------------------------------------------------------------------------------
+void eval_ray(const oracle_grid& g, const oracle_render_options& o_in, const Ray& r, int mode, float param,
+              int max_sample, float* out0, float* out1) {
+    oracle_render_options o = o_in;
+    o.sigma_thresh = -INFINITY;  // these kernels have no density gate
+    const int n_out = (mode == 4) ? 3 : (mode == 5 ? max_sample : 1);
+    if (mode == 5) {  // the launcher hands over zeroed rows (:4066-4067); a missing ray writes one 0
+        if (r.tmin > r.tmax) {
+            if (max_sample > 0) out0[0] = 0.f;
+            return;
+        }
+    } else {
+        for (int i = 0; i < n_out; ++i) out0[i] = 0.f;
+        if (r.tmin > r.tmax) return;
+    }
+    float outv = 0.f, weight_acc = 0.f, max_weight = -1.f, log_transmit = 0.f;
+    int sample_id = 0;
+    Dda d;
+    dda_init(g, r, d);
+    VoxelCtx vc;
+    while (d.t <= r.tmax) {
+        dda_step(g, r, d);
+        bool link_empty;
+        if (!load_voxel(g, o, r, d, vc, &link_empty)) continue;
+        for (int li = 0; li < g.level_set_num; ++li) {
+            const double lv = g.level_set_data[li];
+            if (lv < vc.smin || lv > vc.smax) continue;
+            double st[3] = {-1, -1, -1};
+            solve_cubic_vieta(vc.fs[0] - lv, vc.fs[1], vc.fs[2], vc.fs[3], 1e-10, st);
+            for (int j = 0; j < 3; ++j) {
+                if (st[j] <= 0) continue;
+                float pos[3];
+                int32_t l[3];
+                if (!root_position(g, r, d, vc, st[j], pos, l)) continue;
+                const float alpha = alpha_act(trilerp(vc.dens, pos), o.alpha_activation_type);
+                // (st + t_close) / step_size * world_step, evaluated in double as the reference's
+                // mixed expression is
+                const double depth = (st[j] + (double)d.t_close) / (double)o.step_size * (double)r.world_step;
+                if (mode == 0 || mode == 1) {
+                    const float pcnt = -1 * logf(1 - alpha);
+                    const float weight = expf(log_transmit) * (1.f - expf(-pcnt));
+                    log_transmit -= pcnt;
+                    if (mode == 0) {
+                        outv = (float)((double)outv + (double)weight * depth);
+                    } else {
+                        weight_acc += weight;
+                        if (weight > max_weight) {
+                            max_weight = weight;
+                            outv = (float)depth;
+                        }
+                    }
+                } else if (mode == 2) {
+                    if (alpha > param) {
+                        out0[0] = (float)depth;
+                        return;
+                    }
+                } else if (mode == 3) {
+                    if (alpha > param) {
+                        out0[0] = alpha;
+                        return;
+                    }
+                } else if (mode == 4) {
+                    if (alpha > 0) {
+                        float sf[8];
+                        for (int i = 0; i < 8; ++i) sf[i] = (float)vc.surf[i];
+                        field_grad(sf, pos, out0);
+                        return;
+                    }
+                } else {
+                    if (alpha > param) {
+                        out0[sample_id] = (float)depth;
+                        out1[sample_id] = alpha;
+                        if (++sample_id >= max_sample) return;
+                    }
+                }
+            }
+        }
+        if ((mode == 0 || mode == 1) && expf(log_transmit) < o.stop_thresh) break;
+    }
+    if (mode == 0) out0[0] = outv;
+    if (mode == 1) out0[0] = (weight_acc > param) ? outv : 0.f;
+}
+
 }  // namespace
 
 extern "C" {
@@ -1739,6 +1832,21 @@ int oracle_volume_render_surface_fused(const oracle_grid* grid, const oracle_ray
         for (int c = 0; c < 3; ++c) gout[c] = (rgb_out[3 * q + c] - rgb_gt[3 * q + c]) * norm;
         legacy_backward(*grid, *opt, r, ray_vox->voxel_ls, ray_vox->vox_start_i[q], ray_vox->vox_num[q],
                         gout, rgb_out + 3 * q, sparsity_loss, *grads);
+    }
+    return 0;
+}
+
+int oracle_render_eval(const oracle_grid* grid, const oracle_rays* rays, const oracle_render_options* opt,
+                       int32_t mode, float param, int32_t max_sample, float* out0, float* out1) {
+    if (check_common(grid, rays, opt)) return -1;
+    if (mode < 0 || mode > 5 || !out0 || (mode == 5 && (!out1 || max_sample < 1))) return -1;
+    const int stride = (mode == 4) ? 3 : (mode == 5 ? max_sample : 1);
+#pragma omp parallel for schedule(dynamic, 64)
+    for (int64_t q = 0; q < rays->n_rays; ++q) {
+        Ray r;
+        setup_ray(*grid, *opt, rays->origins + 3 * q, rays->dirs + 3 * q, r);
+        eval_ray(*grid, *opt, r, mode, param, max_sample, out0 + (size_t)stride * q,
+                 out1 ? out1 + (size_t)stride * q : nullptr);
     }
     return 0;
 }

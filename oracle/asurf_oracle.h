@@ -156,6 +156,13 @@ int oracle_volume_render_surface_fused(const oracle_grid* grid, const oracle_ray
                                        float beta_loss, float sparsity_loss, float* rgb_out,
                                        const oracle_grads* grads);
 
+/* Evaluation renders, surf_trav.cu:564-1705 / 3944-4081: mode 0 expected depth, 1 mode depth
+ * (param = weight_thresh), 2 first-crossing depth (param = alpha threshold), 3 first-crossing
+ * alpha, 4 normal (out0[Q,3]), 5 extract_pts (param = alpha_thresh; out0/out1[Q,max_sample],
+ * zeroed by the caller). */
+int oracle_render_eval(const oracle_grid* grid, const oracle_rays* rays, const oracle_render_options* opt,
+                       int32_t mode, float param, int32_t max_sample, float* out0, float* out1);
+
 /* diagnostic: evaluate the legacy d f_k / d s_corner expression (render_util.cuh:1705-1775)
  * in float64 instead of the reference's float32 */
 void oracle_set_legacy_f64_surface_grad(int on);

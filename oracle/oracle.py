@@ -431,3 +431,24 @@ def surface_eikonal_grad_sparse(links, surface, rand_cells, scale, h, with_mask=
     _check(f(_i(links), size, _f(surface), _i(rc), rc.shape[0], _u8(mask) if with_mask else None, scale, h,
              _f(grad), C.byref(loss)), "surface_eikonal_grad_sparse")
     return grad, float(loss.value), mask
+
+
+EVAL_MODES = dict(expected=0, mode=1, sigma_thresh=2, alpha=3, normal=4, extract_pts=5)
+
+
+def render_eval(sc, origins, dirs, opts, what, param=0.0, max_sample=1):
+    """Evaluation renders (surf_trav.cu:3944-4081): returns out[Q] (out[Q,3] for 'normal';
+    (depths, alphas)[Q,max_sample] for 'extract_pts')."""
+    r = _rays(origins, dirs)
+    q = r.n_rays
+    mode = EVAL_MODES[what]
+    stride = 3 if mode == 4 else (max_sample if mode == 5 else 1)
+    out0 = np.zeros((q, stride), np.float32)
+    out1 = np.zeros((q, stride), np.float32) if mode == 5 else None
+    g, o = _grid(sc), make_opts(opts)
+    f = lib().oracle_render_eval
+    f.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_float, C.c_int32, c_f, c_f]
+    _check(f(C.byref(g), C.byref(r), C.byref(o), mode, param, max_sample, _f(out0), _f(out1)), "render_eval")
+    if mode == 5:
+        return out0, out1
+    return out0 if mode == 4 else out0[:, 0]

@@ -159,3 +159,24 @@ def surface_fused(sc, origins, dirs, ray_vox, opts, rgb_gt, beta_loss=0.0, spars
     _C.volume_render_surface_fused(g, r, rv, o, gt, beta_loss, sparsity_loss, rgb, gr)
     torch.cuda.synchronize()
     return rgb.cpu().numpy(), grads_np(gr)
+
+
+# ---- evaluation renders ----
+def render_eval(sc, origins, dirs, opts, what, param=0.0, max_sample=1):
+    g, r, o = grid_spec(sc), rays_spec(origins, dirs), opt_spec(opts)
+    if what == "expected":
+        out = _C.volume_render_expected_term_surf_trav(g, r, o)
+    elif what == "mode":
+        out = _C.volume_render_mode_term_surf_trav(g, r, o, param)
+    elif what == "sigma_thresh":
+        out = _C.volume_render_sigma_thresh_surf_trav(g, r, o, param)
+    elif what == "alpha":
+        out = _C.volume_render_alpha_surf_trav(g, r, o, param)
+    elif what == "normal":
+        out = _C.render_normal_surf_trav(g, r, o)
+    else:
+        d, a = _C.extract_pts_surf_trav(g, r, o, max_sample, param)
+        torch.cuda.synchronize()
+        return d.cpu().numpy(), a.cpu().numpy()
+    torch.cuda.synchronize()
+    return out.cpu().numpy()

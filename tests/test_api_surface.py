@@ -91,8 +91,8 @@ def test_svox2_alias_presents_the_reference_names():
     # out-of-scope entry points fail loudly and say where they belong
     with pytest.raises(NotImplementedError, match="N2"):
         g.inplace_tv_lumisphere_grad(None)
-    with pytest.raises(NotImplementedError, match="N3"):
-        g.volume_render_depth_image(None)
+    with pytest.raises(NotImplementedError, match="N4"):
+        g.resample(None)
     # the N2 regularisers of the live config are built (tests/test_reg_gpu.py)
     for name in ["inplace_tv_grad", "inplace_tv_surface_grad", "inplace_surface_normal_grad",
                  "inplace_surface_eikonal_grad", "inplace_alpha_surf_sparsify_grad", "inplace_tv_color_grad",
