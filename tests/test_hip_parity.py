@@ -338,11 +338,15 @@ def test_brick_skipping_is_exact(hip, monkeypatch):
         gt = rs.rand(o.shape[0], 3).astype(np.float32)
         opts = dict(OPTION_SETS["syn_yaml"], step_size=0.5)
         fused = dict(lambda_l2=1.0, lambda_l_entropy=1e-3)
-        monkeypatch.setenv("ASURF_DEBUG", "8")        # per-voxel walk only
-        rgb_ref, g_ref = hip.render_fused(sc, o, d, opts, gt, fused)
-        monkeypatch.delenv("ASURF_DEBUG")
-        rgb, g = hip.render_fused(sc, o, d, opts, gt, fused)
-        assert np.array_equal(rgb, rgb_ref), f"reso {reso}: {np.abs(rgb - rgb_ref).max()}"
-        assert (g["mask"] == g_ref["mask"]).all()
-        for k in ("sh", "density", "surface"):
-            grad_close(g[k], g_ref[k], 1e-5, f"reso {reso} grad_{k}")
+        # the cube, and a non-cubic crop of it whose sizes are not multiples of the brick edge
+        crop = dict(sc, links=np.ascontiguousarray(sc["links"][: reso - 5, : reso - 19, : reso // 2 + 3]))
+        for scene, extra in ((sc, {}), (crop, dict(near_clip=0.3)), (sc, dict(use_spheric_clip=True))):
+            op = dict(opts, **extra)
+            monkeypatch.setenv("ASURF_DEBUG", "8")        # per-voxel walk only
+            rgb_ref, g_ref = hip.render_fused(scene, o, d, op, gt, fused)
+            monkeypatch.delenv("ASURF_DEBUG")
+            rgb, g = hip.render_fused(scene, o, d, op, gt, fused)
+            assert np.array_equal(rgb, rgb_ref), f"reso {reso} {extra}: {np.abs(rgb - rgb_ref).max()}"
+            assert (g["mask"] == g_ref["mask"]).all()
+            for k in ("sh", "density", "surface"):
+                grad_close(g[k], g_ref[k], 1e-5, f"reso {reso} {extra} grad_{k}")
