@@ -57,7 +57,8 @@ k_eval(KGrid g, KOpt o, const float* __restrict__ origins, const float* __restri
     Walk w;
     walk_init(g, r, w);
     bool active = true;
-    while (active && !done) {
+    int guard = 4 * (g.size[0] + g.size[1] + g.size[2]) + 64;  // see k_walk
+    while (active && !done && --guard > 0) {
         const int kind = walk_hier<CLDS>(g, s_coarse, w, o.step_size, r.tmax, true);
         active = (w.t <= r.tmax);
         if (kind != 2) continue;

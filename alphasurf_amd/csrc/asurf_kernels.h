@@ -259,15 +259,19 @@ __device__ __forceinline__ int walk_hier(const KGrid& g, const unsigned int* lds
         w.cur_flag = (word >> (bz & 31)) & 1u;
         w.cur_lx = -1;
     }
-    const bool jump = allow_jump && w.straight && !w.cur_flag && (key != w.noskip_key);
-    const int m = jump ? 7 : 0;
+    // The cell: the whole brick if it holds no flagged voxel, else the voxel.  (Finer empty cells
+    // read off the slab word -- 1x8x8 slabs, 1x4x4 quadrants -- were measured: the word load moves
+    // onto the critical path of every step and the walk gets slower.)
+    int cell_x = 0, cell_yz = 0;  // half-extent masks of the cell along x and along y/z
+    if (allow_jump && w.straight && !w.cur_flag && key != w.noskip_key) cell_x = cell_yz = 7;
+    const bool jump = (cell_x | cell_yz) != 0;
     const int sx = w.sx, sy = w.sy, sz = w.sz;
     const int l0 = w.lim0, l1 = w.lim1, l2 = w.lim2;
     const float ox = w.ox, oy = w.oy, oz = w.oz, dx = w.dx, dy = w.dy, dz = w.dz;
     // last voxel of the cell in the direction of travel, per axis, and the time it is left
-    const int ex = (sx > 0) ? min(nx | m, l0 - 1) : (nx & ~m);
-    const int ey = (sy > 0) ? min(ny | m, l1 - 1) : (ny & ~m);
-    const int ez = (sz > 0) ? min(nz | m, l2 - 1) : (nz & ~m);
+    const int ex = (sx > 0) ? min(nx | cell_x, l0 - 1) : (nx & ~cell_x);
+    const int ey = (sy > 0) ? min(ny | cell_yz, l1 - 1) : (ny & ~cell_yz);
+    const int ez = (sz > 0) ? min(nz | cell_yz, l2 - 1) : (nz & ~cell_yz);
     const float Tx = plane_time(ex, sx, ox, dx);
     const float Ty = plane_time(ey, sy, oy, dy);
     const float Tz = plane_time(ez, sz, oz, dz);
@@ -280,16 +284,20 @@ __device__ __forceinline__ int walk_hier(const KGrid& g, const unsigned int* lds
         const float px = fmaf(T, dx, ox), py = fmaf(T, dy, oy), pz = fmaf(T, dz, oz);
         const float fx = floorf(px), fy = floorf(py), fz = floorf(pz);
         const float kEps = 1.f / 64.f;
-        const bool mx = a0 || ((px - fx) > kEps && (px - fx) < 1.f - kEps);
-        const bool my = a1 || ((py - fy) > kEps && (py - fy) < 1.f - kEps);
-        const bool mz = a2 || ((pz - fz) > kEps && (pz - fz) < 1.f - kEps);
+        const bool far_x = a0 || ((px - fx) > kEps && (px - fx) < 1.f - kEps);
+        const bool far_y = a1 || ((py - fy) > kEps && (py - fy) < 1.f - kEps);
+        const bool far_z = a2 || ((pz - fz) > kEps && (pz - fz) < 1.f - kEps);
         cx = (int)fx;
         cy = (int)fy;
         cz = (int)fz;
-        // (with the margins met the other axes are inside the brick and have not moved backwards:
-        // at T the ray is still inside the brick on them, and it is 1/64 away from every plane)
-        const bool ok = mx && my && mz && (T <= tmax) && !(T + step_size > tmax);
-        if (!ok) {
+        // the other axes must land inside the cell and not behind the current voxel: while the
+        // ray is still approaching the grid (indices clamped by walk_init) its position is not
+        // inside the voxel the state names
+        const bool rx = a0 || (((cx ^ nx) & ~cell_x) == 0 && (cx - nx) * sx >= 0);
+        const bool ry = a1 || (((cy ^ ny) & ~cell_yz) == 0 && (cy - ny) * sy >= 0);
+        const bool rz = a2 || (((cz ^ nz) & ~cell_yz) == 0 && (cz - nz) * sz >= 0);
+        const bool ok = far_x && far_y && far_z && rx && ry && rz && (T <= tmax) && !(T + step_size > tmax);
+        if (!ok) {  // walk this brick voxel by voxel
             w.noskip_key = key;
             return 0;
         }

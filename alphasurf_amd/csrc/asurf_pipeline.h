@@ -115,7 +115,10 @@ k_walk(KGrid g, KOpt o, const float* __restrict__ origins, const float* __restri
         walk_init(g, r, w);
         bool active = true;
         const bool jump = !(o.debug & 8);
-        while (active) {
+        // every iteration either advances one axis or is a refused jump followed by such a step; the
+        // guard only exists so that no defect in the walk can keep a wave alive
+        int guard = 4 * (g.size[0] + g.size[1] + g.size[2]) + 64;
+        while (active && --guard > 0) {
             const int kind = walk_hier<CLDS>(g, s_coarse, w, o.step_size, r.tmax, jump);
             active = (w.t <= r.tmax);
             if (kind == 2) {
@@ -144,7 +147,8 @@ k_walk(KGrid g, KOpt o, const float* __restrict__ origins, const float* __restri
                 bool active = true;
                 int k = 0;
                 const bool jump = !(o.debug & 8);
-                while (active) {
+                int guard = 4 * (g.size[0] + g.size[1] + g.size[2]) + 64;
+                while (active && --guard > 0) {
                     const bool hit = walk_hier<CLDS>(g, s_coarse, w, o.step_size, r.tmax, jump) == 2;
                     active = (w.t <= r.tmax);
                     if (hit) {

@@ -333,8 +333,20 @@ def test_brick_skipping_is_exact(hip, monkeypatch):
         o3 = world(rs.randint(0, reso, size=(600, 3)) + np.array([-2.0 * reso, 0.25, 0.5])).astype(np.float32)
         d3 = np.tile(np.array([[1.0, 0.0, 0.0]], np.float32), (600, 1))
         d3[300:] = np.array([0.6, 0.8, 0.0], np.float32)
-        o = np.concatenate([o1, o2, o3]).astype(np.float32)
-        d = np.concatenate([d1, d2, d3]).astype(np.float32)
+        # rays that enter the [-0.5, R-0.5] box outside the voxel range on another axis (walk_init
+        # clamps the index there: the state names a voxel the ray has not reached yet)
+        m = 2000
+        ent = np.stack([np.full(m, -0.5), rs.uniform(-0.5, 0.0, m), rs.uniform(0, reso, m)], 1)
+        ent[m // 2:, 1] = rs.uniform(reso - 1.0, reso - 0.5, m - m // 2)
+        dd = np.stack([np.ones(m), rs.uniform(0.02, 0.6, m), rs.uniform(-0.5, 0.5, m)], 1)
+        dd[m // 2:, 1] *= -1.0
+        perm = rs.permutation(3)                     # any axis as the entry axis
+        ent, dd = ent[:, perm], dd[:, perm]
+        dd /= np.linalg.norm(dd, axis=1, keepdims=True)
+        o4 = world(ent - 5.0 * dd).astype(np.float32)
+        d4 = dd.astype(np.float32)
+        o = np.concatenate([o1, o2, o3, o4]).astype(np.float32)
+        d = np.concatenate([d1, d2, d3, d4]).astype(np.float32)
         gt = rs.rand(o.shape[0], 3).astype(np.float32)
         opts = dict(OPTION_SETS["syn_yaml"], step_size=0.5)
         fused = dict(lambda_l2=1.0, lambda_l_entropy=1e-3)
