@@ -236,7 +236,7 @@ __device__ __forceinline__ bool walk_test(const KGrid& g, const unsigned int* ld
 //   * the cell is left through the axis with the smallest exit time T (ties: lowest axis, as in
 //     walk_step); for a voxel cell these are exactly walk_step's far-plane times;
 //   * for a brick cell the voxel index on the other two axes at T is floor(o + T d), PROVIDED
-//     that position is not within 1/64 of a voxel plane: the float error of o + T d and of the
+//     that position is not within 1/256 of a voxel plane: the float error of o + T d and of the
 //     plane times is < 1e-3 voxel at grid sizes <= 1024, so which crossings precede T is decided
 //     without ambiguity.  Otherwise, and near the end of the ray (where the backward's step_size
 //     quirk looks at individual voxels), the brick is walked voxel by voxel.
@@ -283,7 +283,9 @@ __device__ __forceinline__ int walk_hier(const KGrid& g, const unsigned int* lds
     if (jump) {
         const float px = fmaf(T, dx, ox), py = fmaf(T, dy, oy), pz = fmaf(T, dz, oz);
         const float fx = floorf(px), fy = floorf(py), fz = floorf(pz);
-        const float kEps = 1.f / 64.f;
+        // t <= ~2000 and |d| <= 1 at grid sizes <= 1024: T, o + T d and the plane times each carry
+        // < 2.5e-4 voxel of float error, 6e-4 together; 1/256 leaves a 6x margin
+        const float kEps = 1.f / 256.f;
         const bool far_x = a0 || ((px - fx) > kEps && (px - fx) < 1.f - kEps);
         const bool far_y = a1 || ((py - fy) > kEps && (py - fy) < 1.f - kEps);
         const bool far_z = a2 || ((pz - fz) > kEps && (pz - fz) < 1.f - kEps);
