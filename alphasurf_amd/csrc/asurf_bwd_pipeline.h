@@ -8,14 +8,18 @@
 //   k_bwd_seq : one RAY per lane -- the running quantities (transmittance, `accum`, the sample
 //               index of the fused losses, stop_thresh) and every term that needs the ray's
 //               sample cache; emits per sample: weight, dL/dcolour per channel, the first part
-//               of dL/d(rwalpha) and of dL/dt.
-//   k_bwd_sh  : one SAMPLE per wave step, lanes = (corner, SH coefficient) -- row-contiguous
-//               atomics into grad_sh and the d/dpos of the colour; no dependence between
-//               samples any more, so many waves keep their gathers in flight.
-//   k_bwd_geo : one SAMPLE per lane -- reloads the voxel, re-solves the cubic, finishes
-//               dL/d(raw alpha) and dL/dt, root gradient, density / surface scatter.
+//               of dL/d(rwalpha) and of dL/dt; appends the visited (record, ray) cells to a dense
+//               list, record-major within a wave (neighbouring entries = neighbouring rays).
+//   k_bwd_sh  : one SAMPLE per wave step over that list, lanes = (corner, SH coefficient) --
+//               contributions of consecutive samples in the same voxel are summed in registers
+//               and flushed with row-contiguous atomics into grad_sh; d/dpos of the colour from
+//               the voxel's SH rows held in registers.
+//   k_bwd_geo : one SAMPLE per lane over the list -- reloads the voxel, classifies the cubic
+//               (the forward stored the position), finishes dL/d(raw alpha) and dL/dt, root
+//               gradient; a segmented shuffle reduction merges the density / surface
+//               contributions of neighbouring lanes in the same voxel before the scatter.
 //
-// Grid of the last two: (ceil(Q/256), R): block row r handles record r of 256 consecutive rays.
+// The last two are launched with a fixed grid of kListBlocks blocks that stride over the list.
 #pragma once
 #include "asurf_kernels.h"
 #include "asurf_pipeline.h"

@@ -76,7 +76,7 @@ __device__ inline int solve_cubic_legacy(double f0, double f1, double f2, double
     const double f = ((3 * c) - sqrd(b)) / 3;
     const double g = ((2 * cubd(b)) - (9 * b * c) + (27 * d)) / 27;
     const double h = sqrd(g) / 4 + cubd(f) / 27;
-    if ((fabs(f) < eps) & (fabs(g) < eps) & (fabs(h) < eps)) {
+    if ((fabs(f) < eps) && (fabs(g) < eps) && (fabs(h) < eps)) {
         st[0] = cond_cbrt(d);
         return CUBIC_ONE_R;
     }

@@ -1,13 +1,16 @@
 // asurf_pipeline.h -- the forward pass as three dense kernels (gfx950, wave64).
 //
-//   k_walk : one ray per lane, nothing but the DDA + occupancy-bit tests (few registers, many
-//            waves per SIMD).  The first C1 work voxels of a ray go to a lane-coalesced table
-//            [C1][Q]; a ray with more re-walks once and appends the rest to a contiguous slice
-//            of a global spill list, so rays of any length stay on this path.
-//   k_geom : one WORK VOXEL per lane -- every lane of a wave is busy no matter how the work
-//            voxels are spread over rays.  Gathers the 8 corners, forms and solves the cubic
-//            (f64), validates the roots and leaves up to 3 sample candidates per voxel in a
-//            sharded pool.  Launched twice: over the table and over the spill list.
+//   k_walk : one ray per lane, nothing but the hierarchical DDA (walk_hier: empty 8^3 bricks are
+//            left in one step) + occupancy-bit tests (few registers, many waves per SIMD).  The
+//            first C1 work voxels of a ray go to a lane-coalesced table [C1][Q]; a ray with more
+//            re-walks once and appends the rest to a contiguous slice of a global spill list, so
+//            rays of any length stay on this path.  The occupied (slot, ray) cells of the table are
+//            also appended to a dense list (slot-major within a wave).
+//   k_geom : one WORK VOXEL per lane, a fixed grid of kListBlocks blocks striding over the dense
+//            list (and, in a second launch, over the spill list): every lane is busy no matter how
+//            the work voxels are spread over rays, and no block is dispatched only to exit.
+//            Gathers the 8 corners, forms and solves the cubic (f64), validates the roots and
+//            leaves up to 3 sample candidates per voxel in a sharded pool.
 //   k_comp : one ray per lane again, for what is inherently sequential along a ray: the
 //            sigma gate, truncation window, compositing, the sample cache of the fused losses
 //            and the records the replaying backward kernel consumes.  Shading stays
