@@ -20,6 +20,7 @@
 #include "asurf_legacy.h"
 #include "asurf_reg.h"
 #include "asurf_eval.h"
+#include "asurf_misc.h"
 
 namespace {
 
@@ -992,6 +993,43 @@ int asurf_render_eval_surf_trav(const asurf_grid* grid, const asurf_rays* rays,
         case 4: return launch_eval<EVAL_NORMAL>(L, rays, param, max_sample, out0, out1);
         default: return launch_eval<EVAL_EXTRACT>(L, rays, param, max_sample, out0, out1);
     }
+}
+
+// ---- grid maintenance (asurf_misc.h) ----
+int asurf_dilate(const uint8_t* grid, const int32_t size[3], uint8_t* out, void* stream) {
+    if (!grid || !out || !size) return fail(ASURF_E_INVALID, "dilate: NULL tensor");
+    const long long n = (long long)size[0] * size[1] * size[2];
+    if (size[0] < 1 || size[1] < 1 || size[2] < 1 || n >= (1ll << 31)) return fail(ASURF_E_INVALID, "dilate: bad shape");
+    hipLaunchKernelGGL(k_dilate, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       grid, out, size[0], size[1], size[2]);
+    return launch_error("k_dilate");
+}
+
+size_t asurf_accel_dist_prop_tmp_bytes(const int32_t size[3]) {
+    if (!size) return 0;
+    long long sx = size[0], sy = size[1], sz = size[2], req = 0;
+    while (sx > 1 && sy > 1 && sz > 1) {
+        sx = div2_ceil((int)sx);
+        sy = div2_ceil((int)sy);
+        sz = div2_ceil((int)sz);
+        req += sx * sy * sz;
+    }
+    return (size_t)req;
+}
+
+int asurf_accel_dist_prop(int32_t* links, const int32_t size[3], uint8_t* tmp, size_t tmp_bytes, void* stream) {
+    if (!links || !size) return fail(ASURF_E_INVALID, "accel_dist_prop: NULL tensor");
+    const long long n = (long long)size[0] * size[1] * size[2];
+    if (size[0] < 1 || size[1] < 1 || size[2] < 1 || n >= (1ll << 31))
+        return fail(ASURF_E_INVALID, "accel_dist_prop: bad shape");
+    const size_t need = asurf_accel_dist_prop_tmp_bytes(size);
+    if (need > 0 && (!tmp || tmp_bytes < need))
+        return fail(ASURF_E_WORKSPACE, "accel_dist_prop: tmp of %zu bytes needed", need);
+    const dim3 grid_dim((unsigned)((n + 255) / 256));
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    hipLaunchKernelGGL((k_accel_dist<true>), grid_dim, dim3(256), 0, s, links, tmp, size[0], size[1], size[2]);
+    hipLaunchKernelGGL((k_accel_dist<false>), grid_dim, dim3(256), 0, s, links, tmp, size[0], size[1], size[2]);
+    return launch_error("k_accel_dist");
 }
 
 }  // extern "C"

@@ -23,7 +23,7 @@ __all__ = [
     "alpha_surf_sparsify_grad_sparse", "surface_eikonal_grad_sparse",
     "volume_render_expected_term_surf_trav", "volume_render_mode_term_surf_trav",
     "volume_render_sigma_thresh_surf_trav", "volume_render_alpha_surf_trav", "render_normal_surf_trav",
-    "extract_pts_surf_trav",
+    "extract_pts_surf_trav", "dilate", "accel_dist_prop",
     "volume_render_surface_fused", "test_cubic_root_grad", "sample_grid", "rmsprop_step", "sgd_step",
 ]
 
@@ -658,6 +658,30 @@ def extract_pts_surf_trav(grid, rays, opt, max_sample, alpha_thresh):
     if int(max_sample) < 1:
         raise RuntimeError("extract_pts_surf_trav: max_sample must be >= 1")
     return _render_eval(grid, rays, opt, 5, alpha_thresh, int(max_sample))
+
+
+# ---- grid maintenance (misc_kernel.cu) ----
+def dilate(grid):
+    """Tensor dilate(Tensor bool[X,Y,Z]) -- misc_kernel.cu:1005-1020."""
+    _check_input(grid, "grid", torch.bool)
+    if grid.dim() != 3:
+        raise RuntimeError("dilate: grid must be 3-D")
+    out = torch.empty_like(grid)
+    with torch.cuda.device(grid.device):
+        _L.check(_L.lib().asurf_dilate(_ptr(grid), (C.c_int32 * 3)(*grid.shape), _ptr(out), _stream(grid.device)))
+    return out
+
+
+def accel_dist_prop(links):
+    """void accel_dist_prop(Tensor int32[X,Y,Z]) in place -- misc_kernel.cu:1022-1061."""
+    _check_input(links, "links", torch.int32)
+    if links.dim() != 3:
+        raise RuntimeError("accel_dist_prop: links must be 3-D")
+    size = (C.c_int32 * 3)(*links.shape)
+    with torch.cuda.device(links.device):
+        nb = int(_L.lib().asurf_accel_dist_prop_tmp_bytes(size))
+        tmp = torch.zeros(max(nb, 1), dtype=torch.uint8, device=links.device)
+        _L.check(_L.lib().asurf_accel_dist_prop(_ptr(links), size, _ptr(tmp), nb, _stream(links.device)))
 
 
 def sample_grid(*args, **kwargs):

@@ -488,6 +488,66 @@ class SparseGrid(nn.Module):
                  for s in range(0, camera.height * camera.width, batch_size)]
         return torch.cat(parts, dim=0).view(camera.height, camera.width, -1)
 
+    # ---- grid maintenance (:2859-2957, 4483-4490 -> misc_kernel.cu) ----
+    def accelerate(self):
+        """Distance-encode the empty links for empty-space skipping (:4483-4490).  The surf_trav
+        kernels only test the sign of a link (the reference compiles its own use of the distances
+        out, surf_trav.cu:31), so rendering is unchanged by it."""
+        assert self.links.is_cuda, "the HIP extension is required for accelerate"
+        _C.accel_dist_prop(self.links)
+
+    def safe_fetch_data(self, xyz, data, default=0):
+        """data rows at integer grid coordinates, `default` outside the grid / at empty links (:2859-2872)."""
+        out = torch.full([xyz.shape[0], data.shape[-1]], default, device=data.device, dtype=data.dtype)
+        shape = torch.tensor(self.links.shape, device=xyz.device)
+        inside = (xyz >= 0).all(dim=-1) & (xyz < shape[None, :]).all(dim=-1)
+        x, y, z = xyz[inside].unbind(-1)
+        links = self.links[x, y, z]
+        valid = links >= 0
+        idx = torch.arange(out.shape[0], device=data.device)[inside][valid]
+        out[idx] = data[links[valid].long(), :]
+        return out
+
+    def prune_grid(self, density_raw_thres=1, dilate=2, prune_surf=True):
+        """Keep the vertices whose raw opacity exceeds the threshold and (prune_surf) whose surface value
+        changes sign against one of its 26 neighbours, dilated `dilate` times; renumber the rows in
+        raster order (:2874-2957).  Returns the kept fraction."""
+        with torch.no_grad():
+            device = self.density_data.device
+            reso = tuple(self.links.shape)
+            ax = [torch.arange(r, device=device) for r in reso]
+            coords = torch.stack(torch.meshgrid(*ax, indexing="ij"), dim=-1).view(-1, 3)
+            density = self.safe_fetch_data(coords, self.density_data.data)
+            sh = self.safe_fetch_data(coords, self.sh_data.data)
+            valid = (density > density_raw_thres).view(reso)
+            surface = None
+            if self.surface_data is not None:
+                surface = self.safe_fetch_data(coords, self.surface_data.data)
+                if prune_surf:
+                    off = torch.tensor([-1, 0, 1], device=device)
+                    offsets = torch.stack(torch.meshgrid(off, off, off, indexing="ij"), dim=-1).view(-1, 3)
+                    crossing = torch.zeros_like(coords[:, :1]).bool()
+                    for i in range(offsets.shape[0]):
+                        nb = self.safe_fetch_data(coords + offsets[i, None, :], self.surface_data.data)
+                        crossing |= (surface == 0) | (nb == 0) | (torch.sign(surface) != torch.sign(nb))
+                    valid &= crossing.view(reso)
+            for _ in range(int(dilate)):
+                valid = _C.dilate(valid.contiguous())
+            valid = valid.view(-1)
+            self.density_data = nn.Parameter(density[valid])
+            self.sh_data = nn.Parameter(sh[valid])
+            if surface is not None:
+                self.surface_data = nn.Parameter(surface[valid])
+            links = torch.cumsum(valid.to(torch.int32), dim=-1).int() - 1
+            links[~valid] = -1
+            self.links = links.view(reso).contiguous()
+            self.density_rms = self.surface_rms = self.sh_rms = None
+            self.sparse_grad_indexer = self.sparse_sh_grad_indexer = None
+            self._data_to_links = None
+            kept = float(torch.count_nonzero(valid).item()) / valid.numel()
+            self.accelerate()
+            return kept
+
     # ---- evaluation renders (:3693-3961 -> surf_trav.cu:3944-4081) ----
     def _eval_backend(self, kwargs):
         if kwargs.get("no_surface", False):

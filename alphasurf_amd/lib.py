@@ -90,7 +90,7 @@ EXPORTS = [
     "asurf_rmsprop_step", "asurf_sgd_step", "asurf_ray_voxel_count", "asurf_ray_voxel_fill",
     "asurf_tv_grad_sparse", "asurf_surf_tv_grad_sparse", "asurf_surface_normal_grad_sparse",
     "asurf_alpha_surf_sparsify_grad_sparse", "asurf_surface_eikonal_grad_sparse",
-    "asurf_render_eval_surf_trav",
+    "asurf_render_eval_surf_trav", "asurf_dilate", "asurf_accel_dist_prop_tmp_bytes", "asurf_accel_dist_prop",
 ]
 
 _lib = None
@@ -137,6 +137,10 @@ def lib():
                                                             fl, vp, vp, vp]
         L.asurf_surface_eikonal_grad_sparse.argtypes = [vp, vp, vp, vp, i64, vp, fl, fl, vp, vp, vp]
         L.asurf_render_eval_surf_trav.argtypes = [vp, vp, vp, i32, fl, i32, vp, vp, vp, C.c_size_t, vp]
+        L.asurf_dilate.argtypes = [vp, vp, vp, vp]
+        L.asurf_accel_dist_prop_tmp_bytes.restype = C.c_size_t
+        L.asurf_accel_dist_prop_tmp_bytes.argtypes = [vp]
+        L.asurf_accel_dist_prop.argtypes = [vp, vp, vp, C.c_size_t, vp]
         if L.asurf_abi_version() != 1:
             raise RuntimeError("libasurf_hip.so ABI version mismatch")
         _lib = L

@@ -302,6 +302,16 @@ int asurf_surface_eikonal_grad_sparse(const int32_t* links, const int32_t size[3
                                       int64_t n_cells, uint8_t* mask_out, float scale, float h,
                                       float* grad_data, float* loss_out, void* stream);
 
+/* Grid maintenance.
+ *   dilate           svox2.cpp REG dilate, misc_kernel.cu:24-58, 1005-1020: 3x3x3 dilation of a bool grid.
+ *   accel_dist_prop  misc_kernel.cu:113-180, 1022-1061: every empty link becomes -(1 + levels of the
+ *                    power-of-two pyramid that are still empty around it); `tmp` is scratch of
+ *                    asurf_accel_dist_prop_tmp_bytes(size) bytes, ZEROED by the caller. */
+int asurf_dilate(const uint8_t* grid, const int32_t size[3], uint8_t* out, void* stream);
+size_t asurf_accel_dist_prop_tmp_bytes(const int32_t size[3]);
+int asurf_accel_dist_prop(int32_t* links, const int32_t size[3], uint8_t* tmp, size_t tmp_bytes,
+                          void* stream);
+
 /* Measurement hooks (no reference counterpart; used by bench.py).  When enabled, the
  * surf_trav launchers record a hipEvent on the call's stream after every kernel launch.
  * asurf_profile_read() waits for the last call and returns, in milliseconds,
