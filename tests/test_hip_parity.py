@@ -362,3 +362,50 @@ def test_brick_skipping_is_exact(hip, monkeypatch):
             assert (g["mask"] == g_ref["mask"]).all()
             for k in ("sh", "density", "surface"):
                 grad_close(g[k], g_ref[k], 1e-5, f"reso {reso} {extra} grad_{k}")
+
+
+def test_random_option_fuzz(hip, oracle):
+    """Randomised sweep over scenes, options and loss weights: every draw must agree with the
+    oracle (RGB, gradients, masks).  Seeds are fixed; each draw is printed on failure."""
+    from alphasurf_amd import synth
+    rs = np.random.RandomState(2024)
+    for it in range(24):
+        reso = int(rs.choice([24, 40, 57, 72]))
+        B = int(rs.choice([1, 4, 9, 16]))
+        lv = tuple(sorted(rs.uniform(-0.6, 0.6, size=int(rs.choice([1, 1, 2, 3]))).tolist()))
+        sc = synth.make_sparse_scene(reso, B, seed=int(rs.randint(1000)), band=float(rs.uniform(1.5, 4.0)),
+                                     dilate=int(rs.randint(0, 3)), level_set=lv,
+                                     trunc_a=float(rs.uniform(1.0, 6.0)),
+                                     fake_sample_std=float(rs.uniform(0.3, 1.5)))
+        o, d = synth.random_rays(1500, int(rs.randint(1000)))
+        opts = dict(
+            sigma_thresh=float(rs.choice([-1e4, -3.0, 0.3, 0.5])), stop_thresh=float(rs.choice([-1e4, 0.0, 1e-7, 1e-2])),
+            step_size=float(rs.choice([0.01, 0.5, 2.0])), near_clip=float(rs.choice([0.0, 0.0, 0.2])),
+            use_spheric_clip=bool(rs.rand() < 0.2), alpha_activation_type=int(rs.randint(0, 2)),
+            only_outward_intersect=bool(rs.rand() < 0.5), truncated_vol_render=bool(rs.rand() < 0.6),
+            trunc_vol_weight_min=float(rs.choice([0.0, 1e-10, 0.05])), surf_fake_sample=bool(rs.rand() < 0.5),
+            surf_fake_sample_min_vox_len=float(rs.choice([0.0, 0.05, 0.3])), limited_fake_sample=bool(rs.rand() < 0.5),
+            fake_sample_l_dist=bool(rs.rand() < 0.5), fake_sample_normalize_surf=bool(rs.rand() < 0.5),
+            no_surf_grad_from_sh=bool(rs.rand() < 0.2), background_brightness=float(rs.choice([0.0, 0.5, 1.0])))
+        fused = dict(lambda_l2=float(rs.rand()), lambda_l1=float(rs.rand()))
+        for k, hi in (("lambda_l_entropy", 0.05), ("lambda_l_dist", 0.05), ("lambda_l_dist_a", 0.05),
+                      ("lambda_l_entropy_a", 0.02), ("lambda_l_samp_dist", 0.05), ("lambda_conv_mode_samp", 1e-3),
+                      ("sparsity_loss", 0.01), ("lambda_inwards_norm_loss", 0.01), ("lambda_l_di", 0.01),
+                      ("lambda_inplace_surf_sparse", 1e-3)):
+            if rs.rand() < 0.3:
+                fused[k] = float(rs.uniform(0.1, 1.0) * hi)
+        fused["l_di_alpha_thresh"] = 0.5
+        fused["surf_sparse_alpha_thresh"] = 0.5
+        fused["no_norm_weight_l_entropy"] = bool(rs.rand() < 0.5)
+        fused["l_dist_max_sample"] = int(rs.choice([2, 8, 64]))
+        gt = rs.rand(o.shape[0], 3).astype(np.float32)
+        tag = f"draw {it}: reso {reso} B {B} lv {lv} opts {opts} fused {fused}"
+        rgb, g = hip.render_fused(sc, o, d, opts, gt, fused)
+        rgb_o, go, st = oracle.render_fused(sc, o, d, opts, gt, fused)
+        assert np.abs(rgb - rgb_o).max() <= RGB_TOL_ORACLE, tag
+        for k in ("sh", "density", "surface"):
+            if np.abs(go[k]).max() > 0:
+                grad_close(g[k], go[k], 3e-4, tag + f" grad_{k}")
+        scale = max(abs(float(go["fake_sample_std"][0])), float(np.abs(go["density"]).max()), 1e-12)
+        assert abs(float(g["fake_sample_std"][0]) - float(go["fake_sample_std"][0])) <= 1e-2 * scale, tag
+        assert (g["mask"].astype(bool) == go["mask"].astype(bool)).all(), tag
