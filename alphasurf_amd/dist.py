@@ -17,16 +17,27 @@ def _world(group):
     return dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
 
 
+def _reduce(t, op, group):
+    """all_reduce in place; with the gloo backend (CPU tests, rehearsals) device tensors go
+    through host memory."""
+    if t.is_cuda and dist.get_backend(group) == "gloo":
+        h = t.cpu()
+        dist.all_reduce(h, op=op, group=group)
+        t.copy_(h)
+    else:
+        dist.all_reduce(t, op=op, group=group)
+
+
 def all_reduce_dense(tensors, mask=None, group=None):
     """Plain sum all-reduce of every gradient buffer + OR of the mask."""
     if _world(group) == 1:
         return
     for t in tensors:
         if t is not None:
-            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+            _reduce(t, dist.ReduceOp.SUM, group)
     if mask is not None:
         m8 = mask.view(torch.uint8) if mask.dtype == torch.bool else mask
-        dist.all_reduce(m8, op=dist.ReduceOp.MAX, group=group)
+        _reduce(m8, dist.ReduceOp.MAX, group)
 
 
 def all_reduce_sparse(tensors, mask, group=None):

@@ -80,8 +80,12 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        # ASURF_DIST_BACKEND=gloo: rehearsal of the N > 1 control flow on fewer GPUs than ranks
+        # (ranks share devices, the exchange goes through host memory); never used for results
+        backend = os.environ.get("ASURF_DIST_BACKEND", "nccl")  # "nccl" is RCCL on ROCm
+        local_rank = local_rank % torch.cuda.device_count() if backend != "nccl" else local_rank
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl")  # RCCL on ROCm
+        dist.init_process_group(backend)
     dev = torch.device("cuda", local_rank if world > 1 else 0)
     torch.cuda.set_device(dev)
 
@@ -132,7 +136,7 @@ def main():
     M = F["l_dist_max_sample"]
     Q_global = Q * world
 
-    def step(counters=None):
+    def step(counters=None, exchange=True):
         gr.mask_out.zero_()  # the reference allocates a fresh sparse_grad_indexer per call (svox2.py:3535)
         if world > 1:
             # the exchange sums whatever the buffers hold, so they must hold this step only
@@ -145,7 +149,7 @@ def main():
             F["lambda_l_entropy"], False, 0.0, 0.0, 0.0, 0.0, F["l_di_alpha_thresh"],
             F["surf_sparse_alpha_thresh"], 0.0, 0.0, F["lambda_conv_mode_samp"], M, rgb, gr,
             global_n_rays=Q_global, counters=counters)
-        if world > 1:
+        if world > 1 and exchange:
             # data-parallel exchange: sum of per-shard gradients == gradient of the global batch.
             # A view touches ~20 % of the rows here, so the dense ring all-reduce is chosen
             # (alphasurf_amd/dist.py switches to the sparse all-to-all below 1/8).
@@ -167,7 +171,7 @@ def main():
     dt = time.perf_counter() - t0
     if world > 1:
         tt = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        adist._reduce(tt, dist.ReduceOp.MAX, None)
         dt = float(tt.item())
     ms_per_step = dt / args.steps * 1e3
     value = Q_global / (dt / args.steps) / 1e6
@@ -176,7 +180,7 @@ def main():
     if rank == 0:
         # ---- counters (V_t, V_a, S) and per-kernel HIP-event times, outside the timed region ----
         cnt = torch.zeros(4, dtype=torch.int64, device=dev)
-        step(cnt)
+        step(cnt, exchange=False)   # rank 0 only: no collective here
         torch.cuda.synchronize()
         v_t, v_a, s_cnt, n_r = [int(x) for x in cnt.cpu().tolist()]
         _lib.profile_enable(True)
