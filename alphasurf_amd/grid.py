@@ -548,6 +548,53 @@ class SparseGrid(nn.Module):
             self.accelerate()
             return kept
 
+    def init_surface_from_density(self, density_lvs=[0.5], reset_alpha=False, alpha_rescale=None,
+                                  surface_rescale=0.1, alpha_clip_thresh=1e-6, reset_all=False,
+                                  prune_threshold=1e-8, dilate=2, init_type="density", weight_init_cams=None,
+                                  visibility_pruning_scale=0, mask_pruning_rays=None, zero_lv_density=None):
+        """Start the surface field from a trained density grid (:2958-3227), `init_type='density'` with the
+        exponential activation (the live configuration, opt.py:458-475): surface = density - level, pruned,
+        then rescaled so that the mean forward-difference gradient norm is 1 (an SDF-like scale); the level
+        sets are shifted and rescaled with it.  The weight / visibility / mask-pruning variants need the
+        sparse_grid_*_render kernels (N4, not built)."""
+        if init_type != "density" or visibility_pruning_scale > 0 or mask_pruning_rays is not None:
+            _next_row("N4", "init_surface_from_density with weight / visibility / mask pruning")
+        if self.opt.alpha_activation_type == CONSTANTS["SIGMOID_FN"]:
+            raise NotImplementedError("init_surface_from_density: the reference raises for the sigmoid "
+                                      "activation as well (svox2.py:3016)")
+        with torch.no_grad():
+            if zero_lv_density is None:
+                zero_lv_density = density_lvs[len(density_lvs) // 2]
+            device = self.density_data.device
+            self.level_set_data = torch.tensor(density_lvs, device=device, dtype=torch.float32) - zero_lv_density
+            self.surface_type = CONSTANTS["SURFACE_TYPE_SDF"] if self.surface_type == CONSTANTS["SURFACE_TYPE_NONE"] \
+                else self.surface_type
+            self.surface_data = nn.Parameter((self.density_data.detach().clone() - zero_lv_density).to(torch.float32))
+            if "surface_data" not in self.trainable_data:
+                self.trainable_data.append("surface_data")
+            self.prune_grid(prune_threshold, dilate, prune_surf=False)
+            # mean |forward difference| / h over the cells whose +x, +y, +z neighbours exist
+            cells = self._get_rand_cells_non_empty(1, contiguous=True).long()
+            sx, sy, sz = self.links.shape
+            z = cells % sz
+            y = (cells // sz) % sy
+            x = cells // (sz * sy)
+            inner = ~((x >= sx - 1) | (y >= sy - 1) | (z >= sz - 1))
+            x, y, z = x[inner], y[inner], z[inner]
+            l000, l100 = self.links[x, y, z], self.links[x + 1, y, z]
+            l010, l001 = self.links[x, y + 1, z], self.links[x, y, z + 1]
+            ok = ~((l000 < 0) | (l100 < 0) | (l010 < 0) | (l001 < 0))
+            s = self.surface_data.data
+            s0 = s[l000[ok].long()]
+            h = self._get_h()
+            norm_grad = torch.sqrt(((s[l100[ok].long()] - s0) / h) ** 2 + ((s[l010[ok].long()] - s0) / h) ** 2 +
+                                   ((s[l001[ok].long()] - s0) / h) ** 2)
+            scale = norm_grad.mean()
+            self.surface_data.data = self.surface_data.data / scale
+            self.level_set_data = self.level_set_data / scale
+            if alpha_rescale is not None:
+                self.density_data.data *= alpha_rescale
+
     # ---- evaluation renders (:3693-3961 -> surf_trav.cu:3944-4081) ----
     def _eval_backend(self, kwargs):
         if kwargs.get("no_surface", False):

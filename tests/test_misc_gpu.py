@@ -106,3 +106,49 @@ def test_prune_grid_keeps_the_picture(env):
     assert int(grid.links.min()) < -1            # accelerate() ran
     after = grid.volume_render(rays)["rgb"].detach()
     assert (before - after).abs().max().item() <= 1e-5
+
+
+def test_init_surface_from_density(env):
+    """A Plenoxels-like density grid (a soft ball) becomes a surface grid whose level set is the chosen
+    density iso-surface: pruned to a shell, gradient norm ~1, renderable; depth of the level set
+    matches the ball's radius."""
+    torch, _C = env
+    import svox2
+    reso = 48
+    grid = svox2.SparseGrid(reso=reso, center=[0.0, 0.0, 0.0], radius=[1.0, 1.0, 1.0], basis_dim=4,
+                            use_z_order=False, device="cuda:0", background_nlayers=0,
+                            basis_type=svox2.BASIS_TYPE_SH, surface_type=svox2.SURFACE_TYPE_NONE,
+                            use_sphere_bound=False)
+    L = grid.links.cpu().numpy()
+    X, Y, Z = np.meshgrid(*[np.arange(r) for r in L.shape], indexing="ij")
+    rad = np.sqrt((X - 23.5) ** 2 + (Y - 23.5) ** 2 + (Z - 23.5) ** 2)
+    dens = np.clip(30.0 - 2.0 * rad, 0.0, None).astype(np.float32)        # density 10 at radius 10 voxels
+    d = np.zeros((grid.capacity, 1), np.float32)
+    d[L.reshape(-1), 0] = dens.reshape(-1)
+    grid.density_data.data[:] = torch.from_numpy(d).cuda()
+    grid.sh_data.data[:, 0] = 0.5
+    grid.opt.backend = "surf_trav"
+    grid.opt.alpha_activation_type = 1
+    grid.opt.sigma_thresh = 1e-8
+    grid.opt.stop_thresh = 0.0
+    grid.opt.step_size = 0.5
+    grid.opt.surf_fake_sample = False
+    grid.opt.truncated_vol_render = False
+    n0 = grid.capacity
+    grid.init_surface_from_density(density_lvs=[10.0], prune_threshold=5.0, dilate=2)
+    assert grid.surface_data is not None and grid.surface_data.shape == grid.density_data.shape
+    assert grid.density_data.shape[0] < n0 // 2                      # pruned to the ball (+ border shells)
+    assert abs(float(grid.level_set_data[0])) < 1e-6                 # the chosen level becomes 0
+    # |grad surface| = 1 on average: the raw field falls by 2 per voxel = 2/h per world unit
+    h = grid._get_h()
+    cells = grid.surface_data.data
+    assert abs(float(cells.max()) - (30.0 - 10.0) / (2.0 / h)) <= 0.15 * float(cells.max())
+    # the level set is the sphere of radius 10 voxels = 10 * h in world units
+    c2w = torch.eye(4)
+    c2w[2, 3] = -3.0
+    cam = svox2.Camera(c2w.cuda(), fx=100.0, width=32, height=32)
+    depth = grid.volume_render_depth_image(cam, sigma_thresh=0.0)
+    centre = depth[14:18, 14:18]
+    # the grid centre (23.5 voxels) sits at world (23.5 - 24) * h; the camera looks along +z from z = -3
+    want = 3.0 + (23.5 - 24.0) * h - 10.0 * h
+    assert (centre > 0).all() and (centre - want).abs().max().item() <= 0.03
