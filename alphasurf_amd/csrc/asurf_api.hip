@@ -1032,4 +1032,48 @@ int asurf_accel_dist_prop(int32_t* links, const int32_t size[3], uint8_t* tmp, s
     return launch_error("k_accel_dist");
 }
 
+namespace {
+int sample_xf(const int32_t* links, const int32_t size[3], const float* offset, const float* scaling, SampleXf& X) {
+    if (!links || !size || !offset || !scaling) return fail(ASURF_E_INVALID, "sample: NULL links / size / transform");
+    for (int i = 0; i < 3; ++i) {
+        if (size[i] < 2) return fail(ASURF_E_INVALID, "sample: links.shape[%d] = %d < 2", i, size[i]);
+        X.size[i] = size[i];
+        X.offset[i] = offset[i];
+        X.scaling[i] = scaling[i];
+    }
+    return 0;
+}
+}  // namespace
+
+int asurf_sample_plane(const int32_t* links, const int32_t size[3], const float* plane, int32_t n_cols,
+                       float empty_value, const float* points, int64_t n_points, const float offset[3],
+                       const float scaling[3], float* out, void* stream) {
+    SampleXf X;
+    if (int e = sample_xf(links, size, offset, scaling, X)) return e;
+    if (n_points < 0 || n_cols < 1) return fail(ASURF_E_INVALID, "sample: n_points < 0 or n_cols < 1");
+    if (n_points == 0) return 0;
+    if (!plane || !points || !out) return fail(ASURF_E_INVALID, "sample: NULL tensor");
+    const long long Q = (long long)n_points * n_cols;
+    hipLaunchKernelGGL(k_sample_plane, dim3((unsigned)((Q + 255) / 256)), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), links, X, plane, (int)n_cols, empty_value, points,
+                       (long long)n_points, out);
+    return launch_error("k_sample_plane");
+}
+
+int asurf_sample_plane_backward(const int32_t* links, const int32_t size[3], int32_t n_cols,
+                                const float* points, int64_t n_points, const float offset[3],
+                                const float scaling[3], const float* grad_out, float* grad_plane,
+                                void* stream) {
+    SampleXf X;
+    if (int e = sample_xf(links, size, offset, scaling, X)) return e;
+    if (n_points < 0 || n_cols < 1) return fail(ASURF_E_INVALID, "sample backward: n_points < 0 or n_cols < 1");
+    if (n_points == 0) return 0;
+    if (!points || !grad_out || !grad_plane) return fail(ASURF_E_INVALID, "sample backward: NULL tensor");
+    const long long Q = (long long)n_points * n_cols;
+    hipLaunchKernelGGL(k_sample_plane_backward, dim3((unsigned)((Q + 255) / 256)), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), links, X, (int)n_cols, points, (long long)n_points,
+                       grad_out, grad_plane);
+    return launch_error("k_sample_plane_backward");
+}
+
 }  // extern "C"

@@ -64,4 +64,79 @@ k_accel_dist(int32_t* __restrict__ links, uint8_t* __restrict__ tmp, int sx0, in
     }
 }
 
+// ---- trilinear sampling of an [N,C] plane at arbitrary points (svox2_kernel.cu:11-246) ----
+// One thread per (point, channel): the 8 corner reads of a point are C contiguous floats each.
+// A point is mapped by p * scaling + offset, clamped to [0, size-1]; an empty corner reads as `dflt`
+// (0 for density / SH, empty_raw for sample_grid_raw_alpha, default_surf for the surface plane).
+struct SampleXf {
+    float offset[3], scaling[3];
+    int size[3];
+};
+
+__device__ __forceinline__ const int32_t* sample_cell(const int32_t* links, const SampleXf& X,
+                                                      const float* __restrict__ points, long long pid,
+                                                      float* w) {
+    int l[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        float p = fmaf(points[3 * pid + i], X.scaling[i], X.offset[i]);  // transform_coord, cuda_util.cuh:63-69
+        p = fminf(fmaxf(p, 0.f), X.size[i] - 1.f);
+        l[i] = min((int)p, X.size[i] - 2);
+        w[i] = p - l[i];
+    }
+    return links + ((size_t)l[0] * X.size[1] * X.size[2] + (size_t)l[1] * X.size[2] + l[2]);
+}
+
+__global__ void __launch_bounds__(256)
+k_sample_plane(const int32_t* __restrict__ links, SampleXf X, const float* __restrict__ plane, int C, float dflt,
+               const float* __restrict__ points, long long P, float* __restrict__ out) {
+    const long long tid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (tid >= P * C) return;
+    const int idx = (int)(tid % C);
+    const long long pid = tid / C;
+    float w[3];
+    const int32_t* lp = sample_cell(links, X, points, pid, w);
+    const int offy = X.size[2], offx = X.size[1] * X.size[2];
+    auto rd = [&](int u) { const int l = lp[u]; return l >= 0 ? plane[(size_t)l * C + idx] : dflt; };
+    auto lerp = [](float a, float b, float t) { return fmaf(t, b - a, a); };  // cuda_util.cuh:75-77
+    const float ix0y0 = lerp(rd(0), rd(1), w[2]);
+    const float ix0y1 = lerp(rd(offy), rd(offy + 1), w[2]);
+    const float ix0 = lerp(ix0y0, ix0y1, w[1]);
+    const float ix1y0 = lerp(rd(offx), rd(offx + 1), w[2]);
+    const float ix1y1 = lerp(rd(offy + offx), rd(offy + offx + 1), w[2]);
+    const float ix1 = lerp(ix1y0, ix1y1, w[1]);
+    out[tid] = lerp(ix0, ix1, w[0]);
+}
+
+__global__ void __launch_bounds__(256)
+k_sample_plane_backward(const int32_t* __restrict__ links, SampleXf X, int C, const float* __restrict__ points,
+                        long long P, const float* __restrict__ grad_out, float* __restrict__ grad_plane) {
+    const long long tid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (tid >= P * C) return;
+    const int idx = (int)(tid % C);
+    const long long pid = tid / C;
+    float w[3];
+    const int32_t* lp = sample_cell(links, X, points, pid, w);
+    const int offy = X.size[2], offx = X.size[1] * X.size[2];
+    const float go = grad_out[tid];
+    const float xb = w[0], yb = w[1], zb = w[2], xa = 1.f - w[0], ya = 1.f - w[1], za = 1.f - w[2];
+    auto add = [&](int u, float v) {
+        const int l = lp[u];
+        if (l >= 0) atomicAdd(&grad_plane[(size_t)l * C + idx], v);
+    };
+    const float xago = xa * go, xbgo = xb * go;
+    float t = ya * xago;
+    add(0, t * za);
+    add(1, t * zb);
+    t = yb * xago;
+    add(offy, t * za);
+    add(offy + 1, t * zb);
+    t = ya * xbgo;
+    add(offx, t * za);
+    add(offx + 1, t * zb);
+    t = yb * xbgo;
+    add(offx + offy, t * za);
+    add(offx + offy + 1, t * zb);
+}
+
 }  // namespace asurf

@@ -23,7 +23,8 @@ __all__ = [
     "alpha_surf_sparsify_grad_sparse", "surface_eikonal_grad_sparse",
     "volume_render_expected_term_surf_trav", "volume_render_mode_term_surf_trav",
     "volume_render_sigma_thresh_surf_trav", "volume_render_alpha_surf_trav", "render_normal_surf_trav",
-    "extract_pts_surf_trav", "dilate", "accel_dist_prop",
+    "extract_pts_surf_trav", "dilate", "accel_dist_prop", "sample_grid", "sample_grid_sh_surf",
+    "sample_grid_raw_alpha", "sample_grid_backward",
     "volume_render_surface_fused", "test_cubic_root_grad", "sample_grid", "rmsprop_step", "sgd_step",
 ]
 
@@ -684,10 +685,69 @@ def accel_dist_prop(links):
         _L.check(_L.lib().asurf_accel_dist_prop(_ptr(links), size, _ptr(tmp), nb, _stream(links.device)))
 
 
-def sample_grid(*args, **kwargs):
-    """Present because the reference's loader rejects an extension without it
-    (svox2/utils.py:36); point sampling itself is a SURVEY.md 8(f) N4 row."""
-    raise NotImplementedError("sample_grid is outside the hot-path scope (SURVEY.md section 8f, N4)")
+# ---- point sampling (svox2_kernel.cu:384-540) ----
+def _sample_plane(grid, plane, points, empty_value):
+    _check_input(points, "points", torch.float32)
+    _check_input(plane, "plane", torch.float32)
+    if points.dim() != 2 or points.shape[1] != 3:
+        raise RuntimeError("points must be [N,3]")
+    lp, size = _links_args(grid.links)
+    _check_cpu(grid._offset, "_offset")
+    _check_cpu(grid._scaling, "_scaling")
+    off = (C.c_float * 3)(*grid._offset.to(torch.float32).tolist())
+    scl = (C.c_float * 3)(*grid._scaling.to(torch.float32).tolist())
+    dev = points.device
+    out = torch.empty((points.shape[0], plane.shape[1]), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        _L.check(_L.lib().asurf_sample_plane(lp, size, _ptr(plane), plane.shape[1], float(empty_value), _ptr(points),
+                                             points.shape[0], off, scl, _ptr(out), _stream(dev)))
+    return out
+
+
+def _sample_plane_backward(grid, n_cols, points, grad_out, grad_plane):
+    _check_input(points, "points", torch.float32)
+    _check_input(grad_out, "grad_out", torch.float32)
+    _check_input(grad_plane, "grad_plane", torch.float32)
+    lp, size = _links_args(grid.links)
+    off = (C.c_float * 3)(*grid._offset.to(torch.float32).tolist())
+    scl = (C.c_float * 3)(*grid._scaling.to(torch.float32).tolist())
+    dev = points.device
+    with torch.cuda.device(dev):
+        _L.check(_L.lib().asurf_sample_plane_backward(lp, size, int(n_cols), _ptr(points), points.shape[0], off, scl,
+                                                      _ptr(grad_out), _ptr(grad_plane), _stream(dev)))
+
+
+def sample_grid(grid, points, want_colors):
+    """(density[N,1], sh[N,D] or [0,D]) sample_grid(SparseGridSpec&, Tensor points, bool) --
+    svox2_kernel.cu:384-421; empty corners read as 0."""
+    density = _sample_plane(grid, grid.density_data, points, 0.0)
+    if want_colors:
+        sh = _sample_plane(grid, grid.sh_data, points, 0.0)
+    else:
+        sh = torch.empty((0, grid.sh_data.shape[1]), dtype=torch.float32, device=points.device)
+    return density, sh
+
+
+def sample_grid_sh_surf(grid, points, want_colors, want_surfaces, default_surf):
+    """(sh, surface) -- svox2_kernel.cu:423-462; empty surface corners read as default_surf."""
+    dev = points.device
+    sh = _sample_plane(grid, grid.sh_data, points, 0.0) if want_colors else \
+        torch.empty((0, grid.sh_data.shape[1]), dtype=torch.float32, device=dev)
+    surf = _sample_plane(grid, grid.surface_data, points, default_surf) if want_surfaces else \
+        torch.empty((0, grid.surface_data.shape[1]), dtype=torch.float32, device=dev)
+    return sh, surf
+
+
+def sample_grid_raw_alpha(grid, points, empty_raw):
+    """Tensor[N,1] -- svox2_kernel.cu:464-489; empty corners read as empty_raw."""
+    return _sample_plane(grid, grid.density_data, points, empty_raw)
+
+
+def sample_grid_backward(grid, points, grad_out_density, grad_out_sh, grad_density_out, grad_sh_out, want_colors):
+    """void sample_grid_backward(...) -- svox2_kernel.cu:491-540: adds into the two gradient grids."""
+    _sample_plane_backward(grid, 1, points, grad_out_density, grad_density_out)
+    if want_colors:
+        _sample_plane_backward(grid, grid.sh_data.shape[1], points, grad_out_sh, grad_sh_out)
 
 
 def _out_of_scope(name, row):

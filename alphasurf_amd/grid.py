@@ -231,6 +231,30 @@ class _SurfaceRenderFunction(autograd.Function):
                 holder.grad_sh_out if need[2] else None, None, None, None, None, None, None, None)
 
 
+class _SampleGridAutogradFunction(autograd.Function):
+    """Autograd bridge of point sampling (:241-278)."""
+
+    @staticmethod
+    def forward(ctx, data_density, data_sh, grid, points, want_colors):
+        assert not points.requires_grad, "Point gradient not supported"
+        out_density, out_sh = _C.sample_grid(grid, points, want_colors)
+        ctx.save_for_backward(points)
+        ctx.grid, ctx.want_colors = grid, want_colors
+        return out_density, out_sh
+
+    @staticmethod
+    def backward(ctx, grad_out_density, grad_out_sh):
+        (points,) = ctx.saved_tensors
+        g = ctx.grid
+        grad_density = torch.zeros_like(g.density_data.data)
+        grad_sh = torch.zeros_like(g.sh_data.data)
+        _C.sample_grid_backward(g, points, grad_out_density.contiguous(),
+                                grad_out_sh.contiguous() if ctx.want_colors else grad_out_sh, grad_density, grad_sh,
+                                ctx.want_colors)
+        return (grad_density if ctx.needs_input_grad[0] else None,
+                grad_sh if ctx.needs_input_grad[1] else None, None, None, None)
+
+
 class SparseGrid(nn.Module):
     """Sparse voxel grid with a per-vertex surface scalar (:560-990).  Only what the surf_trav
     hot path needs is built: SH basis, SDF/UDF surface types, no MSI background."""
@@ -487,6 +511,74 @@ class SparseGrid(nn.Module):
         parts = [self.volume_render(rays[s:s + batch_size], use_kernel=use_kernel, randomize=randomize)["rgb"]
                  for s in range(0, camera.height * camera.width, batch_size)]
         return torch.cat(parts, dim=0).view(camera.height, camera.width, -1)
+
+    # ---- point sampling and resampling (:1040-1113, 3963-4180 -> svox2_kernel.cu) ----
+    def sample(self, points: torch.Tensor, use_kernel: bool = True, grid_coords: bool = False,
+               want_colors: bool = True):
+        """(density[N,1], sh[N,D]) by trilinear interpolation, border padding, empty vertices = 0 (:1040-1113).
+        `grid_coords`: points are grid coordinates in [-0.5, reso-0.5]."""
+        if not use_kernel:
+            raise NotImplementedError("the PyTorch debugging path is not part of this build (no CPU fallback)")
+        assert points.is_cuda and self.links.is_cuda
+        return _SampleGridAutogradFunction.apply(self.density_data, self.sh_data,
+                                                 self._to_cpp(grid_coords=grid_coords), points.contiguous(),
+                                                 want_colors)
+
+    def sample_surface(self, points: torch.Tensor, use_kernel: bool = True, grid_coords: bool = False,
+                       want_colors: bool = True, want_surfaces: bool = True, default_surf: float = -1):
+        """(sh, surface) at points; empty surface vertices read as `default_surf` (:1115-1146)."""
+        if not use_kernel:
+            raise NotImplementedError("the PyTorch debugging path is not part of this build (no CPU fallback)")
+        assert points.is_cuda and self.links.is_cuda
+        return _C.sample_grid_sh_surf(self._to_cpp(grid_coords=grid_coords), points.contiguous(), want_colors,
+                                      want_surfaces, default_surf)
+
+    def resample(self, reso, sigma_thresh: float = 5.0, weight_thresh: float = 0.01, dilate: int = 2,
+                 cameras=None, use_z_order: bool = False, accelerate: bool = True,
+                 weight_render_stop_thresh: float = 0.2, max_elements: int = 0, batch_size: int = 720720):
+        """Resample density and SH onto a grid of resolution `reso`, keep the vertices whose density reaches
+        `sigma_thresh` (dilated `dilate` times) and renumber them in raster order (:3963-4180).  The
+        camera-weight criterion needs grid_weight_render (N4, not built); Morton order is not offered."""
+        if cameras is not None:
+            _next_row("N4", "resample with camera weights (grid_weight_render)")
+        if use_z_order:
+            _next_row("N4", "resample into Morton order")
+        if self.surface_data is not None:
+            _next_row("N4", "resample of a surface grid (resample_surface)")
+        with torch.no_grad():
+            device = self.links.device
+            reso = [reso] * 3 if isinstance(reso, int) else list(reso)
+            assert len(reso) == 3, "reso must be an integer or indexable object of 3 ints"
+            cur = self.links.shape
+            fac = [0.5 * cur[i] / reso[i] for i in range(3)]
+            ax = [torch.linspace(fac[i] - 0.5, cur[i] - fac[i] - 0.5, reso[i], dtype=torch.float32) for i in range(3)]
+            points = torch.stack(torch.meshgrid(*ax, indexing="ij"), dim=-1).view(-1, 3).to(device)
+            dens = torch.cat([self.sample(points[i:i + batch_size], grid_coords=True, want_colors=False)[0]
+                              for i in range(0, len(points), batch_size)], dim=0).view(reso)
+            mask = dens >= sigma_thresh
+            if 0 < max_elements < dens.numel() and max_elements < int(torch.count_nonzero(mask)):
+                bound = torch.topk(dens.view(-1), k=max_elements, sorted=False).values.min().item()
+                sigma_thresh = max(sigma_thresh, bound)
+                mask = dens >= sigma_thresh
+            if self.opt.last_sample_opaque:
+                mask[:, :, -1] = True
+            for _ in range(int(dilate)):
+                mask = _C.dilate(mask.contiguous())
+            mask = mask.view(-1)
+            kept_pts = points[mask]
+            sh = torch.cat([self.sample(kept_pts[i:i + batch_size], grid_coords=True, want_colors=True)[1]
+                            for i in range(0, len(kept_pts), batch_size)], dim=0) if len(kept_pts) else \
+                torch.empty_like(self.sh_data.data[:0])
+            links = torch.cumsum(mask.to(torch.int32), dim=-1).int() - 1
+            links[~mask] = -1
+            self.density_data = nn.Parameter(dens.view(-1)[mask].view(-1, 1).contiguous())
+            self.sh_data = nn.Parameter(sh.contiguous())
+            self.links = links.view(reso).contiguous()
+            self.density_rms = self.sh_rms = None
+            self.sparse_grad_indexer = self.sparse_sh_grad_indexer = None
+            self._data_to_links = None
+            if accelerate:
+                self.accelerate()
 
     # ---- grid maintenance (:2859-2957, 4483-4490 -> misc_kernel.cu) ----
     def accelerate(self):

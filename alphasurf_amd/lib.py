@@ -91,6 +91,7 @@ EXPORTS = [
     "asurf_tv_grad_sparse", "asurf_surf_tv_grad_sparse", "asurf_surface_normal_grad_sparse",
     "asurf_alpha_surf_sparsify_grad_sparse", "asurf_surface_eikonal_grad_sparse",
     "asurf_render_eval_surf_trav", "asurf_dilate", "asurf_accel_dist_prop_tmp_bytes", "asurf_accel_dist_prop",
+    "asurf_sample_plane", "asurf_sample_plane_backward",
 ]
 
 _lib = None
@@ -141,6 +142,8 @@ def lib():
         L.asurf_accel_dist_prop_tmp_bytes.restype = C.c_size_t
         L.asurf_accel_dist_prop_tmp_bytes.argtypes = [vp]
         L.asurf_accel_dist_prop.argtypes = [vp, vp, vp, C.c_size_t, vp]
+        L.asurf_sample_plane.argtypes = [vp, vp, vp, i32, fl, vp, i64, vp, vp, vp, vp]
+        L.asurf_sample_plane_backward.argtypes = [vp, vp, i32, vp, i64, vp, vp, vp, vp, vp]
         if L.asurf_abi_version() != 1:
             raise RuntimeError("libasurf_hip.so ABI version mismatch")
         _lib = L

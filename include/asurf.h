@@ -312,6 +312,19 @@ size_t asurf_accel_dist_prop_tmp_bytes(const int32_t size[3]);
 int asurf_accel_dist_prop(int32_t* links, const int32_t size[3], uint8_t* tmp, size_t tmp_bytes,
                           void* stream);
 
+/* Trilinear sampling of an [n_rows, n_cols] parameter plane at `points` float[n_points,3]
+ * (sample_grid / sample_grid_sh_surf / sample_grid_raw_alpha, svox2_kernel.cu:11-150, 384-489):
+ * p * scaling + offset, clamped to the grid, an empty corner reads as `empty_value`; out is
+ * float[n_points, n_cols].  The backward (sample_grid_backward, :151-246, 491-540) ADDS
+ * d out / d plane * grad_out into grad_plane. */
+int asurf_sample_plane(const int32_t* links, const int32_t size[3], const float* plane, int32_t n_cols,
+                       float empty_value, const float* points, int64_t n_points, const float offset[3],
+                       const float scaling[3], float* out, void* stream);
+int asurf_sample_plane_backward(const int32_t* links, const int32_t size[3], int32_t n_cols,
+                                const float* points, int64_t n_points, const float offset[3],
+                                const float scaling[3], const float* grad_out, float* grad_plane,
+                                void* stream);
+
 /* Measurement hooks (no reference counterpart; used by bench.py).  When enabled, the
  * surf_trav launchers record a hipEvent on the call's stream after every kernel launch.
  * asurf_profile_read() waits for the last call and returns, in milliseconds,
