@@ -21,6 +21,7 @@
 #include "asurf_reg.h"
 #include "asurf_eval.h"
 #include "asurf_misc.h"
+#include "asurf_cuvol.h"
 
 namespace {
 
@@ -129,11 +130,11 @@ MaskLayout layout_for(const int32_t size[3], int64_t n_rays, int32_t M) {
     return L;
 }
 
-int check_grid(const asurf_grid* g) {
+int check_grid(const asurf_grid* g, bool need_surface = true) {
     if (!g) return fail(ASURF_E_INVALID, "grid is NULL");
     if (!g->links || !g->density_data || !g->sh_data)
         return fail(ASURF_E_INVALID, "links, density_data and sh_data must be device tensors");
-    if (g->surface_type == ASURF_SURFACE_TYPE_NONE || !g->surface_data)
+    if (need_surface && (g->surface_type == ASURF_SURFACE_TYPE_NONE || !g->surface_data))
         return fail(ASURF_E_INVALID, "surf_trav needs surface_data (surface_type != NONE)");
     if (g->level_set_num < 0 || (g->level_set_num > 0 && !g->level_set_data))
         return fail(ASURF_E_INVALID, "level_set_data missing");
@@ -264,8 +265,8 @@ int launch_error(const char* what) {
 // Common prologue: validation, workspace carve-up and the occupancy-pyramid pass.
 int prepare(const asurf_grid* grid, const asurf_rays* rays, const asurf_render_options* opt,
             int32_t M, void* workspace, size_t workspace_bytes, void* stream, Launch& L,
-            bool masks_only = false) {
-    if (int e = check_grid(grid)) return e;
+            bool masks_only = false, bool cuvol = false) {
+    if (int e = check_grid(grid, !cuvol)) return e;
     if (int e = check_rays(rays)) return e;
     if (!opt) return fail(ASURF_E_INVALID, "render options are NULL");
     if (opt->alpha_activation_type != ASURF_SIGMOID_FN && opt->alpha_activation_type != ASURF_EXP_FN)
@@ -280,7 +281,7 @@ int prepare(const asurf_grid* grid, const asurf_rays* rays, const asurf_render_o
     // is on (surf_trav.cu:423); and with stop_thresh > 1 the reference stops at the first
     // voxel that passes the link/density gates (:544), so the walk must test that plane.
     const bool need_surf = !(opt->surf_fake_sample && !opt->limited_fake_sample);
-    const bool use_live = !need_surf || (opt->stop_thresh > 1.f);
+    const bool use_live = !cuvol && (!need_surf || (opt->stop_thresh > 1.f));
     L.g = make_kgrid(grid, L.ML, L.ws, use_live);
     L.o = make_kopt(opt);
     L.coarse_in_lds = (L.ML.coarse_words * 4 <= kMaxCoarseLds) ? 1 : 0;
@@ -288,7 +289,7 @@ int prepare(const asurf_grid* grid, const asurf_rays* rays, const asurf_render_o
     L.ray_grid = dim3((unsigned)((rays->n_rays + kBlock - 1) / kBlock));
     prof_begin(L.stream);
     hipLaunchKernelGGL(k_build_masks, dim3((unsigned)L.ML.coarse_words), dim3(512), 0, L.stream, L.g,
-                       opt->sigma_thresh, need_surf ? 1 : 0,
+                       opt->sigma_thresh, cuvol ? 2 : (need_surf ? 1 : 0),  // 2: cuvol cells (asurf_cuvol.h)
                        reinterpret_cast<unsigned long long*>(L.ws + L.ML.off_fine_work),
                        reinterpret_cast<unsigned long long*>(L.ws + L.ML.off_fine_live),
                        reinterpret_cast<unsigned int*>(L.ws + L.ML.off_coarse_work),
@@ -557,6 +558,33 @@ int launch_eval(const Launch& L, const asurf_rays* rays, float param, int max_sa
         hipLaunchKernelGGL((k_eval<MODE, false>), L.ray_grid, dim3(kBlock), 0, L.stream, L.g, L.o,
                            rays->origins, rays->dirs, (long long)rays->n_rays, param, max_sample, out0, out1);
     return launch_error("k_eval");
+}
+
+template <int B>
+int cuvol_fwd(const Launch& L, const asurf_rays* rays, int last_opaque, float* rgb_out, float* log_t) {
+    if (L.coarse_in_lds)
+        hipLaunchKernelGGL((k_cuvol_fwd<B, true>), L.ray_grid, dim3(kBlock), L.dyn_lds, L.stream, L.g, L.o,
+                           last_opaque, rays->origins, rays->dirs, (long long)rays->n_rays, rgb_out, log_t);
+    else
+        hipLaunchKernelGGL((k_cuvol_fwd<B, false>), L.ray_grid, dim3(kBlock), 0, L.stream, L.g, L.o,
+                           last_opaque, rays->origins, rays->dirs, (long long)rays->n_rays, rgb_out, log_t);
+    prof_after("k_cuvol_fwd", 1, L.stream);
+    return launch_error("k_cuvol_fwd");
+}
+
+template <int B>
+int cuvol_bwd(const Launch& L, const asurf_rays* rays, int last_opaque, const KGrads& G, const float* grad_in,
+              const float* color_cache, int is_rgb, const float* log_t, float beta_loss, float sparsity_loss) {
+    if (L.coarse_in_lds)
+        hipLaunchKernelGGL((k_cuvol_bwd<B, true>), L.ray_grid, dim3(kBlock), L.dyn_lds, L.stream, L.g, L.o,
+                           last_opaque, G, rays->origins, rays->dirs, (long long)rays->n_rays, grad_in,
+                           color_cache, is_rgb, log_t, beta_loss, sparsity_loss);
+    else
+        hipLaunchKernelGGL((k_cuvol_bwd<B, false>), L.ray_grid, dim3(kBlock), 0, L.stream, L.g, L.o,
+                           last_opaque, G, rays->origins, rays->dirs, (long long)rays->n_rays, grad_in,
+                           color_cache, is_rgb, log_t, beta_loss, sparsity_loss);
+    prof_after("k_cuvol_bwd", 2, L.stream);
+    return launch_error("k_cuvol_bwd");
 }
 
 }  // namespace
@@ -1074,6 +1102,59 @@ int asurf_sample_plane_backward(const int32_t* links, const int32_t size[3], int
                        static_cast<hipStream_t>(stream), links, X, (int)n_cols, points, (long long)n_points,
                        grad_out, grad_plane);
     return launch_error("k_sample_plane_backward");
+}
+
+// ---- cuvol renderer (asurf_cuvol.h) ----
+int asurf_volume_render_cuvol(const asurf_grid* grid, const asurf_rays* rays,
+                              const asurf_render_options* opt, float* rgb_out, void* workspace,
+                              size_t workspace_bytes, void* stream) {
+    Launch L;
+    if (opt && !(opt->step_size > 0.f)) return fail(ASURF_E_INVALID, "cuvol: step_size must be > 0");
+    if (int e = prepare(grid, rays, opt, 0, workspace, workspace_bytes, stream, L, true, true)) return e;
+    if (rays->n_rays == 0) return 0;
+    if (!rgb_out) return fail(ASURF_E_INVALID, "rgb_out is NULL");
+    int rc = 0;
+    ASURF_DISPATCH_B(grid->basis_dim, (cuvol_fwd<B_>(L, rays, opt->last_sample_opaque, rgb_out, nullptr)));
+    return rc;
+}
+
+int asurf_volume_render_cuvol_backward(const asurf_grid* grid, const asurf_rays* rays,
+                                       const asurf_render_options* opt, const float* grad_out,
+                                       const float* color_cache, const asurf_grads* grads, void* workspace,
+                                       size_t workspace_bytes, void* stream) {
+    Launch L;
+    if (opt && !(opt->step_size > 0.f)) return fail(ASURF_E_INVALID, "cuvol: step_size must be > 0");
+    if (int e = prepare(grid, rays, opt, 0, workspace, workspace_bytes, stream, L, true, true)) return e;
+    if (!grads) return fail(ASURF_E_INVALID, "grads is NULL");
+    if (rays->n_rays == 0) return 0;
+    if (!grad_out || !color_cache) return fail(ASURF_E_INVALID, "grad_out / color_cache is NULL");
+    const KGrads G = make_grads(grads);
+    int rc = 0;
+    ASURF_DISPATCH_B(grid->basis_dim, (cuvol_bwd<B_>(L, rays, opt->last_sample_opaque, G, grad_out, color_cache, 0,
+                                                     nullptr, 0.f, 0.f)));
+    return rc;
+}
+
+// render_lerp_kernel_cuvol.cu:1272-1354: forward, then backward with the MSE gradient formed in the
+// kernel; beta_loss / Q as there (:1323); the log-transmittance hand-over lives in the workspace.
+int asurf_volume_render_cuvol_fused(const asurf_grid* grid, const asurf_rays* rays,
+                                    const asurf_render_options* opt, const float* rgb_gt, float beta_loss,
+                                    float sparsity_loss, float* rgb_out, const asurf_grads* grads,
+                                    void* workspace, size_t workspace_bytes, void* stream) {
+    Launch L;
+    if (opt && !(opt->step_size > 0.f)) return fail(ASURF_E_INVALID, "cuvol: step_size must be > 0");
+    if (int e = prepare(grid, rays, opt, 0, workspace, workspace_bytes, stream, L, false, true)) return e;
+    if (!grads) return fail(ASURF_E_INVALID, "grads is NULL");
+    if (rays->n_rays == 0) return 0;
+    if (!rgb_gt || !rgb_out) return fail(ASURF_E_INVALID, "rgb_gt / rgb_out is NULL");
+    const KGrads G = make_grads(grads);
+    float* log_t = beta_loss > 0.f ? reinterpret_cast<float*>(L.ws + L.ML.off_cache_n) : nullptr;
+    int rc = 0;
+    ASURF_DISPATCH_B(grid->basis_dim, (cuvol_fwd<B_>(L, rays, opt->last_sample_opaque, rgb_out, log_t)));
+    if (rc) return rc;
+    ASURF_DISPATCH_B(grid->basis_dim, (cuvol_bwd<B_>(L, rays, opt->last_sample_opaque, G, rgb_gt, rgb_out, 1, log_t,
+                                                     beta_loss / (float)rays->n_rays, sparsity_loss)));
+    return rc;
 }
 
 }  // extern "C"

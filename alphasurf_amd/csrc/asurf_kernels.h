@@ -52,7 +52,16 @@ k_build_masks(KGrid g, float sigma_thresh, int need_surf, unsigned long long* fi
             const int32_t l0 = p[0], l1 = p[1], l2 = p[g.offy], l3 = p[g.offy + 1];
             const int32_t l4 = p[g.offx], l5 = p[g.offx + 1], l6 = p[g.offx + g.offy],
                           l7 = p[g.offx + g.offy + 1];
-            if ((l0 | l1 | l2 | l3 | l4 | l5 | l6 | l7) >= 0) {
+            if (need_surf == 2) {
+                // cuvol cells (render_lerp_kernel_cuvol.cu:66-77): a missing corner reads as 0 and
+                // the sample counts iff the trilinear density exceeds sigma_thresh -- impossible
+                // unless some corner value does (a convex combination)
+                const int32_t lk[8] = {l0, l1, l2, l3, l4, l5, l6, l7};
+                float mx = 0.f;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) mx = fmaxf(mx, lk[i] >= 0 ? g.density[lk[i]] : 0.f);
+                live = work = mx > sigma_thresh;
+            } else if ((l0 | l1 | l2 | l3 | l4 | l5 | l6 | l7) >= 0) {
                 const int32_t lk[8] = {l0, l1, l2, l3, l4, l5, l6, l7};
                 bool all_below = true;  // surf_trav.cu:230-239
 #pragma unroll
@@ -499,12 +508,15 @@ __device__ __forceinline__ void coop_shade_fwd(const KGrid& g, unsigned long lon
         need &= need - 1;
         const float px = bcast_f(pos[0], r), py = bcast_f(pos[1], r), pz = bcast_f(pos[2], r);
         const int first = bcast_i(my_first, r);
-        if (first != held) {
+        if (first != held || first < 0) {  // a missing first corner (cuvol cells) identifies nothing
             held = first;
 #pragma unroll
             for (int rd = 0; rd < C::ROUNDS; ++rd) {
                 const int c = rd * C::CPR + cs;
-                if (on && c < 8) val[rd] = g.sh[(size_t)rec_wave[r].link[c] * C::D + e];
+                if (on && c < 8) {
+                    const int link = rec_wave[r].link[c];  // < 0 in cuvol cells: the corner reads as 0
+                    val[rd] = link >= 0 ? g.sh[(size_t)link * C::D + e] : 0.f;
+                }
             }
         }
         float acc = 0.f;
@@ -557,7 +569,7 @@ __device__ __forceinline__ void coop_shade_bwd(const KGrid& g, const KGrads& G, 
             w_r[rd] = 0.f;
             if (on && c < 8) {
                 const int link = rec_wave[r].link[c];
-                const float val = g.sh[(size_t)link * C::D + e];
+                const float val = link >= 0 ? g.sh[(size_t)link * C::D + e] : 0.f;
                 const float wx = (c & 4) ? px : 1.f - px;
                 const float wy = (c & 2) ? py : 1.f - py;
                 const float wz = (c & 1) ? pz : 1.f - pz;

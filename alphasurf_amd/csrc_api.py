@@ -144,14 +144,16 @@ def _defined(t):
     return torch.is_tensor(t) and t.numel() > 0
 
 
-def _pack_grid(grid):
+def _pack_grid(grid, need_surface=True):
     _check_input(grid.density_data, "density_data", torch.float32)
     _check_input(grid.sh_data, "sh_data", torch.float32)
     _check_input(grid.links, "links", torch.int32)
-    if grid.surface_type == 100 or grid.surface_data is None:
+    has_surface = grid.surface_type != 100 and _defined(grid.surface_data)
+    if need_surface and not has_surface:
         raise RuntimeError("surf_trav requires a surface grid (surface_type != SURFACE_TYPE_NONE)")
-    _check_input(grid.surface_data, "surface_data", torch.float32)
-    _check_input(grid.level_set_data, "level_set_data", torch.float32)
+    if has_surface:
+        _check_input(grid.surface_data, "surface_data", torch.float32)
+        _check_input(grid.level_set_data, "level_set_data", torch.float32)
     _check_cpu(grid._offset, "_offset")
     _check_cpu(grid._scaling, "_scaling")
     if grid.density_data.dim() != 2 or grid.sh_data.dim() != 2 or grid.links.dim() != 3:
@@ -163,20 +165,20 @@ def _pack_grid(grid):
     if grid.sh_data.shape[1] != 3 * grid.basis_dim:
         raise RuntimeError("sh_data.shape[1] must equal 3 * basis_dim")
     if grid.sh_data.shape[0] != grid.density_data.shape[0] or \
-            grid.surface_data.shape[0] != grid.density_data.shape[0]:
+            (has_surface and grid.surface_data.shape[0] != grid.density_data.shape[0]):
         raise RuntimeError("density/surface/sh row counts differ")
     g = _L.AsurfGrid()
     g.links = _ptr(grid.links)
     g.density_data = _ptr(grid.density_data)
-    g.surface_data = _ptr(grid.surface_data)
+    g.surface_data = _ptr(grid.surface_data) if has_surface else C.c_void_p(0)
     g.sh_data = _ptr(grid.sh_data)
-    g.level_set_data = _ptr(grid.level_set_data)
+    g.level_set_data = _ptr(grid.level_set_data) if has_surface else C.c_void_p(0)
     g.capacity = grid.density_data.shape[0]
     g.size = (C.c_int32 * 3)(*grid.links.shape)
-    g.level_set_num = grid.level_set_data.numel()
+    g.level_set_num = grid.level_set_data.numel() if has_surface else 0
     g.basis_dim = int(grid.basis_dim)
     g.basis_type = int(grid.basis_type)
-    g.surface_type = int(grid.surface_type)
+    g.surface_type = int(grid.surface_type) if has_surface else 100
     off = grid._offset.to(torch.float32).tolist()
     scl = grid._scaling.to(torch.float32).tolist()
     g.offset = (C.c_float * 3)(*off)
@@ -224,7 +226,7 @@ def _pack_grads(grads, grid):
 
     g.grad_density_out = chk(grads.grad_density_out, "grad_density_out", grid.density_data.shape)
     g.grad_sh_out = chk(grads.grad_sh_out, "grad_sh_out", grid.sh_data.shape)
-    g.grad_surface_out = chk(grads.grad_surface_out, "grad_surface_out", grid.surface_data.shape)
+    g.grad_surface_out = chk(grads.grad_surface_out, "grad_surface_out", grid.density_data.shape)
     if _defined(grads.grad_fake_sample_std_out):
         _check_input(grads.grad_fake_sample_std_out, "grad_fake_sample_std_out", torch.float32)
         g.grad_fake_sample_std_out = _ptr(grads.grad_fake_sample_std_out)
@@ -748,6 +750,51 @@ def sample_grid_backward(grid, points, grad_out_density, grad_out_sh, grad_densi
     _sample_plane_backward(grid, 1, points, grad_out_density, grad_density_out)
     if want_colors:
         _sample_plane_backward(grid, grid.sh_data.shape[1], points, grad_out_sh, grad_sh_out)
+
+
+# ---- the Plenoxels `cuvol` renderer ----
+def volume_render_cuvol(grid, rays, opt):
+    """Tensor volume_render_cuvol(grid, rays, opt) -- svox2.cpp:18; render_lerp_kernel_cuvol.cu:1120-1165.
+    The surface plane of the grid is not read (a SURFACE_TYPE_NONE grid is accepted)."""
+    g, r, o = _pack_grid(grid, need_surface=False), _pack_rays(rays), _pack_opt(opt)
+    dev = grid.sh_data.device
+    with torch.cuda.device(dev):
+        out = torch.empty_like(rays.origins)
+        nb = _L.workspace_bytes(grid.links.shape, 0, 0)
+        ws = _workspace(dev, nb)
+        _L.check(_L.lib().asurf_volume_render_cuvol(C.byref(g), C.byref(r), C.byref(o), _ptr(out), _ptr(ws), nb,
+                                                     _stream(dev)))
+    return out
+
+
+def volume_render_cuvol_backward(grid, rays, opt, grad_out, color_cache, grads):
+    """svox2.cpp:20; render_lerp_kernel_cuvol.cu:1209-1270."""
+    g, r, o = _pack_grid(grid, need_surface=False), _pack_rays(rays), _pack_opt(opt)
+    _check_input(grad_out, "grad_out", torch.float32)
+    _check_input(color_cache, "color_cache", torch.float32)
+    gg = _pack_grads(grads, grid)
+    dev = grid.sh_data.device
+    with torch.cuda.device(dev):
+        nb = _L.workspace_bytes(grid.links.shape, 0, 0)
+        ws = _workspace(dev, nb)
+        _L.check(_L.lib().asurf_volume_render_cuvol_backward(
+            C.byref(g), C.byref(r), C.byref(o), _ptr(grad_out), _ptr(color_cache), C.byref(gg), _ptr(ws), nb,
+            _stream(dev)))
+
+
+def volume_render_cuvol_fused(grid, rays, opt, rgb_gt, beta_loss, sparsity_loss, rgb_out, grads):
+    """svox2.cpp:21; render_lerp_kernel_cuvol.cu:1272-1354."""
+    g, r, o = _pack_grid(grid, need_surface=False), _pack_rays(rays), _pack_opt(opt)
+    _check_input(rgb_gt, "rgb_gt", torch.float32)
+    _check_input(rgb_out, "rgb_out", torch.float32)
+    gg = _pack_grads(grads, grid)
+    dev = grid.sh_data.device
+    with torch.cuda.device(dev):
+        nb = _L.workspace_bytes(grid.links.shape, r.n_rays, 0)
+        ws = _workspace(dev, nb)
+        _L.check(_L.lib().asurf_volume_render_cuvol_fused(
+            C.byref(g), C.byref(r), C.byref(o), _ptr(rgb_gt), float(beta_loss), float(sparsity_loss),
+            _ptr(rgb_out), C.byref(gg), _ptr(ws), nb, _stream(dev)))
 
 
 def _out_of_scope(name, row):

@@ -203,6 +203,31 @@ class _SurfTravRenderFunction(autograd.Function):
                 holder.grad_fake_sample_std_out if need[5] else None, None, None, None, None)
 
 
+class _VolumeRenderFunction(autograd.Function):
+    """Autograd bridge of the surface-less renderers (:280-347; here: `cuvol`)."""
+
+    @staticmethod
+    def forward(ctx, data_density, data_sh, data_basis, data_background, grid, rays, opt, backend):
+        color = getattr(_C, f"volume_render_{backend}")(grid, rays, opt)
+        ctx.save_for_backward(color)
+        ctx.grid, ctx.rays, ctx.opt, ctx.backend = grid, rays, opt, backend
+        return color
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        (color_cache,) = ctx.saved_tensors
+        g = ctx.grid
+        holder = _C.GridOutputGrads()
+        holder.grad_density_out = torch.zeros_like(g.density_data.data)
+        holder.grad_sh_out = torch.zeros_like(g.sh_data.data)
+        getattr(_C, f"volume_render_{ctx.backend}_backward")(
+            g, ctx.rays, ctx.opt, grad_out.contiguous(), color_cache, holder)
+        ctx.grid = ctx.rays = ctx.opt = None
+        need = ctx.needs_input_grad
+        return (holder.grad_density_out if need[0] else None, holder.grad_sh_out if need[1] else None,
+                None, None, None, None, None, None)
+
+
 class _SurfaceRenderFunction(autograd.Function):
     """Autograd bridge of the legacy voxel-list backend (:432-511)."""
 
@@ -410,11 +435,17 @@ class SparseGrid(nn.Module):
         return ret
 
     # ---- rendering (:3390-3638) ----
-    def _check_backend(self):
-        if self.opt.backend not in ("surf_trav", "surface"):
-            _next_row("N4", f"renderer backend {self.opt.backend!r}")
-        if self.surface_data is None:
+    def _check_backend(self, no_surface: bool = False) -> str:
+        """The renderer that serves this call: `no_surface` swaps the surface renderers for the
+        Plenoxels one (:3554-3557, :3657-3659)."""
+        backend = self.opt.backend
+        if backend not in ("surf_trav", "surface", "cuvol"):
+            _next_row("N4", f"renderer backend {backend!r}")
+        if no_surface and backend in ("surf_trav", "surface"):
+            backend = "cuvol"
+        if backend != "cuvol" and self.surface_data is None:
             raise RuntimeError("the surf_trav backend needs a surface grid (surface_type SDF/UDF)")
+        return backend
 
     def ray_voxel_lists(self, rays: Rays, skip_empty: bool = True) -> RayVoxIntersecs:
         """Per-ray voxel lists of the legacy backend (what :3415-3428 builds from
@@ -438,9 +469,14 @@ class SparseGrid(nn.Module):
         if not use_kernel or return_raylen:
             raise NotImplementedError("the pure-PyTorch debugging renderer is not part of this build; "
                                       "the HIP path is the only implementation (no CPU fallback)")
-        self._check_backend()
+        backend = self._check_backend(kwargs.get("no_surface", False))
         assert rays.is_cuda and self.links.is_cuda
-        if self.opt.backend == "surface":  # :3410-3437
+        if backend == "cuvol":  # :3456-3466
+            rgb = _VolumeRenderFunction.apply(
+                self.density_data, self.sh_data, None, None, self._to_cpp(), rays._to_cpp(),
+                self.opt._to_cpp(randomize=randomize), backend)
+            return {"rgb": rgb}
+        if backend == "surface":  # :3410-3437
             ray_vox = self.ray_voxel_lists(rays)
             rgb = _SurfaceRenderFunction.apply(
                 self.density_data, self.surface_data, self.sh_data, None, None, self._to_cpp(),
@@ -467,19 +503,23 @@ class SparseGrid(nn.Module):
         """Render + fused loss gradients accumulated into the parameters' .grad (:3477-3638).
         `global_n_rays` (extension) = ray count of the whole data-parallel batch."""
         assert self.sh_data.is_cuda and rays.is_cuda, "the HIP extension is required for fused"
-        if no_surface:
-            _next_row("N4", "no_surface warm-up (cuvol renderer)")
-        self._check_backend()
+        backend = self._check_backend(no_surface)
         grad = self._get_data_grads()
         rgb_out = torch.zeros_like(rgb_gt)
         self.sparse_grad_indexer = torch.zeros((self.density_data.size(0),), dtype=torch.bool,
                                                device=self.density_data.device)
         holder = _C.GridOutputGrads()
         holder.grad_density_out = grad["density_data"]
-        holder.grad_surface_out = grad["surface_data"]
+        if "surface_data" in grad:
+            holder.grad_surface_out = grad["surface_data"]
         holder.grad_sh_out = grad["sh_data"]
         holder.mask_out = self.sparse_grad_indexer
-        if self.opt.backend == "surface":  # :3560-3597
+        if backend == "cuvol":  # :3625-3634
+            _C.volume_render_cuvol_fused(self._to_cpp(), rays._to_cpp(), self.opt._to_cpp(randomize=randomize),
+                                         rgb_gt, beta_loss, sparsity_loss, rgb_out, holder)
+            self.sparse_sh_grad_indexer = self.sparse_grad_indexer.clone()
+            return {"rgb": rgb_out}
+        if backend == "surface":  # :3560-3597
             ray_vox = self.ray_voxel_lists(rays)
             _C.volume_render_surface_fused(
                 self._to_cpp(), rays._to_cpp(), ray_vox._to_cpp(), self.opt._to_cpp(randomize=randomize),
@@ -503,12 +543,14 @@ class SparseGrid(nn.Module):
                             batch_size: int = 5000, return_raylen: bool = False, debug_pixels=None,
                             **kwargs):
         """Whole-image render in ray batches (:3641-3691): no image kernel is registered for
-        surf_trav in the reference either (svox2.cpp:153)."""
+        surf_trav in the reference either (svox2.cpp:153); `no_surface=True` renders with cuvol
+        (the reference's volume_render_cuvol_image, :3657-3659)."""
         rays = camera.gen_rays()
+        kw = dict(use_kernel=use_kernel, randomize=randomize, no_surface=kwargs.get("no_surface", False))
         if debug_pixels is not None:
             ids = debug_pixels[:, 0] + debug_pixels[:, 1] * camera.width
-            return self.volume_render(rays[ids], use_kernel=use_kernel, randomize=randomize)["rgb"]
-        parts = [self.volume_render(rays[s:s + batch_size], use_kernel=use_kernel, randomize=randomize)["rgb"]
+            return self.volume_render(rays[ids], **kw)["rgb"]
+        parts = [self.volume_render(rays[s:s + batch_size], **kw)["rgb"]
                  for s in range(0, camera.height * camera.width, batch_size)]
         return torch.cat(parts, dim=0).view(camera.height, camera.width, -1)
 

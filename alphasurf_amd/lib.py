@@ -92,6 +92,7 @@ EXPORTS = [
     "asurf_alpha_surf_sparsify_grad_sparse", "asurf_surface_eikonal_grad_sparse",
     "asurf_render_eval_surf_trav", "asurf_dilate", "asurf_accel_dist_prop_tmp_bytes", "asurf_accel_dist_prop",
     "asurf_sample_plane", "asurf_sample_plane_backward",
+    "asurf_volume_render_cuvol", "asurf_volume_render_cuvol_backward", "asurf_volume_render_cuvol_fused",
 ]
 
 _lib = None
@@ -144,6 +145,9 @@ def lib():
         L.asurf_accel_dist_prop.argtypes = [vp, vp, vp, C.c_size_t, vp]
         L.asurf_sample_plane.argtypes = [vp, vp, vp, i32, fl, vp, i64, vp, vp, vp, vp]
         L.asurf_sample_plane_backward.argtypes = [vp, vp, i32, vp, i64, vp, vp, vp, vp, vp]
+        L.asurf_volume_render_cuvol.argtypes = [vp, vp, vp, vp, vp, C.c_size_t, vp]
+        L.asurf_volume_render_cuvol_backward.argtypes = [vp, vp, vp, vp, vp, vp, vp, C.c_size_t, vp]
+        L.asurf_volume_render_cuvol_fused.argtypes = [vp, vp, vp, vp, fl, fl, vp, vp, vp, C.c_size_t, vp]
         if L.asurf_abi_version() != 1:
             raise RuntimeError("libasurf_hip.so ABI version mismatch")
         _lib = L

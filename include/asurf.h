@@ -312,6 +312,23 @@ size_t asurf_accel_dist_prop_tmp_bytes(const int32_t size[3]);
 int asurf_accel_dist_prop(int32_t* links, const int32_t size[3], uint8_t* tmp, size_t tmp_bytes,
                           void* stream);
 
+/* The Plenoxels volume renderer (`cuvol` backend):
+ *   volume_render_cuvol / _backward / _fused, svox2.cpp REG, render_lerp_kernel_cuvol.cu:1120-1354.
+ * surface_data may be NULL.  Workspace: asurf_workspace_bytes(size, 0, 0) for the first two,
+ * asurf_workspace_bytes(size, n_rays, 0) for the fused call.  The MSI background, learned bases and
+ * the random density perturbation of the reference are not built. */
+int asurf_volume_render_cuvol(const asurf_grid* grid, const asurf_rays* rays,
+                              const asurf_render_options* opt, float* rgb_out, void* workspace,
+                              size_t workspace_bytes, void* stream);
+int asurf_volume_render_cuvol_backward(const asurf_grid* grid, const asurf_rays* rays,
+                                       const asurf_render_options* opt, const float* grad_out,
+                                       const float* color_cache, const asurf_grads* grads, void* workspace,
+                                       size_t workspace_bytes, void* stream);
+int asurf_volume_render_cuvol_fused(const asurf_grid* grid, const asurf_rays* rays,
+                                    const asurf_render_options* opt, const float* rgb_gt, float beta_loss,
+                                    float sparsity_loss, float* rgb_out, const asurf_grads* grads,
+                                    void* workspace, size_t workspace_bytes, void* stream);
+
 /* Trilinear sampling of an [n_rows, n_cols] parameter plane at `points` float[n_points,3]
  * (sample_grid / sample_grid_sh_surf / sample_grid_raw_alpha, svox2_kernel.cu:11-150, 384-489):
  * p * scaling + offset, clamped to the grid, an empty corner reads as `empty_value`; out is

@@ -1616,6 +1616,188 @@ void eval_ray(const oracle_grid& g, const oracle_render_options& o_in, const Ray
     if (mode == 1) out0[0] = (weight_acc > param) ? outv : 0.f;
 }
 
+
+// =================================================================================
+// The Plenoxels volume renderer (`cuvol` backend).  render_lerp_kernel_cuvol.cu
+// =================================================================================
+// compute_skip_dist, render_util.cuh:286-348: links below -1 hold the distance transform written by
+// accelerate() (misc_kernel.cu accel_dist_*); the cell side of a link value -d is 2^(d-1).
+float cuvol_skip_dist(const oracle_grid& g, const Ray& r, const int32_t* l, const float* pos) {
+    const int64_t offx = (int64_t)g.size[1] * g.size[2], offy = g.size[2];
+    const int32_t link_val = g.links[offx * l[0] + offy * l[1] + l[2]];
+    if (link_val >= -1) return 0.f;
+    const uint32_t dist = (uint32_t)(-link_val);
+    const uint32_t shift = dist - 1;
+    const uint32_t side = (uint32_t)((float)(1 << shift) - 1.f);
+    float tmin = 0.f, tmax = 1e9f;
+    for (int i = 0; i < 3; ++i) {
+        int ul = ((l[i] >> shift) << shift);
+        ul -= l[i];
+        const float invdir = (float)(1.0 / (double)r.dir[i]);
+        const float t1 = ((float)ul - pos[i]) * invdir;
+        const float t2 = ((float)(ul + side) - pos[i]) * invdir;   // uint + int -> uint, then float
+        if (r.dir[i] != 0.f) {
+            tmin = fmaxf(tmin, fminf(t1, t2));
+            if (fmaxf(t1, t2) < tmax) tmax = fmaxf(t1, t2);
+        }
+    }
+    if (tmin > 0.f) return 0.f;
+    return tmax;
+}
+
+// the sample cell and weights, render_lerp_kernel_cuvol.cu:57-62
+void cuvol_cell(const oracle_grid& g, const Ray& r, float t, int32_t* l, float* pos) {
+    for (int j = 0; j < 3; ++j) {
+        pos[j] = fmaf(t, r.dir[j], r.origin[j]);
+        pos[j] = fminf(fmaxf(pos[j], 0.f), (float)g.size[j] - 1.f);
+        l[j] = std::min((int32_t)pos[j], g.size[j] - 2);
+        pos[j] -= (float)l[j];
+    }
+}
+
+// corner links of the cell and the MAYBE_READ_LINK gather (render_util.cuh:80-91) of column idx
+void cuvol_links(const oracle_grid& g, const int32_t* l, int32_t* lk) {
+    const int64_t offx = (int64_t)g.size[1] * g.size[2], offy = g.size[2];
+    const int32_t* p = g.links + (offx * l[0] + offy * l[1] + l[2]);
+    lk[0] = p[0];
+    lk[1] = p[1];
+    lk[2] = p[offy];
+    lk[3] = p[offy + 1];
+    lk[4] = p[offx];
+    lk[5] = p[offx + 1];
+    lk[6] = p[offx + offy];
+    lk[7] = p[offx + offy + 1];
+}
+float cuvol_lerp(const float* data, int64_t stride, int idx, const int32_t* lk, const float* pos) {
+    float v[8];
+    for (int i = 0; i < 8; ++i) v[i] = lk[i] >= 0 ? data[(int64_t)lk[i] * stride + idx] : 0.f;
+    return trilerp(v, pos);
+}
+
+// trace_ray_cuvol, render_lerp_kernel_cuvol.cu:30-125
+void cuvol_forward(const oracle_grid& g, const oracle_render_options& o, Ray r, float* out, float* out_log_transmit) {
+    if (r.tmin > r.tmax) {
+        for (int c = 0; c < 3; ++c) out[c] = o.background_brightness;
+        if (out_log_transmit) *out_log_transmit = 0.f;
+        return;
+    }
+    const int B = g.basis_dim;
+    float t = r.tmin, log_transmit = 0.f;
+    float outv[3] = {0.f, 0.f, 0.f};
+    while (t <= r.tmax) {
+        int32_t l[3], lk[8];
+        float pos[3];
+        cuvol_cell(g, r, t, l, pos);
+        const float skip = cuvol_skip_dist(g, r, l, pos);
+        if (skip >= o.step_size) {
+            t += ceilf(skip / o.step_size) * o.step_size;
+            continue;
+        }
+        cuvol_links(g, l, lk);
+        const float sigma = cuvol_lerp(g.density_data, 1, 0, lk, pos);
+        if (o.last_sample_opaque && t + o.step_size > r.tmax) r.world_step = 1e9f;
+        if (sigma > o.sigma_thresh) {
+            const float pcnt = r.world_step * sigma;
+            const float weight = expf(log_transmit) * (1.f - expf(-pcnt));
+            log_transmit -= pcnt;
+            for (int c = 0; c < 3; ++c) {
+                float tot = 0.f;
+                for (int k = 0; k < B; ++k) tot += cuvol_lerp(g.sh_data, 3 * B, c * B + k, lk, pos) * r.sph[k];
+                outv[c] += weight * fmaxf(tot + 0.5f, 0.f);
+            }
+            if (expf(log_transmit) < o.stop_thresh) {
+                log_transmit = -1e3f;
+                break;
+            }
+        }
+        t += o.step_size;
+    }
+    for (int c = 0; c < 3; ++c) out[c] = outv[c] + expf(log_transmit) * o.background_brightness;
+    if (out_log_transmit) *out_log_transmit = log_transmit;
+}
+
+// trace_ray_cuvol_backward, render_lerp_kernel_cuvol.cu:371-536
+void cuvol_backward(const oracle_grid& g, const oracle_render_options& o, Ray r, const float* gout,
+                    const float* color_cache, bool has_log_transmit, float log_transmit_in, float beta_loss,
+                    float sparsity_loss, const oracle_grads& G) {
+    float accum = fmaf(color_cache[0], gout[0], fmaf(color_cache[1], gout[1], color_cache[2] * gout[2]));
+    if (beta_loss > 0.f) {
+        const float transmit_in = expf(has_log_transmit ? log_transmit_in : 0.f);
+        beta_loss = (float)((double)beta_loss * (1. - (double)transmit_in / (double)(1 - transmit_in + 1e-3)));
+        accum += beta_loss;
+    }
+    if (r.tmin > r.tmax) return;
+    const int B = g.basis_dim;
+    float t = r.tmin, log_transmit = 0.f;
+    while (t <= r.tmax) {
+        int32_t l[3], lk[8];
+        float pos[3];
+        cuvol_cell(g, r, t, l, pos);
+        const float skip = cuvol_skip_dist(g, r, l, pos);
+        if (skip >= o.step_size) {
+            t += ceilf(skip / o.step_size) * o.step_size;
+            continue;
+        }
+        cuvol_links(g, l, lk);
+        const float sigma = cuvol_lerp(g.density_data, 1, 0, lk, pos);
+        if (o.last_sample_opaque && t + o.step_size > r.tmax) r.world_step = 1e9f;
+        if (sigma > o.sigma_thresh) {
+            const float pcnt = r.world_step * sigma;
+            const float weight = expf(log_transmit) * (1.f - expf(-pcnt));
+            log_transmit -= pcnt;
+            float total_color = 0.f;
+            float ch[3], in01[3];
+            for (int c = 0; c < 3; ++c) {
+                float tot = 0.f;
+                for (int k = 0; k < B; ++k) tot += cuvol_lerp(g.sh_data, 3 * B, c * B + k, lk, pos) * r.sph[k];
+                tot += 0.5f;
+                const float cl = fmaxf(tot, 0.f);
+                in01[c] = (cl == tot) ? 1.f : 0.f;
+                ch[c] = cl * gout[c];
+            }
+            total_color = ch[0] + ch[2];   // :469-471 (c0 + c2, then + c1)
+            total_color += ch[1];
+            float cw[8];
+            corner_weights(pos, 1.f, cw);
+            if (G.grad_sh_out) {
+                for (int c = 0; c < 3; ++c) {
+                    const float grad_common = weight * in01[c] * gout[c];
+                    for (int k = 0; k < B; ++k) {
+                        const float curr = r.sph[k] * grad_common;
+                        float w8[8];
+                        corner_weights(pos, curr, w8);
+                        for (int i = 0; i < 8; ++i)
+                            if (lk[i] >= 0) atomic_addf(&G.grad_sh_out[(int64_t)lk[i] * 3 * B + c * B + k], w8[i]);
+                    }
+                }
+            }
+            accum -= weight * total_color;
+            float curr_grad_sigma = r.world_step * (total_color * expf(log_transmit) - accum);
+            if (sparsity_loss > 0.f) curr_grad_sigma += sparsity_loss * (4 * sigma / (1 + 2 * (sigma * sigma)));
+            if (G.grad_density_out) {
+                float w8[8];
+                corner_weights(pos, curr_grad_sigma, w8);
+                for (int i = 0; i < 8; ++i)
+                    if (lk[i] >= 0) {
+                        atomic_addf(&G.grad_density_out[lk[i]], w8[i]);
+                        if (G.mask_out) G.mask_out[lk[i]] = 1;
+                    }
+            }
+            if (expf(log_transmit) < o.stop_thresh) break;
+        }
+        t += o.step_size;
+    }
+}
+
+int cuvol_check(const oracle_grid* g, const oracle_rays* r, const oracle_render_options* o) {
+    if (!g || !r || !o) return -1;
+    if (g->basis_type != 1 || g->background_nlayers != 0) return -2;
+    if (!(g->basis_dim == 1 || g->basis_dim == 4 || g->basis_dim == 9 || g->basis_dim == 16)) return -1;
+    if (!g->links || !g->density_data || !g->sh_data) return -1;
+    if (!(o->step_size > 0.f)) return -1;
+    return 0;
+}
+
 }  // namespace
 
 extern "C" {
@@ -1847,6 +2029,55 @@ int oracle_render_eval(const oracle_grid* grid, const oracle_rays* rays, const o
         setup_ray(*grid, *opt, rays->origins + 3 * q, rays->dirs + 3 * q, r);
         eval_ray(*grid, *opt, r, mode, param, max_sample, out0 + (size_t)stride * q,
                  out1 ? out1 + (size_t)stride * q : nullptr);
+    }
+    return 0;
+}
+
+/* render_lerp_kernel_cuvol.cu:1120-1165 */
+int oracle_volume_render_cuvol(const oracle_grid* grid, const oracle_rays* rays, const oracle_render_options* opt,
+                               float* rgb_out) {
+    if (int rc = cuvol_check(grid, rays, opt)) return rc;
+#pragma omp parallel for schedule(dynamic, 64)
+    for (int64_t q = 0; q < rays->n_rays; ++q) {
+        Ray r;
+        setup_ray(*grid, *opt, rays->origins + 3 * q, rays->dirs + 3 * q, r);
+        cuvol_forward(*grid, *opt, r, rgb_out + 3 * q, nullptr);
+    }
+    return 0;
+}
+
+/* render_lerp_kernel_cuvol.cu:1209-1270 */
+int oracle_volume_render_cuvol_backward(const oracle_grid* grid, const oracle_rays* rays,
+                                        const oracle_render_options* opt, const float* grad_out,
+                                        const float* color_cache, const oracle_grads* grads) {
+    if (int rc = cuvol_check(grid, rays, opt)) return rc;
+    if (!grads || !grad_out || !color_cache) return -1;
+#pragma omp parallel for schedule(dynamic, 64)
+    for (int64_t q = 0; q < rays->n_rays; ++q) {
+        Ray r;
+        setup_ray(*grid, *opt, rays->origins + 3 * q, rays->dirs + 3 * q, r);
+        cuvol_backward(*grid, *opt, r, grad_out + 3 * q, color_cache + 3 * q, false, 0.f, 0.f, 0.f, *grads);
+    }
+    return 0;
+}
+
+/* render_lerp_kernel_cuvol.cu:1272-1354: beta_loss / Q (:1323), gout = (rgb - gt) * 2 / (3 Q) (:889-895) */
+int oracle_volume_render_cuvol_fused(const oracle_grid* grid, const oracle_rays* rays,
+                                     const oracle_render_options* opt, const float* rgb_gt, float beta_loss,
+                                     float sparsity_loss, float* rgb_out, const oracle_grads* grads) {
+    if (int rc = cuvol_check(grid, rays, opt)) return rc;
+    if (!grads || !rgb_gt || !rgb_out) return -1;
+    const float norm = 2.f / (3 * (int)rays->n_rays);
+    const float beta = beta_loss / (float)rays->n_rays;
+#pragma omp parallel for schedule(dynamic, 64)
+    for (int64_t q = 0; q < rays->n_rays; ++q) {
+        Ray r;
+        setup_ray(*grid, *opt, rays->origins + 3 * q, rays->dirs + 3 * q, r);
+        float log_t = 0.f;
+        cuvol_forward(*grid, *opt, r, rgb_out + 3 * q, &log_t);
+        float gout[3];
+        for (int c = 0; c < 3; ++c) gout[c] = (rgb_out[3 * q + c] - rgb_gt[3 * q + c]) * norm;
+        cuvol_backward(*grid, *opt, r, gout, rgb_out + 3 * q, beta_loss > 0.f, log_t, beta, sparsity_loss, *grads);
     }
     return 0;
 }

@@ -181,6 +181,17 @@ int64_t oracle_trace_voxel_lists(const oracle_grid* grid, const oracle_rays* ray
 /* SH basis at unit directions (render_util.cuh:405-436; svox2/utils.py:119-166) */
 void oracle_eval_sh(int32_t basis_dim, const float* dirs, int64_t n, float* out);
 
+/* render_lerp_kernel_cuvol.cu:1120-1354 (the Plenoxels `cuvol` renderer; surface_data may be NULL) */
+int oracle_volume_render_cuvol(const oracle_grid* grid, const oracle_rays* rays,
+                               const oracle_render_options* opt, float* rgb_out);
+int oracle_volume_render_cuvol_backward(const oracle_grid* grid, const oracle_rays* rays,
+                                        const oracle_render_options* opt, const float* grad_out,
+                                        const float* color_cache, const oracle_grads* grads);
+int oracle_volume_render_cuvol_fused(const oracle_grid* grid, const oracle_rays* rays,
+                                     const oracle_render_options* opt, const float* rgb_gt,
+                                     float beta_loss, float sparsity_loss, float* rgb_out,
+                                     const oracle_grads* grads);
+
 #ifdef __cplusplus
 }
 #endif

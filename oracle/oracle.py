@@ -331,6 +331,38 @@ def surface_fused(sc, origins, dirs, ray_vox, opts, rgb_gt, beta_loss=0.0, spars
     return rgb, grads
 
 
+def cuvol_forward(sc, origins, dirs, opts=None):
+    """volume_render_cuvol (render_lerp_kernel_cuvol.cu:1120-1165); sc["surface"] is not read."""
+    r = _rays(origins, dirs)
+    rgb = np.zeros((r.n_rays, 3), np.float32)
+    g, o = _grid(sc), make_opts(opts)
+    _check(lib().oracle_volume_render_cuvol(C.byref(g), C.byref(r), C.byref(o), _f(rgb)), "cuvol forward")
+    return rgb
+
+
+def cuvol_backward(sc, origins, dirs, opts, grad_out, color_cache, grads=None):
+    r = _rays(origins, dirs)
+    grads = grads if grads is not None else zero_grads(sc)
+    grad_out = np.ascontiguousarray(grad_out, np.float32)
+    color_cache = np.ascontiguousarray(color_cache, np.float32)
+    g, o, gg = _grid(sc), make_opts(opts), _grads(grads)
+    _check(lib().oracle_volume_render_cuvol_backward(
+        C.byref(g), C.byref(r), C.byref(o), _f(grad_out), _f(color_cache), C.byref(gg)), "cuvol backward")
+    return grads
+
+
+def cuvol_fused(sc, origins, dirs, opts, rgb_gt, beta_loss=0.0, sparsity_loss=0.0, grads=None):
+    r = _rays(origins, dirs)
+    grads = grads if grads is not None else zero_grads(sc)
+    rgb_gt = np.ascontiguousarray(rgb_gt, np.float32)
+    rgb = np.zeros((r.n_rays, 3), np.float32)
+    g, o, gg = _grid(sc), make_opts(opts), _grads(grads)
+    _check(lib().oracle_volume_render_cuvol_fused(
+        C.byref(g), C.byref(r), C.byref(o), _f(rgb_gt), C.c_float(beta_loss), C.c_float(sparsity_loss),
+        _f(rgb), C.byref(gg)), "cuvol fused")
+    return rgb, grads
+
+
 def set_legacy_f64_surface_grad(on):
     lib().oracle_set_legacy_f64_surface_grad(int(bool(on)))
 

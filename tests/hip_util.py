@@ -161,6 +161,47 @@ def surface_fused(sc, origins, dirs, ray_vox, opts, rgb_gt, beta_loss=0.0, spars
     return rgb.cpu().numpy(), grads_np(gr)
 
 
+# ---- the Plenoxels `cuvol` renderer ----
+def _cuvol_grads(g):
+    gr = _C.GridOutputGrads()
+    gr.grad_density_out = torch.zeros_like(g.density_data)
+    gr.grad_sh_out = torch.zeros_like(g.sh_data)
+    gr.mask_out = torch.zeros(g.density_data.shape[0], dtype=torch.bool, device=dev())
+    return gr
+
+
+def _cuvol_grads_np(gr):
+    return dict(density=gr.grad_density_out.cpu().numpy(), sh=gr.grad_sh_out.cpu().numpy(),
+                mask=gr.mask_out.cpu().numpy())
+
+
+def cuvol_forward(sc, origins, dirs, opts=None):
+    g, r, o = grid_spec(sc), rays_spec(origins, dirs), opt_spec(opts)
+    rgb = _C.volume_render_cuvol(g, r, o)
+    torch.cuda.synchronize()
+    return rgb.cpu().numpy()
+
+
+def cuvol_backward(sc, origins, dirs, opts, grad_out, color_cache):
+    g, r, o = grid_spec(sc), rays_spec(origins, dirs), opt_spec(opts)
+    gr = _cuvol_grads(g)
+    _C.volume_render_cuvol_backward(
+        g, r, o, torch.from_numpy(np.ascontiguousarray(grad_out, np.float32)).to(dev()),
+        torch.from_numpy(np.ascontiguousarray(color_cache, np.float32)).to(dev()), gr)
+    torch.cuda.synchronize()
+    return _cuvol_grads_np(gr)
+
+
+def cuvol_fused(sc, origins, dirs, opts, rgb_gt, beta_loss=0.0, sparsity_loss=0.0):
+    g, r, o = grid_spec(sc), rays_spec(origins, dirs), opt_spec(opts)
+    gr = _cuvol_grads(g)
+    gt = torch.from_numpy(np.ascontiguousarray(rgb_gt, np.float32)).to(dev())
+    rgb = torch.zeros_like(gt)
+    _C.volume_render_cuvol_fused(g, r, o, gt, beta_loss, sparsity_loss, rgb, gr)
+    torch.cuda.synchronize()
+    return rgb.cpu().numpy(), _cuvol_grads_np(gr)
+
+
 # ---- evaluation renders ----
 def render_eval(sc, origins, dirs, opts, what, param=0.0, max_sample=1):
     g, r, o = grid_spec(sc), rays_spec(origins, dirs), opt_spec(opts)

@@ -1,0 +1,188 @@
+"""HIP `cuvol` renderer (the Plenoxels volume renderer of render_lerp_kernel_cuvol.cu) through the
+C ABI, against the reference's goldens (its PyTorch renderer, tests/golden/gen_golden_cuvol.py) and
+the CPU oracle.  `pytest -m gpu`."""
+import numpy as np
+import pytest
+
+from golden_util import grad_close
+from test_hip_parity import hip  # noqa: F401  (fixture)
+from test_oracle_cuvol import CUVOL_CASES, load_cuvol
+
+pytestmark = pytest.mark.gpu
+
+
+def cuvol_scene(basis_dim, reso=48, seed=5, surface_type=100):
+    """Pruned-grid look-alike with signed densities (the gate sigma > sigma_thresh acts)."""
+    from alphasurf_amd import synth
+    sc = synth.make_sparse_scene(reso, basis_dim, seed=seed)
+    rs = np.random.RandomState(seed + 7)
+    n = sc["density"].shape[0]
+    sc["density"] = (rs.randn(n, 1) * 3.0 + 1.0).astype(np.float32)
+    sc["sh"][:, ::basis_dim] = (0.5 + 0.3 * rs.randn(n, 3)).astype(np.float32)
+    sc["surface_type"] = surface_type
+    o, d = synth.random_rays(2000, seed + 100)
+    return sc, o, d
+
+
+def compare(hip, oracle, sc, o, d, opts, beta_loss=0.0, sparsity_loss=0.0, rgb_tol=2e-5, grad_tol=2e-4):
+    gt = np.random.RandomState(3).rand(o.shape[0], 3).astype(np.float32)
+    rgb, g = hip.cuvol_fused(sc, o, d, opts, gt, beta_loss=beta_loss, sparsity_loss=sparsity_loss)
+    rgb_o, go = oracle.cuvol_fused(sc, o, d, opts, gt, beta_loss=beta_loss, sparsity_loss=sparsity_loss)
+    assert np.abs(rgb - rgb_o).max() <= rgb_tol, np.abs(rgb - rgb_o).max()
+    for k in ("sh", "density"):
+        grad_close(g[k], go[k], grad_tol, f"grad_{k}")
+    assert (g["mask"].astype(bool) == go["mask"].astype(bool)).all()
+    return rgb, g
+
+
+@pytest.mark.parametrize("name", CUVOL_CASES)
+def test_golden(hip, oracle, name):
+    z, sc, opt = load_cuvol(oracle, name)
+    sc["surface_type"] = 100
+    rgb, g = hip.cuvol_fused(sc, z["origins"], z["dirs"], opt, z["rgb_gt"])
+    assert np.abs(rgb - z["rgb"]).max() <= 1e-4
+    grad_close(g["sh"], z["grad_sh"], 5e-4, f"{name} grad_sh")
+    grad_close(g["density"], z["grad_density"], 5e-4, f"{name} grad_density")
+    compare(hip, oracle, sc, z["origins"], z["dirs"], opt)
+    fwd = hip.cuvol_forward(sc, z["origins"], z["dirs"], opt)
+    np.testing.assert_array_equal(fwd, rgb)
+
+
+OPTION_SETS = {
+    "plenoxels": dict(sigma_thresh=1e-8, stop_thresh=1e-7, step_size=0.5),
+    "gate": dict(sigma_thresh=0.7, stop_thresh=1e-3, step_size=0.31),
+    "no_gate": dict(sigma_thresh=-1e9, stop_thresh=0.0, step_size=0.8),
+    "opaque_end": dict(sigma_thresh=0.0, stop_thresh=1e-7, step_size=0.5, last_sample_opaque=True),
+    "near_clip": dict(sigma_thresh=0.0, stop_thresh=1e-7, step_size=0.45, near_clip=0.35),
+    "spheric": dict(sigma_thresh=0.0, stop_thresh=0.0, step_size=0.5, use_spheric_clip=True, near_clip=0.1),
+    "dark": dict(sigma_thresh=0.0, stop_thresh=1e-7, step_size=0.5, background_brightness=0.0),
+}
+
+
+@pytest.mark.parametrize("basis_dim", [1, 4, 9, 16])
+@pytest.mark.parametrize("optname", list(OPTION_SETS))
+def test_sparse_scene_vs_oracle(hip, oracle, basis_dim, optname):
+    sc, o, d = cuvol_scene(basis_dim)
+    rgb, g = compare(hip, oracle, sc, o, d, OPTION_SETS[optname])
+    assert np.abs(g["density"]).max() > 0 and (np.abs(rgb - OPTION_SETS[optname].get("background_brightness", 1.0))
+                                                .max(axis=1) > 1e-3).sum() > 300
+
+
+@pytest.mark.parametrize("beta,sparsity", [(0.1, 0.0), (0.0, 0.02), (0.05, 0.01)])
+def test_fused_losses(hip, oracle, beta, sparsity):
+    sc, o, d = cuvol_scene(9)
+    compare(hip, oracle, sc, o, d, OPTION_SETS["plenoxels"], beta_loss=beta, sparsity_loss=sparsity)
+
+
+def test_backward_equals_fused(hip, oracle):
+    sc, o, d = cuvol_scene(4)
+    opt = OPTION_SETS["plenoxels"]
+    gt = np.random.RandomState(3).rand(o.shape[0], 3).astype(np.float32)
+    rgb, gf = hip.cuvol_fused(sc, o, d, opt, gt)
+    gout = (rgb - gt) * np.float32(2.0 / (3 * rgb.shape[0]))
+    gb = hip.cuvol_backward(sc, o, d, opt, gout, rgb)
+    for k in ("sh", "density"):
+        grad_close(gb[k], gf[k], 1e-5, k)
+    go = oracle.cuvol_backward(sc, o, d, opt, gout, rgb)
+    for k in ("sh", "density"):
+        grad_close(gb[k], go[k], 2e-4, k)
+
+
+def test_surface_plane_is_ignored(hip, oracle):
+    """An SDF grid rendered with cuvol (the `no_surface` warm-up of opt.py:690-830) == the same
+    grid without its surface plane."""
+    sc, o, d = cuvol_scene(4, surface_type=102)
+    a = hip.cuvol_forward(sc, o, d, OPTION_SETS["plenoxels"])
+    b = hip.cuvol_forward(dict(sc, surface_type=100), o, d, OPTION_SETS["plenoxels"])
+    np.testing.assert_array_equal(a, b)
+
+
+@pytest.mark.parametrize("shape", [(40, 24, 56), (17, 33, 9), (8, 8, 8), (3, 5, 2)])
+def test_odd_shapes_and_sample_set(hip, oracle, shape):
+    """Grids that are not whole bricks, down to smaller than one; dense random links (some missing
+    corners inside the cells that are sampled)."""
+    rs = np.random.RandomState(sum(shape))
+    present = rs.rand(*shape) < 0.6
+    n = int(present.sum())
+    links = np.full(shape, -1, np.int32)
+    links[present] = np.arange(n, dtype=np.int32)
+    B = 4
+    sh = (rs.randn(n, 3 * B) * 0.2).astype(np.float32)
+    sc = oracle.make_scene(links, (rs.randn(n, 1) * 3 + 1).astype(np.float32), np.zeros((n, 1), np.float32), sh,
+                           np.zeros((0,), np.float32), 0.5 * np.asarray(shape, np.float32),
+                           0.5 * np.asarray(shape, np.float32), B, surface_type=100)
+    from alphasurf_amd import synth
+    o, d = synth.random_rays(1500, 9)
+    compare(hip, oracle, sc, o, d, dict(sigma_thresh=0.0, stop_thresh=1e-7, step_size=0.5))
+
+
+def test_empty_brick_skipping_is_exact(hip, oracle):
+    """A few small blobs in a 96^3 grid: almost every brick is empty, rays start far outside, inside,
+    graze faces.  The HIP march leaves empty bricks in one move and must still evaluate exactly the
+    reference's sample parameters (repeated t += step): tight tolerance, every ray."""
+    from alphasurf_amd import synth
+    sc = synth.make_sparse_scene(96, 4, seed=11, n_spheres=3, radius_range=(0.04, 0.08), band=2.0, dilate=1)
+    rs = np.random.RandomState(2)
+    n = sc["density"].shape[0]
+    sc["density"] = (np.abs(rs.randn(n, 1)) * 2.0).astype(np.float32)
+    sc["surface_type"] = 100
+    o, d = synth.random_rays(3000, 77)
+    # axis-parallel and face-grazing rays
+    o2 = np.tile(np.array([[-3.0, 0.0, 0.0]], np.float32), (64, 1))
+    o2[:, 1:] = rs.uniform(-0.6, 0.6, size=(64, 2))
+    d2 = np.tile(np.array([[1.0, 0.0, 0.0]], np.float32), (64, 1))
+    o3 = rs.uniform(-0.5, 0.5, size=(200, 3)).astype(np.float32)          # origins inside the grid
+    d3 = rs.randn(200, 3).astype(np.float32)
+    d3 /= np.linalg.norm(d3, axis=1, keepdims=True)
+    o, d = np.concatenate([o, o2, o3]), np.concatenate([d, d2, d3])
+    for opts in (dict(sigma_thresh=1e-8, stop_thresh=1e-7, step_size=0.5),
+                 dict(sigma_thresh=1e-8, stop_thresh=0.0, step_size=0.07),
+                 dict(sigma_thresh=1e-8, stop_thresh=1e-7, step_size=2.9, last_sample_opaque=True)):
+        compare(hip, oracle, sc, o, d, opts, rgb_tol=1e-5, grad_tol=1e-4)
+
+
+def test_errors(hip):
+    sc, o, d = cuvol_scene(4)
+    with pytest.raises(RuntimeError):
+        hip.cuvol_forward(sc, o, d, dict(step_size=0.0))
+    rgb = hip.cuvol_forward(sc, o[:0], d[:0], OPTION_SETS["plenoxels"])
+    assert rgb.shape == (0, 3)
+
+
+def test_sparse_grid_api(hip):
+    """SparseGrid with backend 'cuvol' (a surface-less grid) and `no_surface=True` on an SDF grid."""
+    import torch
+    import svox2
+    from alphasurf_amd import synth
+    dev = torch.device("cuda:0")
+    grid = svox2.SparseGrid(reso=32, basis_dim=4, use_sphere_bound=True, device=dev,
+                            surface_type=svox2.SURFACE_TYPE_NONE)
+    grid.opt.backend = "cuvol"
+    grid.opt.sigma_thresh, grid.opt.stop_thresh, grid.opt.step_size = 1e-8, 1e-7, 0.5
+    gen = torch.Generator(device="cpu").manual_seed(0)
+    grid.density_data.data[:] = (torch.randn(grid.density_data.shape, generator=gen) * 2 + 1).to(dev)
+    grid.sh_data.data[:] = (torch.randn(grid.sh_data.shape, generator=gen) * 0.2).to(dev)
+    o, d = synth.random_rays(1024, 3)
+    rays = svox2.Rays(torch.from_numpy(o).to(dev), torch.from_numpy(d).to(dev))
+    gt = torch.rand(1024, 3, generator=gen).to(dev)
+    rgb = grid.volume_render(rays)["rgb"]
+    torch.nn.functional.mse_loss(rgb, gt).backward()
+    ga_d, ga_s = grid.density_data.grad.clone(), grid.sh_data.grad.clone()
+    grid.density_data.grad = grid.sh_data.grad = None
+    out = grid.volume_render_fused(rays, gt)["rgb"]
+    assert torch.equal(out, rgb.detach())
+    assert torch.allclose(grid.density_data.grad, ga_d, rtol=1e-4, atol=1e-7 * float(ga_d.abs().max()) + 1e-12)
+    assert torch.allclose(grid.sh_data.grad, ga_s, rtol=1e-4, atol=1e-5 * float(ga_s.abs().max()))
+    assert grid.sparse_grad_indexer.any()
+
+    sdf = svox2.SparseGrid(reso=32, basis_dim=4, use_sphere_bound=True, device=dev,
+                           surface_type=svox2.SURFACE_TYPE_SDF, surface_init="sphere")
+    sdf.opt.backend = "surf_trav"
+    sdf.opt.sigma_thresh, sdf.opt.stop_thresh, sdf.opt.step_size = 1e-8, 1e-7, 0.5
+    sdf.density_data.data[:] = grid.density_data.data
+    sdf.sh_data.data[:] = grid.sh_data.data
+    out2 = sdf.volume_render_fused(rays, gt, no_surface=True)["rgb"]
+    assert torch.equal(out2, out)
+    assert sdf.surface_data.grad is None or not sdf.surface_data.grad.any()
+    assert torch.equal(sdf.density_data.grad, grid.density_data.grad) or \
+        torch.allclose(sdf.density_data.grad, grid.density_data.grad, rtol=1e-4, atol=1e-9)
