@@ -61,15 +61,18 @@ __device__ __forceinline__ void march_cell(const March& m, float t, int* l, floa
     pos[2] = p2 - (float)l[2];
 }
 
-// Advances m.t to the next sample parameter whose cell is flagged; returns false when the ray ends.
-// On success *t_out, l, pos describe that point (the caller then adds one step).
+// Advances m.t to the next sample parameter whose cell is flagged; on success *t_out, l, pos describe
+// that point (the caller then adds one step).
+// `budget` (lattice points this call may still visit) bounds the divergence between the lanes of a
+// wave: 0 = ray ended, 1 = found, 2 = budget spent (call again).
 template <bool LDS>
-__device__ __forceinline__ bool march_next(const KGrid& g, const unsigned int* lds_coarse, March& m,
-                                           float* t_out, int* l, float* pos) {
-    // the guard only exists so that no defect can keep a wave alive (every iteration advances t)
-    for (int guard = 0; guard < (1 << 22); ++guard) {
+__device__ __forceinline__ int march_next(const KGrid& g, const unsigned int* lds_coarse, March& m,
+                                          float* t_out, int* l, float* pos, int& budget) {
+    // every iteration advances t and spends budget: no defect can keep a wave alive
+    while (budget > 0) {
+        --budget;
         const float t = m.t;
-        if (!(t <= m.tmax)) return false;
+        if (!(t <= m.tmax)) return 0;
         march_cell(m, t, l, pos);
         const int key = ((l[0] >> 3) << 20) | ((l[1] >> 3) << 10) | (l[2] >> 3);
         if (key != m.cur_key) {
@@ -113,28 +116,159 @@ __device__ __forceinline__ bool march_next(const KGrid& g, const unsigned int* l
         }
         if ((m.cur_word >> (((l[1] & 7) << 3) | (l[2] & 7))) & 1ull) {
             *t_out = t;
-            return true;
+            return 1;
         }
         m.t += m.step;
     }
-    return false;
+    return 2;
 }
 
-// 8 corner links of cell l and the trilinear raw density (missing corner = 0)
-__device__ __forceinline__ float cuvol_sigma(const KGrid& g, const int* l, const float* pos, int* lk) {
-    const int32_t* p = g.links + ((size_t)l[0] * g.offx + (size_t)l[1] * g.offy + l[2]);
-    lk[0] = p[0];
-    lk[1] = p[1];
-    lk[2] = p[g.offy];
-    lk[3] = p[g.offy + 1];
-    lk[4] = p[g.offx];
-    lk[5] = p[g.offx + 1];
-    lk[6] = p[g.offx + g.offy];
-    lk[7] = p[g.offx + g.offy + 1];
-    float v[8];
+// ------------------------------------------------------------------------------------
+// Records.  A lane gathers up to kCuvolK consecutive counting samples of its ray that lie in ONE
+// cell (at step 0.5 a ray spends ~1.7 samples per cell) and the wave then serves that record: the
+// cell's 8 SH rows are loaded once (and stay in registers while the next lanes' records name the
+// same cell), every sample costs only its weights and three reductions, and in the backward pass
+// the SH gradient of all samples of all consecutive records of one cell leaves as ONE set of
+// row-contiguous atomics.  Weights and the stopping rule depend on the densities alone
+// (render_lerp_kernel_cuvol.cu:99-111), so the lane knows them before any colour exists.
+// ------------------------------------------------------------------------------------
+constexpr int kCuvolK = 4;
+#ifndef ASURF_CUVOL_BUDGET
+#define ASURF_CUVOL_BUDGET 4
+#endif
+constexpr int kCuvolBudget = ASURF_CUVOL_BUDGET;  // lattice points a lane may visit per round
+
+struct CuvolCell {  // the cell whose corner data the lane holds in registers
+    int cid;        // flat index of its first corner in `links`; -1 = none
+    int lk0, lk1, lk2, lk3, lk4, lk5, lk6, lk7;
+    float d0, d1, d2, d3, d4, d5, d6, d7;
+};
+
+struct CuvolSmp {
+    float px, py, pz;  // position in the cell
+    float w;           // compositing weight
+    float ws;          // world step (1e9 for an opaque last sample)
+    float ta;          // transmittance after the sample
+    float sig;
+};
+
+// Next sample whose density exceeds sigma_thresh; m.t is left one step past it.
+template <bool CLDS>
+__device__ __forceinline__ int cuvol_next(const KGrid& g, const KOpt& o, const unsigned int* lds_coarse,
+                                          March& m, CuvolCell& c, float* t, float* pos, float* sigma, int& budget) {
+    while (true) {
+        int l[3];
+        const int got = march_next<CLDS>(g, lds_coarse, m, t, l, pos, budget);
+        if (got != 1) return got;
+        const int cid = l[0] * g.offx + l[1] * g.offy + l[2];
+        if (cid != c.cid) {
+            c.cid = cid;
+            const int32_t* p = g.links + cid;
+            c.lk0 = p[0];
+            c.lk1 = p[1];
+            c.lk2 = p[g.offy];
+            c.lk3 = p[g.offy + 1];
+            c.lk4 = p[g.offx];
+            c.lk5 = p[g.offx + 1];
+            c.lk6 = p[g.offx + g.offy];
+            c.lk7 = p[g.offx + g.offy + 1];
+            c.d0 = c.lk0 >= 0 ? g.density[c.lk0] : 0.f;
+            c.d1 = c.lk1 >= 0 ? g.density[c.lk1] : 0.f;
+            c.d2 = c.lk2 >= 0 ? g.density[c.lk2] : 0.f;
+            c.d3 = c.lk3 >= 0 ? g.density[c.lk3] : 0.f;
+            c.d4 = c.lk4 >= 0 ? g.density[c.lk4] : 0.f;
+            c.d5 = c.lk5 >= 0 ? g.density[c.lk5] : 0.f;
+            c.d6 = c.lk6 >= 0 ? g.density[c.lk6] : 0.f;
+            c.d7 = c.lk7 >= 0 ? g.density[c.lk7] : 0.f;
+        }
+        const float v[8] = {c.d0, c.d1, c.d2, c.d3, c.d4, c.d5, c.d6, c.d7};
+        *sigma = trilerp8(v, pos);
+        m.t += m.step;
+        if (*sigma > o.sigma_thresh) return 1;
+    }
+}
+
+// Per-lane gathering state that survives from one record to the next
+struct CuvolGather {
+    CuvolCell cell;
+    bool pend;  // a counting sample of the NEXT cell was already found (cell holds its data)
+    float pend_t, pend_px, pend_py, pend_pz, pend_sig;
+    float log_transmit;
+};
+
+// Fills one record (<= kCuvolK samples of one cell) for this lane: returns the sample count, writes
+// the cell's links to *rec.  `active` turns false when the ray has ended or reached stop_thresh.
+template <bool CLDS>
+__device__ __forceinline__ int cuvol_gather(const KGrid& g, const KOpt& o, const unsigned int* lds_coarse,
+                                            March& m, CuvolGather& st, float tmax, float world_step,
+                                            int last_sample_opaque, bool& active, LaneRec* rec, int* rec_cid,
+                                            CuvolSmp* smp) {
+    int n = 0;
+    bool collecting = active;
+    int budget = kCuvolBudget;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) v[i] = lk[i] >= 0 ? g.density[lk[i]] : 0.f;
-    return trilerp8(v, pos);
+    for (int j = 0; j < kCuvolK; ++j) {
+        smp[j].px = smp[j].py = smp[j].pz = 0.f;
+        smp[j].w = 0.f;
+        smp[j].ws = world_step;
+        smp[j].ta = 0.f;
+        smp[j].sig = 0.f;
+        if (collecting) {
+            float t = st.pend_t, pos[3] = {st.pend_px, st.pend_py, st.pend_pz}, sigma = st.pend_sig;
+            bool have = st.pend;
+            if (!have) {
+                const int got = cuvol_next<CLDS>(g, o, lds_coarse, m, st.cell, &t, pos, &sigma, budget);
+                have = got == 1;
+                if (!have) {
+                    active = active && got != 0;
+                    collecting = false;
+                } else if (j > 0 && st.cell.cid != *rec_cid) {
+                    // first sample of the next cell: keep it for the next record
+                    st.pend = true;
+                    st.pend_t = t;
+                    st.pend_px = pos[0];
+                    st.pend_py = pos[1];
+                    st.pend_pz = pos[2];
+                    st.pend_sig = sigma;
+                    have = false;
+                    collecting = false;
+                }
+            }
+            if (have) {
+                st.pend = false;
+                if (j == 0) {
+                    *rec_cid = st.cell.cid;
+                    rec->link[0] = st.cell.lk0;
+                    rec->link[1] = st.cell.lk1;
+                    rec->link[2] = st.cell.lk2;
+                    rec->link[3] = st.cell.lk3;
+                    rec->link[4] = st.cell.lk4;
+                    rec->link[5] = st.cell.lk5;
+                    rec->link[6] = st.cell.lk6;
+                    rec->link[7] = st.cell.lk7;
+                }
+                const float ws = (last_sample_opaque && t + o.step_size > tmax) ? 1e9f : world_step;  // :93-95
+                const float pcnt = ws * sigma;
+                const float weight = expf(st.log_transmit) * (1.f - expf(-pcnt));
+                st.log_transmit -= pcnt;
+                const float ta = expf(st.log_transmit);
+                smp[j].px = pos[0];
+                smp[j].py = pos[1];
+                smp[j].pz = pos[2];
+                smp[j].w = weight;
+                smp[j].ws = ws;
+                smp[j].ta = ta;
+                smp[j].sig = sigma;
+                n = j + 1;
+                if (ta < o.stop_thresh) {  // :107-110
+                    st.log_transmit = -1e3f;
+                    active = false;
+                    collecting = false;
+                }
+            }
+        }
+    }
+    return n;
 }
 
 __device__ __forceinline__ void cuvol_ray(const KGrid& g, const KOpt& o, const float* origins, const float* dirs,
@@ -148,15 +282,79 @@ __device__ __forceinline__ void cuvol_ray(const KGrid& g, const KOpt& o, const f
     *world_step = (1.f / sqrtf(ds0 * ds0 + ds1 * ds1 + ds2 * ds2)) * o.step_size;
 }
 
+__device__ __forceinline__ void cuvol_gather_init(CuvolGather& st) {
+    st.cell.cid = -1;
+    st.cell.lk0 = st.cell.lk1 = st.cell.lk2 = st.cell.lk3 = -1;
+    st.cell.lk4 = st.cell.lk5 = st.cell.lk6 = st.cell.lk7 = -1;
+    st.cell.d0 = st.cell.d1 = st.cell.d2 = st.cell.d3 = 0.f;
+    st.cell.d4 = st.cell.d5 = st.cell.d6 = st.cell.d7 = 0.f;
+    st.pend = false;
+    st.pend_t = st.pend_px = st.pend_py = st.pend_pz = st.pend_sig = 0.f;
+    st.log_transmit = 0.f;
+}
+
 // ------------------------------------------------------------------------------------
+// Serving.  Two records are served at a time, one per half wave.  In a half, lane (ch, c) =
+// (channel 0..2, corner 0..7; the fourth octet idles) holds the B coefficients of its channel in
+// its corner's SH row (one contiguous 4B-byte load), reduces them against the ray's SH basis ONCE
+// per record (the sample position does not enter), and a sample then costs one trilinear weight,
+// one multiply and a 3-step DPP sum over the 8 corners.  Sample positions come in and colours go
+// back through the record's LDS slots.
+// ------------------------------------------------------------------------------------
+struct alignas(16) CuvolRec {
+    int link[8];
+    int cid, n;
+    float g0, g1, g2;  // d(loss)/d(rgb) of the ray (backward)
+    int pad;
+};
+
+template <int B>
+struct CuvolLay {
+    static constexpr int SP = (B + 3) / 4 * 4;  // LDS floats per ray for its SH basis
+};
+
+__device__ __forceinline__ float dpp_sum8(float v) {  // lanes 8m+7 receive the sum of lanes 8m .. 8m+7
+#define ASURF_DPP_ADD8(ctrl)                                                                           \
+    v += __builtin_bit_cast(float,                                                                     \
+                            __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), ctrl, 0xf, 0xf, false))
+    ASURF_DPP_ADD8(0x111);
+    ASURF_DPP_ADD8(0x112);
+    ASURF_DPP_ADD8(0x114);
+#undef ASURF_DPP_ADD8
+    return v;
+}
+
+// The pair of records to serve next: lanes of half h get r[h]; `two` = the second one exists.
+__device__ __forceinline__ void cuvol_next_pair(unsigned long long& need, int* r0, int* r1, bool* two) {
+    *r0 = __ffsll((long long)need) - 1;
+    need &= need - 1;
+    *two = need != 0;
+    *r1 = *two ? __ffsll((long long)need) - 1 : *r0;
+    if (*two) need &= need - 1;
+}
+
+template <int B>
+__device__ __forceinline__ void cuvol_load_rows(const KGrid& g, int link, int ch, float* val) {
+    if (link >= 0) {
+        const float* row = g.sh + ((size_t)link * (3 * B) + ch * B);
+#pragma unroll
+        for (int k = 0; k < B; ++k) val[k] = row[k];
+    } else {
+#pragma unroll
+        for (int k = 0; k < B; ++k) val[k] = 0.f;
+    }
+}
+
 template <int B, bool CLDS>
 __global__ void __launch_bounds__(kBlock)
 k_cuvol_fwd(KGrid g, KOpt o, int last_sample_opaque, const float* __restrict__ origins,
             const float* __restrict__ dirs, long long Q, float* __restrict__ rgb_out,
             float* __restrict__ log_transmit_out) {
+    constexpr int SP = CuvolLay<B>::SP;
     extern __shared__ unsigned int s_coarse[];
-    __shared__ float s_sph[kBlock * kSphPad];
-    __shared__ LaneRec s_rec[kBlock];
+    __shared__ __attribute__((aligned(16))) float s_sph[kBlock * SP];
+    __shared__ CuvolRec s_rec[kBlock];
+    __shared__ float4 s_smp[kBlock * kCuvolK];
     const int tid = threadIdx.x;
     if constexpr (CLDS) {
         for (int i = tid; i < g.coarse_words; i += kBlock) s_coarse[i] = g.coarse[i];
@@ -171,63 +369,93 @@ k_cuvol_fwd(KGrid g, KOpt o, int last_sample_opaque, const float* __restrict__ o
         float sph[B];
         eval_sh<B>(r.d, sph);
 #pragma unroll
-        for (int k = 0; k < B; ++k) s_sph[tid * kSphPad + k] = sph[k];
+        for (int k = 0; k < SP; ++k) s_sph[tid * SP + k] = k < B ? sph[k < B ? k : 0] : 0.f;
     }
     setup_ray(g, o, r);
     bool active = valid && !(r.tmin > r.tmax);
     const bool misses = valid && !active;
     March m;
     march_init(g, o, r, m);
+    CuvolGather st;
+    cuvol_gather_init(st);
     float outv[3] = {0.f, 0.f, 0.f};
-    float log_transmit = 0.f;
-    const float* sph_wave = s_sph + (tid & ~63) * kSphPad;
-    const LaneRec* rec_wave = s_rec + (tid & ~63);
-    while (__any(active)) {
-        float pos[3] = {0.f, 0.f, 0.f};
-        float sigma = 0.f, t = 0.f;
-        bool hit = false;
-        int lk[8];
-        while (active && !hit) {
-            int l[3];
-            if (!march_next<CLDS>(g, s_coarse, m, &t, l, pos)) {
-                active = false;
-                break;
-            }
-            sigma = cuvol_sigma(g, l, pos, lk);
-            hit = sigma > o.sigma_thresh;
-            m.t += m.step;
-        }
-        const unsigned long long need = __ballot(hit);
-        if (!need) continue;
-        if (hit) {
+    const int lane = tid & 63, wbase = tid & ~63;
+    const int half = lane >> 5, ch = (lane >> 3) & 3, c = lane & 7;
+    int held = -1;
+    float val[B];
 #pragma unroll
-            for (int i = 0; i < 8; ++i) s_rec[tid].link[i] = lk[i];
+    for (int k = 0; k < B; ++k) val[k] = 0.f;
+    while (__any(active)) {
+        CuvolSmp smp[kCuvolK];
+        LaneRec lr;
+        int rec_cid = -1;
+        const int n = cuvol_gather<CLDS>(g, o, s_coarse, m, st, r.tmax, world_step, last_sample_opaque, active,
+                                         &lr, &rec_cid, smp);
+        unsigned long long need = __ballot(n > 0);
+        if (!need) continue;
+        if (n > 0) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) s_rec[tid].link[i] = lr.link[i];
+            s_rec[tid].cid = rec_cid;
+            s_rec[tid].n = n;
+#pragma unroll
+            for (int j = 0; j < kCuvolK; ++j) s_smp[tid * kCuvolK + j] = make_float4(smp[j].px, smp[j].py, smp[j].pz, 0.f);
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        float color[3] = {0.f, 0.f, 0.f};
-        coop_shade_fwd<B>(g, need, rec_wave, sph_wave, pos, color);
-        if (hit) {
-            const float ws = (last_sample_opaque && t + o.step_size > r.tmax) ? 1e9f : world_step;
-            const float pcnt = ws * sigma;
-            const float weight = expf(log_transmit) * (1.f - expf(-pcnt));
-            log_transmit -= pcnt;
+#ifdef ASURF_CUVOL_NOSERVE
+        need = 0;
+#endif
+        while (need) {
+            int r0, r1;
+            bool two;
+            cuvol_next_pair(need, &r0, &r1, &two);
+            const int rr = wbase + (half ? r1 : r0);
+            const bool mine = ch < 3 && (half == 0 || two);
+            const int cid = s_rec[rr].cid, nr = mine ? s_rec[rr].n : 0;
+            if (mine && cid != held) {
+                held = cid;
+                cuvol_load_rows<B>(g, s_rec[rr].link[c], ch, val);
+            }
+            float d = 0.f;
 #pragma unroll
-            for (int ch = 0; ch < 3; ++ch) outv[ch] += weight * fmaxf(color[ch] + 0.5f, 0.f);
-            if (expf(log_transmit) < o.stop_thresh) {
-                log_transmit = -1e3f;
-                active = false;
+            for (int k = 0; k < B; ++k) d = fmaf(s_sph[rr * SP + k], val[k], d);
+            const int jmax = max(bcast_i(n, r0), bcast_i(n, r1));
+#pragma unroll
+            for (int j = 0; j < kCuvolK; ++j) {
+                if (j < jmax) {
+                    const float4 p = s_smp[rr * kCuvolK + j];
+                    float a = j < nr ? corner_w(c << 0, p.x, p.y, p.z) * d : 0.f;
+                    a = dpp_sum8(a);
+                    if (c == 7 && j < nr) reinterpret_cast<float*>(&s_smp[rr * kCuvolK + j])[ch] = a;
+                }
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+#pragma unroll
+        for (int j = 0; j < kCuvolK; ++j) {
+            if (j < n) {
+                const float4 col = s_smp[tid * kCuvolK + j];
+                outv[0] += smp[j].w * fmaxf(col.x + 0.5f, 0.f);
+                outv[1] += smp[j].w * fmaxf(col.y + 0.5f, 0.f);
+                outv[2] += smp[j].w * fmaxf(col.z + 0.5f, 0.f);
             }
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     }
     if (valid) {
         const float bg = o.background_brightness;
+        const float tr = expf(st.log_transmit);
 #pragma unroll
-        for (int ch = 0; ch < 3; ++ch) rgb_out[3 * q + ch] = misses ? bg : outv[ch] + expf(log_transmit) * bg;
-        if (log_transmit_out != nullptr) log_transmit_out[q] = misses ? 0.f : log_transmit;
+        for (int c3 = 0; c3 < 3; ++c3) rgb_out[3 * q + c3] = misses ? bg : outv[c3] + tr * bg;
+        if (log_transmit_out != nullptr) log_transmit_out[q] = misses ? 0.f : st.log_transmit;
     }
 }
 
+// ------------------------------------------------------------------------------------
+// Backward.  Phase A (per pair, the layout above): colours, clamp masks, and per lane (ch, c)
+// A = sum_j w_c(pos_j) * weight_j * in01_j[ch] * gout[ch].  Phase B (per record, lanes = corner x
+// SH coefficient as in coop_shade_bwd): grad_sh[c][e] += A[ch(e)][c] * sph[k(e)], accumulated in
+// registers while consecutive records name the same cell and flushed as row-contiguous atomics.
 // ------------------------------------------------------------------------------------
 template <int B, bool CLDS>
 __global__ void __launch_bounds__(kBlock)
@@ -235,9 +463,12 @@ k_cuvol_bwd(KGrid g, KOpt o, int last_sample_opaque, KGrads G, const float* __re
             const float* __restrict__ dirs, long long Q, const float* __restrict__ grad_in,
             const float* __restrict__ color_cache, int grad_in_is_rgb,
             const float* __restrict__ log_transmit_in, float beta_loss, float sparsity_loss) {
+    using C = Coop<B>;
+    constexpr int SP = CuvolLay<B>::SP;
     extern __shared__ unsigned int s_coarse[];
-    __shared__ float s_sph[kBlock * kSphPad];
-    __shared__ LaneRec s_rec[kBlock];
+    __shared__ __attribute__((aligned(16))) float s_sph[kBlock * SP];
+    __shared__ CuvolRec s_rec[kBlock];
+    __shared__ float4 s_smp[kBlock * kCuvolK];
     const int tid = threadIdx.x;
     if constexpr (CLDS) {
         for (int i = tid; i < g.coarse_words; i += kBlock) s_coarse[i] = g.coarse[i];
@@ -252,7 +483,7 @@ k_cuvol_bwd(KGrid g, KOpt o, int last_sample_opaque, KGrads G, const float* __re
         float sph[B];
         eval_sh<B>(r.d, sph);
 #pragma unroll
-        for (int k = 0; k < B; ++k) s_sph[tid * kSphPad + k] = sph[k];
+        for (int k = 0; k < SP; ++k) s_sph[tid * SP + k] = k < B ? sph[k < B ? k : 0] : 0.f;
     }
     setup_ray(g, o, r);
     bool active = valid && !(r.tmin > r.tmax);
@@ -272,57 +503,153 @@ k_cuvol_bwd(KGrid g, KOpt o, int last_sample_opaque, KGrads G, const float* __re
             accum += beta_loss * (1 - tr / (1 - tr + 1e-3f));
         }
     }
+    s_rec[tid].g0 = gout[0];
+    s_rec[tid].g1 = gout[1];
+    s_rec[tid].g2 = gout[2];
     March m;
     march_init(g, o, r, m);
-    float log_transmit = 0.f;
-    const float* sph_wave = s_sph + (tid & ~63) * kSphPad;
-    const LaneRec* rec_wave = s_rec + (tid & ~63);
-    while (__any(active)) {
-        float pos[3] = {0.f, 0.f, 0.f};
-        float sigma = 0.f, t = 0.f;
-        bool hit = false;
-        int lk[8];
-        while (active && !hit) {
-            int l[3];
-            if (!march_next<CLDS>(g, s_coarse, m, &t, l, pos)) {
-                active = false;
-                break;
-            }
-            sigma = cuvol_sigma(g, l, pos, lk);
-            hit = sigma > o.sigma_thresh;
-            m.t += m.step;
-        }
-        const unsigned long long need = __ballot(hit);
-        if (!need) continue;
-        float ws = world_step, weight = 0.f;
-        if (hit) {
+    CuvolGather st;
+    cuvol_gather_init(st);
+    const int lane = tid & 63, wbase = tid & ~63;
+    const int half = lane >> 5, ch = (lane >> 3) & 3, c = lane & 7;
+    // phase B layout
+    const int cs = lane / C::D;
+    const int e = lane - cs * C::D;
+    const int chB = e / B;
+    const int kB = e - chB * B;
+    const bool onB = cs < C::CPR;
+    int held = -1;
+    float val[B];
 #pragma unroll
-            for (int i = 0; i < 8; ++i) s_rec[tid].link[i] = lk[i];
-            ws = (last_sample_opaque && t + o.step_size > r.tmax) ? 1e9f : world_step;
-            const float pcnt = ws * sigma;
-            weight = expf(log_transmit) * (1.f - expf(-pcnt));
-            log_transmit -= pcnt;
+    for (int k = 0; k < B; ++k) val[k] = 0.f;
+    while (__any(active)) {
+        CuvolSmp smp[kCuvolK];
+        LaneRec lr;
+        int rec_cid = -1;
+        const int n = cuvol_gather<CLDS>(g, o, s_coarse, m, st, r.tmax, world_step, last_sample_opaque, active,
+                                         &lr, &rec_cid, smp);
+        unsigned long long need = __ballot(n > 0);
+        if (!need) continue;
+        if (n > 0) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) s_rec[tid].link[i] = lr.link[i];
+            s_rec[tid].cid = rec_cid;
+            s_rec[tid].n = n;
+#pragma unroll
+            for (int j = 0; j < kCuvolK; ++j)
+                s_smp[tid * kCuvolK + j] = make_float4(smp[j].px, smp[j].py, smp[j].pz, smp[j].w);
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        float total_color = 0.f;
-        float unused[3] = {0.f, 0.f, 0.f};
-        coop_shade_bwd<B>(g, G, false, need, rec_wave, sph_wave, pos, weight, gout, &total_color, unused);
-        if (hit) {
-            accum -= weight * total_color;
-            float grad_sigma = ws * (total_color * expf(log_transmit) - accum);  // :486-487
-            if (sparsity_loss > 0.f) grad_sigma += sparsity_loss * (4 * sigma / (1 + 2 * (sigma * sigma)));
-            if (G.grad_density != nullptr) {
-                float cw[8];
-                corner_weights(pos, grad_sigma, cw);
+        int heldB = -1;
+        float gacc[C::ROUNDS];
+        int link_h[C::ROUNDS];
 #pragma unroll
-                for (int i = 0; i < 8; ++i) {
-                    if (lk[i] >= 0) {
-                        atomicAdd(&G.grad_density[lk[i]], cw[i]);
-                        if (G.mask != nullptr) G.mask[lk[i]] = 1;
+        for (int rd = 0; rd < C::ROUNDS; ++rd) {
+            gacc[rd] = 0.f;
+            link_h[rd] = -1;
+        }
+        auto flush = [&]() {
+            if (G.mask != nullptr && e == 0) {  // every corner row of a served cell is touched (:120-135)
+#pragma unroll
+                for (int rd = 0; rd < C::ROUNDS; ++rd)
+                    if (link_h[rd] >= 0) G.mask[link_h[rd]] = 1;
+            }
+            if (G.grad_sh != nullptr) {
+#pragma unroll
+                for (int rd = 0; rd < C::ROUNDS; ++rd) {
+                    if (link_h[rd] >= 0 && gacc[rd] != 0.f)
+                        atomicAdd(&G.grad_sh[(size_t)link_h[rd] * C::D + e], gacc[rd]);
+                }
+            }
+        };
+        while (need) {
+            int r0, r1;
+            bool two;
+            cuvol_next_pair(need, &r0, &r1, &two);
+            // ---- phase A ----
+            const int rr = wbase + (half ? r1 : r0);
+            const bool mine = ch < 3 && (half == 0 || two);
+            const int cid = s_rec[rr].cid, nr = mine ? s_rec[rr].n : 0;
+            if (mine && cid != held) {
+                held = cid;
+                cuvol_load_rows<B>(g, s_rec[rr].link[c], ch, val);
+            }
+            float d = 0.f;
+#pragma unroll
+            for (int k = 0; k < B; ++k) d = fmaf(s_sph[rr * SP + k], val[k], d);
+            const float gch = ch == 0 ? s_rec[rr].g0 : ch == 1 ? s_rec[rr].g1 : s_rec[rr].g2;
+            const int jmax = max(bcast_i(n, r0), bcast_i(n, r1));
+            float A = 0.f;
+#pragma unroll
+            for (int j = 0; j < kCuvolK; ++j) {
+                if (j < jmax) {
+                    const float4 p = s_smp[rr * kCuvolK + j];
+                    const float w = j < nr ? corner_w(c, p.x, p.y, p.z) : 0.f;
+                    float a = dpp_sum8(w * d);
+                    // every lane of the octet needs the channel sum (held by its lane 7)
+                    a = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute((lane | 7) << 2, __builtin_bit_cast(int, a)));
+                    const float sc = a + 0.5f;
+                    const float tcl = fmaxf(sc, 0.f);
+                    const float in01 = tcl == sc ? 1.f : 0.f;
+                    A = fmaf(w, p.w * in01 * gch, A);
+                    if (c == 7 && j < nr) reinterpret_cast<float*>(&s_smp[rr * kCuvolK + j])[ch] = tcl * gch;
+                }
+            }
+            // ---- phase B ----
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                if (h == 0 || two) {
+                    const int rb = wbase + (h ? r1 : r0);
+                    const int cidb = s_rec[rb].cid;  // wave-uniform
+                    if (cidb != heldB) {
+                        flush();
+                        heldB = cidb;
+#pragma unroll
+                        for (int rd = 0; rd < C::ROUNDS; ++rd) {
+                            const int cb = rd * C::CPR + cs;
+                            gacc[rd] = 0.f;
+                            link_h[rd] = (onB && cb < 8) ? s_rec[rb].link[cb] : -1;
+                        }
+                    }
+                    const float sphk = onB ? s_sph[rb * SP + kB] : 0.f;
+#pragma unroll
+                    for (int rd = 0; rd < C::ROUNDS; ++rd) {
+                        const int cb = rd * C::CPR + cs;
+                        const int src = h * 32 + chB * 8 + (cb & 7);
+                        const float Av = __builtin_bit_cast(
+                            float, __builtin_amdgcn_ds_bpermute(src << 2, __builtin_bit_cast(int, A)));
+                        if (onB && cb < 8) gacc[rd] = fmaf(Av, sphk, gacc[rd]);
                     }
                 }
             }
-            if (expf(log_transmit) < o.stop_thresh) active = false;
+        }
+        flush();
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        if (n > 0) {
+            float cw[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int j = 0; j < kCuvolK; ++j) {
+                if (j < n) {
+                    const float4 tq = s_smp[tid * kCuvolK + j];
+                    const float tc = (tq.x + tq.z) + tq.y;  // (c0 + c2) + c1, :469-471
+                    accum -= smp[j].w * tc;
+                    float grad_sigma = smp[j].ws * (tc * smp[j].ta - accum);  // :486-487
+                    if (sparsity_loss > 0.f)
+                        grad_sigma += sparsity_loss * (4 * smp[j].sig / (1 + 2 * (smp[j].sig * smp[j].sig)));
+                    const float pos[3] = {smp[j].px, smp[j].py, smp[j].pz};
+                    float w8[8];
+                    corner_weights(pos, grad_sigma, w8);
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) cw[i] += w8[i];
+                }
+            }
+            if (G.grad_density != nullptr) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const int link = lr.link[i];
+                    if (link >= 0) atomicAdd(&G.grad_density[link], cw[i]);
+                }
+            }
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     }

@@ -15,19 +15,6 @@ import torch
 
 from . import lib as _L
 
-__all__ = [
-    "SparseGridSpec", "CameraSpec", "RaysSpec", "RayVoxIntersecSpec", "RenderOptions",
-    "GridOutputGrads", "volume_render_surf_trav", "volume_render_surf_trav_backward",
-    "volume_render_surf_trav_fused", "volume_render_surface", "volume_render_surface_backward",
-    "ray_voxel_lists", "tv_grad_sparse", "surf_tv_grad_sparse", "surface_normal_grad_sparse",
-    "alpha_surf_sparsify_grad_sparse", "surface_eikonal_grad_sparse",
-    "volume_render_expected_term_surf_trav", "volume_render_mode_term_surf_trav",
-    "volume_render_sigma_thresh_surf_trav", "volume_render_alpha_surf_trav", "render_normal_surf_trav",
-    "extract_pts_surf_trav", "dilate", "accel_dist_prop", "sample_grid", "sample_grid_sh_surf",
-    "sample_grid_raw_alpha", "sample_grid_backward",
-    "volume_render_surface_fused", "test_cubic_root_grad", "sample_grid", "rmsprop_step", "sgd_step",
-]
-
 
 class SparseGridSpec:
     """svox2.cpp:209-225 / data_spec.hpp:39-82"""
@@ -797,8 +784,55 @@ def volume_render_cuvol_fused(grid, rays, opt, rgb_gt, beta_loss, sparsity_loss,
             _ptr(rgb_out), C.byref(gg), _ptr(ws), nb, _stream(dev)))
 
 
+def _camera_rays(cam):
+    """Pixel-centre rays of a CameraSpec in image order (cam2world_ray, render_util.cuh:599-617)."""
+    _check_input(cam.c2w, "c2w", torch.float32)
+    if cam.ndc_coeffx > 0.0:
+        raise NotImplementedError("NDC cameras are outside the hot-path scope (SURVEY.md section 8f, N4)")
+    dev = cam.c2w.device
+    ix = torch.arange(cam.width, dtype=torch.float32, device=dev)
+    iy = torch.arange(cam.height, dtype=torch.float32, device=dev)
+    y, x = torch.meshgrid((iy + 0.5 - cam.cy) / cam.fy, (ix + 0.5 - cam.cx) / cam.fx, indexing="ij")
+    z = torch.sqrt(x * x + y * y + 1.0)
+    d = torch.stack([x / z, y / z, 1.0 / z], dim=-1).reshape(-1, 3)
+    dirs = (d @ cam.c2w[:3, :3].T).contiguous()
+    origins = cam.c2w[:3, 3].expand(dirs.shape[0], 3).contiguous()
+    r = RaysSpec()
+    r.origins, r.dirs = origins, dirs
+    r.masks = torch.ones(dirs.shape[0], dtype=torch.bool, device=dev)
+    return r
+
+
+def volume_render_cuvol_image(grid, cam, opt):
+    """Tensor[H,W,3] volume_render_cuvol_image(grid, cam, opt) -- svox2.cpp:19;
+    render_lerp_kernel_cuvol.cu:1167-1207 (rays generated per pixel, then the same march)."""
+    rgb = volume_render_cuvol(grid, _camera_rays(cam), opt)
+    return rgb.view(cam.height, cam.width, 3)
+
+
 def _out_of_scope(name, row):
     def fn(*args, **kwargs):
         raise NotImplementedError(f"{name} is outside the hot-path scope (SURVEY.md section 8f, {row})")
     fn.__name__ = name
     return fn
+
+
+# The rest of the reference's binding table (svox2.cpp:139-225): named, so that a caller learns which
+# SURVEY.md section 8(f) row the missing piece belongs to instead of an AttributeError.
+for _name, _row in [
+        ("volume_render_cuvol_image_backward", "N4"), ("volume_render_expected_term", "N3"),
+        ("volume_render_sigma_thresh", "N3"), ("volume_render_mode_term", "N3"), ("volume_render_med_term", "N3"),
+        ("volume_render_surf_trav_image", "N4"), ("volume_render_surface_image", "N4"),
+        ("volume_render_nvol", "out of scope"), ("volume_render_nvol_backward", "out of scope"),
+        ("volume_render_nvol_fused", "out of scope"), ("volume_render_svox1", "out of scope"),
+        ("volume_render_svox1_backward", "out of scope"), ("volume_render_svox1_fused", "out of scope"),
+        ("grid_weight_render", "N4"), ("sparse_grid_weight_render", "N4"), ("sparse_grid_mask_render", "N4"),
+        ("sparse_grid_visbility_render_surf", "N4"), ("cubic_extract_iso_pts", "N4"), ("sample_cubemap", "N4"),
+        ("tv", "N2"), ("tv_grad", "N2"), ("surface_normal_grad", "N2"), ("alpha_lap_grad_sparse", "N2"),
+        ("lumisphere_tv_grad_sparse", "N2"), ("msi_tv_grad_sparse", "N2"), ("surf_sign_change_grad_sparse", "N2")]:
+    globals()[_name] = _out_of_scope(_name, _row)
+del _name, _row
+
+# everything public defined here is the module's surface (svox2/csrc.py re-exports it)
+__all__ = sorted(n for n, v in list(globals().items())
+                 if not n.startswith("_") and callable(v) and getattr(v, "__module__", None) == __name__)

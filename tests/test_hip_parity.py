@@ -279,8 +279,8 @@ def test_error_behaviour(hip):
     args[2] = 1.0  # fused_surf_norm_reg_scale > 0: the reference asserts
     with pytest.raises(RuntimeError):
         _C.volume_render_surf_trav_fused(g, r, op, gt, *args, torch.zeros_like(gt), hip.zero_grads(g))
-    with pytest.raises(NotImplementedError):
-        _C.sample_grid()
+    with pytest.raises(NotImplementedError, match="N4"):
+        _C.grid_weight_render()
 
 
 def test_cubic_root_grad_kernel(hip, oracle):
