@@ -269,12 +269,26 @@ template <int B>
 __global__ void __launch_bounds__(kBlock)
 k_bwd_sh(KGrid g, KGrads G, int want_dpos, const float* __restrict__ dirs, long long Q, SampleRec S) {
     using C = Coop<B>;
-    __shared__ float s_sph[kBlock * kSphPad];
+    constexpr int SP = B | 1;  // odd LDS row stride of the per-sample SH basis
+    __shared__ float s_sph[kBlock * SP];
     __shared__ LaneRec s_rec[kBlock];
+    __shared__ float4 s_smp[kBlock];  // position in the voxel | real sample?   (in), d/dpos (out)
+    __shared__ float4 s_gch[kBlock];  // d(loss)/d(colour channel) | packed voxel
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int n_list = *S.n_list;
     const int wave_id = blockIdx.x * (kBlock / 64) + (tid >> 6);
+    const int wbase = tid & ~63;
+    const float* sph_wave = s_sph + wbase * SP;
+    const LaneRec* rec_wave = s_rec + wbase;
+    // phase A layout: two samples at a time, lane = (half, channel, corner)
+    const int half = lane >> 5, chA = (lane >> 3) & 3, cA = lane & 7;
+    // phase B layout: lanes = (corner slot, SH coefficient): row-contiguous atomics
+    const int cs = lane / C::D;
+    const int e = lane - cs * C::D;
+    const int ch = e / B;
+    const int k = e - ch * B;
+    const bool on = cs < C::CPR;
   // one dense chunk of 64 list entries per wave and turn (see k_bwd_geo)
   for (int base = wave_id * 64; base < n_list; base += (int)gridDim.x * kBlock) {
     const bool mine = base + lane < n_list;
@@ -283,8 +297,6 @@ k_bwd_sh(KGrid g, KGrads G, int want_dpos, const float* __restrict__ dirs, long 
     const int r = (int)(cell >> kListRayBits);
     const unsigned long long need0 = __ballot(mine);
     const size_t idx = (size_t)r * Q + q;
-    float pos[3] = {0.f, 0.f, 0.f}, gch[3] = {0.f, 0.f, 0.f};
-    bool real = false;
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // the previous turn's readers are done
     if (mine) {
         const int pv = S.v[idx];
@@ -302,32 +314,19 @@ k_bwd_sh(KGrid g, KGrads G, int want_dpos, const float* __restrict__ dirs, long 
         float sph[B];
         eval_sh<B>(d, sph);
 #pragma unroll
-        for (int k = 0; k < B; ++k) s_sph[tid * kSphPad + k] = sph[k];
-        pos[0] = S.px[idx];
-        pos[1] = S.py[idx];
-        pos[2] = S.pz[idx];
-        gch[0] = S.g0[idx];
-        gch[1] = S.g1[idx];
-        gch[2] = S.g2[idx];
-        real = !(S.m[idx] & 1);
+        for (int kk = 0; kk < B; ++kk) s_sph[tid * SP + kk] = sph[kk];
+        // fake samples carry no d/dpos (surf_trav.cu:2722)
+        s_smp[tid] = make_float4(S.px[idx], S.py[idx], S.pz[idx], (S.m[idx] & 1) ? 0.f : 1.f);
+        s_gch[tid] = make_float4(S.g0[idx], S.g1[idx], S.g2[idx], __builtin_bit_cast(float, pv));
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    const float* sph_wave = s_sph + (tid & ~63) * kSphPad;
-    const LaneRec* rec_wave = s_rec + (tid & ~63);
-    const int cs = lane / C::D;
-    const int e = lane - cs * C::D;
-    const int ch = e / B;
-    const int k = e - ch * B;
-    const bool on = cs < C::CPR;
-    float gx_out = 0.f, gy_out = 0.f, gz_out = 0.f;
     unsigned long long need = need0;
     // Neighbouring rays mostly sit in the same voxel: their contributions to the 8 SH rows are
     // summed in registers and flushed with one atomic per (row, coefficient) when the voxel changes
     // (wave-uniform test, so the lanes never diverge on it).
-    const int my_pv = mine ? S.v[idx] : -1;
-    float run[C::ROUNDS], val[C::ROUNDS];
+    float run[C::ROUNDS];
 #pragma unroll
-    for (int rd = 0; rd < C::ROUNDS; ++rd) run[rd] = val[rd] = 0.f;
+    for (int rd = 0; rd < C::ROUNDS; ++rd) run[rd] = 0.f;
     int run_pv = -1, run_sl = 0;
     auto flush = [&]() {
         if (run_pv < 0 || G.grad_sh == nullptr) return;
@@ -341,58 +340,70 @@ k_bwd_sh(KGrid g, KGrads G, int want_dpos, const float* __restrict__ dirs, long 
             run[rd] = 0.f;
         }
     };
+    int held = -1;  // voxel whose SH rows this lane holds (phase A, per half)
+    float val[B];
+#pragma unroll
+    for (int kk = 0; kk < B; ++kk) val[kk] = 0.f;
     while (need) {
-        const int sl = __ffsll((long long)need) - 1;
-        need &= need - 1;
-        const int pv = bcast_i(my_pv, sl);
-        if (pv != run_pv) {
-            flush();
-            run_pv = pv;
-            run_sl = sl;
-            if (want_dpos) {  // the voxel's SH rows, kept for every sample of the run
+        int r0, r1;
+        bool two;
+        next_pair(need, &r0, &r1, &two);
+        // ---- phase A: per lane (channel, corner): A = w_c * gout[ch]; d/dpos through the colour ----
+        const int rr = wbase + (half ? r1 : r0);
+        const bool mineA = chA < 3 && (half == 0 || two);
+        const float4 sp = s_smp[rr];
+        const float4 sg = s_gch[rr];
+        const float gch = chA == 0 ? sg.x : chA == 1 ? sg.y : sg.z;
+        const float wx = (cA & 4) ? sp.x : 1.f - sp.x;
+        const float wy = (cA & 2) ? sp.y : 1.f - sp.y;
+        const float wz = (cA & 1) ? sp.z : 1.f - sp.z;
+        const float A = mineA ? (wx * wy * wz) * gch : 0.f;
+        if (want_dpos) {  // :2249-2264
+            const int pvA = __builtin_bit_cast(int, sg.w);
+            if (mineA && pvA != held) {
+                held = pvA;
+                const float* row = g.sh + ((size_t)s_rec[rr].link[cA] * C::D + chA * B);
+#pragma unroll
+                for (int kk = 0; kk < B; ++kk) val[kk] = row[kk];
+            }
+            float dsh = 0.f;
+#pragma unroll
+            for (int kk = 0; kk < B; ++kk) dsh = fmaf(s_sph[rr * SP + kk], val[kk], dsh);
+            const float cgd = mineA ? gch * dsh * sp.w : 0.f;
+            const float gx = dpp_sum32(cgd * (((cA & 4) ? wy : -wy) * wz));
+            const float gy = dpp_sum32(cgd * (((cA & 2) ? wx : -wx) * wz));
+            const float gz = dpp_sum32(cgd * (((cA & 1) ? wx : -wx) * wy));
+            if ((lane & 31) == 31 && (half == 0 || two)) s_smp[rr] = make_float4(gx, gy, gz, 0.f);
+        }
+        // ---- phase B: grad_sh[c][e] += A[ch(e)][c] * sph[k(e)], merged over runs of one voxel ----
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            if (h == 0 || two) {
+                const int sl = h ? r1 : r0;
+                const int pv = __builtin_bit_cast(int, s_gch[wbase + sl].w);  // wave-uniform
+                if (pv != run_pv) {
+                    flush();
+                    run_pv = pv;
+                    run_sl = sl;
+                }
+                const float sphk = on ? sph_wave[sl * SP + k] : 0.f;  // :2120-2122
 #pragma unroll
                 for (int rd = 0; rd < C::ROUNDS; ++rd) {
                     const int c = rd * C::CPR + cs;
-                    if (on && c < 8) val[rd] = g.sh[(size_t)rec_wave[sl].link[c] * C::D + e];
+                    const float Av = __builtin_bit_cast(
+                        float, __builtin_amdgcn_ds_bpermute((h * 32 + ch * 8 + (c & 7)) << 2, __builtin_bit_cast(int, A)));
+                    if (on && c < 8) run[rd] = fmaf(Av, sphk, run[rd]);
                 }
-            }
-        }
-        const float px = bcast_f(pos[0], sl), py = bcast_f(pos[1], sl), pz = bcast_f(pos[2], sl);
-        const float g0 = bcast_f(gch[0], sl), g1 = bcast_f(gch[1], sl), g2 = bcast_f(gch[2], sl);
-        // fake samples carry no d/dpos (surf_trav.cu:2722)
-        const bool dpos = want_dpos && (bcast_i(real ? 1 : 0, sl) != 0);
-        const float sphk = on ? sph_wave[sl * kSphPad + k] : 0.f;
-        const float cg = sphk * ((ch == 0) ? g0 : (ch == 1) ? g1 : g2);  // :2120-2122
-        float ax = 0.f, ay = 0.f, az = 0.f;
-#pragma unroll
-        for (int rd = 0; rd < C::ROUNDS; ++rd) {
-            const int c = rd * C::CPR + cs;
-            if (on && c < 8) {
-                const float wx = (c & 4) ? px : 1.f - px;
-                const float wy = (c & 2) ? py : 1.f - py;
-                const float wz = (c & 1) ? pz : 1.f - pz;
-                run[rd] = fmaf(wx * wy * wz, cg, run[rd]);
-                if (dpos) {
-                    ax = fmaf(((c & 4) ? wy : -wy) * wz, val[rd], ax);
-                    ay = fmaf(((c & 2) ? wx : -wx) * wz, val[rd], ay);
-                    az = fmaf(((c & 1) ? wx : -wx) * wy, val[rd], az);
-                }
-            }
-        }
-        if (dpos) {  // :2249-2264
-            const float gx = wave_sum(cg * ax), gy = wave_sum(cg * ay), gz = wave_sum(cg * az);
-            if (lane == sl) {
-                gx_out = gx;
-                gy_out = gy;
-                gz_out = gz;
             }
         }
     }
     flush();
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     if (mine) {
-        S.gx[idx] = gx_out;
-        S.gy[idx] = gy_out;
-        S.gz[idx] = gz_out;
+        const float4 go = want_dpos ? s_smp[tid] : make_float4(0.f, 0.f, 0.f, 0.f);
+        S.gx[idx] = go.x;
+        S.gy[idx] = go.y;
+        S.gz[idx] = go.z;
     }
   }
 }

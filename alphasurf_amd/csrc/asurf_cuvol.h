@@ -313,26 +313,6 @@ struct CuvolLay {
     static constexpr int SP = (B + 3) / 4 * 4;  // LDS floats per ray for its SH basis
 };
 
-__device__ __forceinline__ float dpp_sum8(float v) {  // lanes 8m+7 receive the sum of lanes 8m .. 8m+7
-#define ASURF_DPP_ADD8(ctrl)                                                                           \
-    v += __builtin_bit_cast(float,                                                                     \
-                            __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), ctrl, 0xf, 0xf, false))
-    ASURF_DPP_ADD8(0x111);
-    ASURF_DPP_ADD8(0x112);
-    ASURF_DPP_ADD8(0x114);
-#undef ASURF_DPP_ADD8
-    return v;
-}
-
-// The pair of records to serve next: lanes of half h get r[h]; `two` = the second one exists.
-__device__ __forceinline__ void cuvol_next_pair(unsigned long long& need, int* r0, int* r1, bool* two) {
-    *r0 = __ffsll((long long)need) - 1;
-    need &= need - 1;
-    *two = need != 0;
-    *r1 = *two ? __ffsll((long long)need) - 1 : *r0;
-    if (*two) need &= need - 1;
-}
-
 template <int B>
 __device__ __forceinline__ void cuvol_load_rows(const KGrid& g, int link, int ch, float* val) {
     if (link >= 0) {
@@ -408,7 +388,7 @@ k_cuvol_fwd(KGrid g, KOpt o, int last_sample_opaque, const float* __restrict__ o
         while (need) {
             int r0, r1;
             bool two;
-            cuvol_next_pair(need, &r0, &r1, &two);
+            next_pair(need, &r0, &r1, &two);
             const int rr = wbase + (half ? r1 : r0);
             const bool mine = ch < 3 && (half == 0 || two);
             const int cid = s_rec[rr].cid, nr = mine ? s_rec[rr].n : 0;
@@ -565,7 +545,7 @@ k_cuvol_bwd(KGrid g, KOpt o, int last_sample_opaque, KGrads G, const float* __re
         while (need) {
             int r0, r1;
             bool two;
-            cuvol_next_pair(need, &r0, &r1, &two);
+            next_pair(need, &r0, &r1, &two);
             // ---- phase A ----
             const int rr = wbase + (half ? r1 : r0);
             const bool mine = ch < 3 && (half == 0 || two);

@@ -362,10 +362,22 @@ k_comp(KGrid g, KOpt o, const float* __restrict__ dirs, long long Q, PipeBuf P,
     bool rec_over = false;
     int n_left = valid ? n : 0;  // becomes 0 when stop_thresh ends the ray
 
+    // the per-voxel candidate words of four consecutive slots are fetched together (independent
+    // loads): the loop is otherwise one dependent memory round trip per slot
+    int ci4[4] = {0, 0, 0, 0};
     for (int s = 0; __any(s < n_left); ++s) {
         const bool have = s < n_left;
-        int ci = 0;
-        if (have) ci = (s < P.C1) ? P.citem[(size_t)s * Q + q] : P.sp_citem[spb + s - P.C1];
+        if ((s & 3) == 0) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int su = s + u;
+                ci4[u] = 0;
+                if (su < n_left) ci4[u] = (su < P.C1) ? P.citem[(size_t)su * Q + q] : P.sp_citem[spb + su - P.C1];
+            }
+        }
+        const int sel = s & 3;
+        int ci = sel == 0 ? ci4[0] : sel == 1 ? ci4[1] : sel == 2 ? ci4[2] : ci4[3];
+        if (!have) ci = 0;
         const int nc = ci & 3;
         if (!__any(nc > 0)) continue;
         const int base = ci >> 2;
@@ -421,7 +433,7 @@ k_comp(KGrid g, KOpt o, const float* __restrict__ dirs, long long Q, PipeBuf P,
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             float color[3] = {0.f, 0.f, 0.f};
             const float pos[3] = {cr.px, cr.py, cr.pz};
-            coop_shade_fwd<B>(g, need, rec_wave, sph_wave, pos, color);
+            pair_shade_fwd<B>(g, need, rec_wave, sph_wave, pos, color);
             if (!shade) continue;
             const float pcnt = -1 * logf(1 - a);  // :397-404
             const float weight = expf(log_transmit) * (1.f - expf(-pcnt));
