@@ -1104,6 +1104,58 @@ int asurf_sample_plane_backward(const int32_t* links, const int32_t size[3], int
     return launch_error("k_sample_plane_backward");
 }
 
+// ---- weight renders (asurf_misc.h) ----
+static int weight_render_common(const int32_t size[3], const asurf_camera* cam, float step_size,
+                                const float* offset, const float* scaling, const float* out, CamK& K) {
+    if (!size || !cam || !offset || !scaling || !out) return fail(ASURF_E_INVALID, "weight_render: NULL argument");
+    const long long n = (long long)size[0] * size[1] * size[2];
+    if (size[0] < 2 || size[1] < 2 || size[2] < 2 || n >= (1ll << 31))
+        return fail(ASURF_E_INVALID, "weight_render: bad grid shape");
+    if (!(step_size > 0.f)) return fail(ASURF_E_INVALID, "weight_render: step_size must be > 0");
+    if (cam->width < 0 || cam->height < 0 || (long long)cam->width * cam->height >= (1ll << 31))
+        return fail(ASURF_E_INVALID, "weight_render: bad image size");
+    if (!(cam->fx != 0.f) || !(cam->fy != 0.f)) return fail(ASURF_E_INVALID, "weight_render: zero focal length");
+    for (int i = 0; i < 12; ++i) K.c2w[i] = cam->c2w[i];
+    K.fx = cam->fx;
+    K.fy = cam->fy;
+    K.cx = cam->cx;
+    K.cy = cam->cy;
+    K.width = cam->width;
+    K.height = cam->height;
+    return 0;
+}
+
+int asurf_grid_weight_render(const float* data, const int32_t size[3], const asurf_camera* cam, float step_size,
+                             float stop_thresh, int32_t last_sample_opaque, const float offset[3],
+                             const float scaling[3], float* grid_weight_out, void* stream) {
+    CamK K;
+    if (!data) return fail(ASURF_E_INVALID, "grid_weight_render: data is NULL");
+    if (int e = weight_render_common(size, cam, step_size, offset, scaling, grid_weight_out, K)) return e;
+    const long long Q = (long long)K.width * K.height;
+    if (Q == 0) return 0;
+    hipLaunchKernelGGL((k_weight_render<false>), dim3((unsigned)((Q + 255) / 256)), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), data, (const int32_t*)nullptr, size[0], size[1], size[2], K,
+                       step_size, stop_thresh, last_sample_opaque ? 1 : 0, offset[0], offset[1], offset[2],
+                       scaling[0], scaling[1], scaling[2], grid_weight_out);
+    return launch_error("k_weight_render");
+}
+
+int asurf_sparse_grid_weight_render(const int32_t* links, const float* density_data, const int32_t size[3],
+                                    const asurf_camera* cam, float step_size, float stop_thresh,
+                                    const float offset[3], const float scaling[3], float* grid_weight_out,
+                                    void* stream) {
+    CamK K;
+    if (!links || !density_data) return fail(ASURF_E_INVALID, "sparse_grid_weight_render: NULL tensor");
+    if (int e = weight_render_common(size, cam, step_size, offset, scaling, grid_weight_out, K)) return e;
+    const long long Q = (long long)K.width * K.height;
+    if (Q == 0) return 0;
+    hipLaunchKernelGGL((k_weight_render<true>), dim3((unsigned)((Q + 255) / 256)), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), density_data, links, size[0], size[1], size[2], K, step_size,
+                       stop_thresh, 0, offset[0], offset[1], offset[2], scaling[0], scaling[1], scaling[2],
+                       grid_weight_out);
+    return launch_error("k_weight_render");
+}
+
 // ---- cuvol renderer (asurf_cuvol.h) ----
 int asurf_volume_render_cuvol(const asurf_grid* grid, const asurf_rays* rays,
                               const asurf_render_options* opt, float* rgb_out, void* workspace,

@@ -2,7 +2,9 @@
 //   k_dilate            misc_kernel.cu:24-58    3x3x3 binary dilation, edges clamped
 //   k_accel_dist_set    misc_kernel.cu:113-144  marks, level by level, the 2^k-cells that hold a vertex
 //   k_accel_dist_prop   misc_kernel.cu:147-180  empty links become -(1 + number of empty pyramid levels)
-// One voxel per thread, streaming.
+//   k_weight_render     misc_kernel.cu:186-284, 286-400, 888-937  per-vertex max of the compositing weight (dense
+//                       density volume) / of the transmittance in front of the sample (sparse grid) over a camera's rays
+// One voxel (or pixel) per thread.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -68,6 +70,126 @@ k_accel_dist(int32_t* __restrict__ links, uint8_t* __restrict__ tmp, int sx0, in
 // One thread per (point, channel): the 8 corner reads of a point are C contiguous floats each.
 // A point is mapped by p * scaling + offset, clamped to [0, size-1]; an empty corner reads as `dflt`
 // (0 for density / SH, empty_raw for sample_grid_raw_alpha, default_surf for the surface plane).
+// ---- weight renders (resample's camera-weight criterion, the weight-masked surface initialisation) ----
+struct CamK {
+    float c2w[12];  // rows of the 3x4 camera-to-world matrix
+    float fx, fy, cx, cy;
+    int width, height;
+};
+
+// max for non-negative floats (misc weights and transmittances): integer order == float order there.
+// A plain read first: after the first few cameras almost every sample is below what the vertex holds.
+__device__ __forceinline__ void max_nonneg(float* p, float v) {
+    if (v > *p) atomicMax(reinterpret_cast<int*>(p), __builtin_bit_cast(int, v));
+}
+
+// SPARSE = false: `data` is a dense [X,Y,Z] density volume and the vertex keeps the largest compositing
+// weight (grid_trace_ray, misc_kernel.cu:186-284).  SPARSE = true: densities come through `links`
+// (missing = 0) and the vertex keeps the largest transmittance in front of a sample (:286-400).
+template <bool SPARSE>
+__global__ void __launch_bounds__(256)
+k_weight_render(const float* __restrict__ data, const int32_t* __restrict__ links, int sx, int sy, int sz, CamK cam,
+                float step_size, float stop_thresh, int last_sample_opaque, float off0, float off1, float off2,
+                float sc0, float sc1, float sc2, float* __restrict__ out) {
+    const int tid = blockIdx.x * blockDim.x + threadIdx.x;
+    if (tid >= cam.width * cam.height) return;
+    const int iy = tid / cam.width, ix = tid % cam.width;
+    // cam2world_ray, render_util.cuh:599-617 (OpenCV convention, pixel centres)
+    float x = ((float)ix + 0.5f - cam.cx) / cam.fx;
+    float y = ((float)iy + 0.5f - cam.cy) / cam.fy;
+    float z = sqrtf((float)((double)(x * x + y * y) + 1.0));
+    x /= z;
+    y /= z;
+    z = 1.0f / z;
+    float d[3], o[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        d[i] = cam.c2w[4 * i] * x + cam.c2w[4 * i + 1] * y + cam.c2w[4 * i + 2] * z;
+        o[i] = cam.c2w[4 * i + 3];
+    }
+    o[0] = fmaf(o[0], sc0, off0);
+    o[1] = fmaf(o[1], sc1, off1);
+    o[2] = fmaf(o[2], sc2, off2);
+    d[0] *= sc0;
+    d[1] *= sc1;
+    d[2] *= sc2;
+    const float rn = 1.f / sqrtf(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
+    d[0] *= rn;
+    d[1] *= rn;
+    d[2] *= rn;
+    const float world_step = rn * step_size;
+    const int size[3] = {sx, sy, sz};
+    float t = 0.f, tmax = 2e3f;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const float invdir = (float)(1.0 / (double)d[i]);
+        const float t1 = (-0.5f - o[i]) * invdir;
+        const float t2 = ((float)size[i] - 0.5f - o[i]) * invdir;
+        if (d[i] != 0.f) {
+            t = fmaxf(t, fminf(t1, t2));
+            tmax = fminf(tmax, fmaxf(t1, t2));
+        }
+    }
+    if (t > tmax) return;
+    const int st0 = sy * sz, st1 = sz;
+    float lli = 0.f;  // log light intensity
+    // t <= tmax <= 2e3 and step_size > 0 (checked by the caller): the loop ends
+    while (t <= tmax) {
+        float pos[3];
+        int l[3];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            pos[j] = o[j] + t * d[j];
+            pos[j] = fminf(fmaxf(pos[j], 0.f), (float)size[j] - 1.f);
+            l[j] = min((int)pos[j], size[j] - 2);
+            pos[j] -= (float)l[j];
+        }
+        const int idx = l[0] * st0 + l[1] * st1 + l[2];
+        float v[8];
+        if constexpr (SPARSE) {
+            const int32_t* p = links + idx;
+            const int32_t lk[8] = {p[0], p[1], p[st1], p[st1 + 1], p[st0], p[st0 + 1], p[st0 + st1], p[st0 + st1 + 1]};
+#pragma unroll
+            for (int i = 0; i < 8; ++i) v[i] = lk[i] >= 0 ? data[lk[i]] : 0.f;
+        } else {
+            const float* p = data + idx;
+            v[0] = p[0];
+            v[1] = p[1];
+            v[2] = p[st1];
+            v[3] = p[st1 + 1];
+            v[4] = p[st0];
+            v[5] = p[st0 + 1];
+            v[6] = p[st0 + st1];
+            v[7] = p[st0 + st1 + 1];
+        }
+        const float i00 = fmaf(pos[2], v[1] - v[0], v[0]), i01 = fmaf(pos[2], v[3] - v[2], v[2]);
+        const float i10 = fmaf(pos[2], v[5] - v[4], v[4]), i11 = fmaf(pos[2], v[7] - v[6], v[6]);
+        const float i0 = fmaf(pos[1], i01 - i00, i00), i1 = fmaf(pos[1], i11 - i10, i10);
+        float sigma = fmaf(pos[0], i1 - i0, i0);
+        if (!SPARSE && last_sample_opaque && t + step_size > tmax) {
+            sigma += 1e9f;
+            lli = 0.f;
+        }
+        if (sigma > 1e-8f) {
+            const float log_att = -world_step * sigma;
+            const float tr = expf(lli);
+            const float val = SPARSE ? tr : tr * (1.f - expf(log_att));
+            lli += log_att;
+            float* q = out + idx;
+            max_nonneg(q, val);
+            max_nonneg(q + 1, val);
+            max_nonneg(q + st1, val);
+            max_nonneg(q + st1 + 1, val);
+            max_nonneg(q + st0, val);
+            max_nonneg(q + st0 + 1, val);
+            max_nonneg(q + st0 + st1, val);
+            max_nonneg(q + st0 + st1 + 1, val);
+            if (expf(lli) < stop_thresh) break;
+        }
+        t += step_size;
+    }
+}
+
 struct SampleXf {
     float offset[3], scaling[3];
     int size[3];

@@ -810,6 +810,57 @@ def volume_render_cuvol_image(grid, cam, opt):
     return rgb.view(cam.height, cam.width, 3)
 
 
+# ---- weight renders (misc_kernel.cu:186-400, 888-937, 1084-1138) ----
+def _pack_camera(cam):
+    if cam.ndc_coeffx > 0.0:
+        raise NotImplementedError("NDC cameras are outside the hot-path scope (SURVEY.md section 8f, N4)")
+    if not torch.is_tensor(cam.c2w) or cam.c2w.dim() != 2 or cam.c2w.shape[1] != 4 or cam.c2w.shape[0] < 3:
+        raise RuntimeError("c2w must be a [3,4] or [4,4] tensor")
+    k = _L.AsurfCamera()
+    k.c2w = (C.c_float * 12)(*cam.c2w[:3, :4].detach().to("cpu", torch.float32).reshape(-1).tolist())
+    k.fx, k.fy, k.cx, k.cy = float(cam.fx), float(cam.fy), float(cam.cx), float(cam.cy)
+    k.width, k.height = int(cam.width), int(cam.height)
+    return k
+
+
+def _vec3(t, name):
+    if not torch.is_tensor(t) or t.numel() != 3:
+        raise RuntimeError(f"{name} must hold 3 floats")
+    return (C.c_float * 3)(*t.detach().to("cpu", torch.float32).reshape(-1).tolist())
+
+
+def grid_weight_render(data, cam, step_size, stop_thresh, last_sample_opaque, offset, scaling, grid_weight_out):
+    """void grid_weight_render(Tensor data[X,Y,Z], CameraSpec, float step_size, float stop_thresh,
+    bool last_sample_opaque, Tensor offset, Tensor scaling, Tensor grid_weight_out) -- misc_kernel.cu:1084-1111."""
+    _check_input(data, "data", torch.float32)
+    _check_input(grid_weight_out, "grid_weight_out", torch.float32)
+    if data.dim() != 3 or tuple(grid_weight_out.shape) != tuple(data.shape):
+        raise RuntimeError("data and grid_weight_out must be 3-D and of one shape")
+    k = _pack_camera(cam)
+    size = (C.c_int32 * 3)(*data.shape)
+    with torch.cuda.device(data.device):
+        _L.check(_L.lib().asurf_grid_weight_render(
+            _ptr(data), size, C.byref(k), float(step_size), float(stop_thresh), int(bool(last_sample_opaque)),
+            _vec3(offset, "offset"), _vec3(scaling, "scaling"), _ptr(grid_weight_out), _stream(data.device)))
+
+
+def sparse_grid_weight_render(grid, cam, step_size, stop_thresh, offset, scaling, grid_weight_out):
+    """void sparse_grid_weight_render(SparseGridSpec, CameraSpec, float step_size, float stop_thresh,
+    Tensor offset, Tensor scaling, Tensor grid_weight_out) -- misc_kernel.cu:1113-1138."""
+    _check_input(grid.links, "links", torch.int32)
+    _check_input(grid.density_data, "density_data", torch.float32)
+    _check_input(grid_weight_out, "grid_weight_out", torch.float32)
+    if grid.links.dim() != 3 or tuple(grid_weight_out.shape) != tuple(grid.links.shape):
+        raise RuntimeError("links and grid_weight_out must be 3-D and of one shape")
+    k = _pack_camera(cam)
+    size = (C.c_int32 * 3)(*grid.links.shape)
+    dev = grid.links.device
+    with torch.cuda.device(dev):
+        _L.check(_L.lib().asurf_sparse_grid_weight_render(
+            _ptr(grid.links), _ptr(grid.density_data), size, C.byref(k), float(step_size), float(stop_thresh),
+            _vec3(offset, "offset"), _vec3(scaling, "scaling"), _ptr(grid_weight_out), _stream(dev)))
+
+
 def _out_of_scope(name, row):
     def fn(*args, **kwargs):
         raise NotImplementedError(f"{name} is outside the hot-path scope (SURVEY.md section 8f, {row})")
@@ -826,7 +877,7 @@ for _name, _row in [
         ("volume_render_nvol", "out of scope"), ("volume_render_nvol_backward", "out of scope"),
         ("volume_render_nvol_fused", "out of scope"), ("volume_render_svox1", "out of scope"),
         ("volume_render_svox1_backward", "out of scope"), ("volume_render_svox1_fused", "out of scope"),
-        ("grid_weight_render", "N4"), ("sparse_grid_weight_render", "N4"), ("sparse_grid_mask_render", "N4"),
+        ("sparse_grid_mask_render", "N4"),
         ("sparse_grid_visbility_render_surf", "N4"), ("cubic_extract_iso_pts", "N4"), ("sample_cubemap", "N4"),
         ("tv", "N2"), ("tv_grad", "N2"), ("surface_normal_grad", "N2"), ("alpha_lap_grad_sparse", "N2"),
         ("lumisphere_tv_grad_sparse", "N2"), ("msi_tv_grad_sparse", "N2"), ("surf_sign_change_grad_sparse", "N2")]:

@@ -579,10 +579,9 @@ class SparseGrid(nn.Module):
                  cameras=None, use_z_order: bool = False, accelerate: bool = True,
                  weight_render_stop_thresh: float = 0.2, max_elements: int = 0, batch_size: int = 720720):
         """Resample density and SH onto a grid of resolution `reso`, keep the vertices whose density reaches
-        `sigma_thresh` (dilated `dilate` times) and renumber them in raster order (:3963-4180).  The
-        camera-weight criterion needs grid_weight_render (N4, not built); Morton order is not offered."""
-        if cameras is not None:
-            _next_row("N4", "resample with camera weights (grid_weight_render)")
+        `sigma_thresh` -- or, given `cameras`, whose largest compositing weight over those views reaches
+        `weight_thresh` (grid_weight_render) -- dilated `dilate` times, and renumber them in raster order
+        (:3963-4180).  Morton order is not offered."""
         if use_z_order:
             _next_row("N4", "resample into Morton order")
         if self.surface_data is not None:
@@ -597,13 +596,28 @@ class SparseGrid(nn.Module):
             points = torch.stack(torch.meshgrid(*ax, indexing="ij"), dim=-1).view(-1, 3).to(device)
             dens = torch.cat([self.sample(points[i:i + batch_size], grid_coords=True, want_colors=False)[0]
                               for i in range(0, len(points), batch_size)], dim=0).view(reso)
-            mask = dens >= sigma_thresh
-            if 0 < max_elements < dens.numel() and max_elements < int(torch.count_nonzero(mask)):
-                bound = torch.topk(dens.view(-1), k=max_elements, sorted=False).values.min().item()
-                sigma_thresh = max(sigma_thresh, bound)
+            if cameras is not None:  # :4058-4098
+                gsz = torch.tensor(reso, dtype=torch.float32)
+                offset, scaling = self._offset * gsz - 0.5, self._scaling * gsz
+                max_wt = torch.zeros(reso, dtype=torch.float32, device=device)
+                dens = dens.contiguous()
+                for cam in cameras:
+                    _C.grid_weight_render(dens, cam._to_cpp(), 0.5, weight_render_stop_thresh, False, offset,
+                                          scaling, max_wt)
+                mask = max_wt >= weight_thresh
+                if 0 < max_elements < max_wt.numel() and max_elements < int(torch.count_nonzero(mask)):
+                    bound = torch.topk(max_wt.view(-1), k=max_elements, sorted=False).values.min().item()
+                    weight_thresh = max(weight_thresh, bound)
+                    mask = max_wt >= weight_thresh
+                del max_wt
+            else:
                 mask = dens >= sigma_thresh
-            if self.opt.last_sample_opaque:
-                mask[:, :, -1] = True
+                if 0 < max_elements < dens.numel() and max_elements < int(torch.count_nonzero(mask)):
+                    bound = torch.topk(dens.view(-1), k=max_elements, sorted=False).values.min().item()
+                    sigma_thresh = max(sigma_thresh, bound)
+                    mask = dens >= sigma_thresh
+                if self.opt.last_sample_opaque:
+                    mask[:, :, -1] = True
             for _ in range(int(dilate)):
                 mask = _C.dilate(mask.contiguous())
             mask = mask.view(-1)
@@ -689,10 +703,14 @@ class SparseGrid(nn.Module):
         """Start the surface field from a trained density grid (:2958-3227), `init_type='density'` with the
         exponential activation (the live configuration, opt.py:458-475): surface = density - level, pruned,
         then rescaled so that the mean forward-difference gradient norm is 1 (an SDF-like scale); the level
-        sets are shifted and rescaled with it.  The weight / visibility / mask-pruning variants need the
-        sparse_grid_*_render kernels (N4, not built)."""
-        if init_type != "density" or visibility_pruning_scale > 0 or mask_pruning_rays is not None:
-            _next_row("N4", "init_surface_from_density with weight / visibility / mask pruning")
+        sets are shifted and rescaled with it.  Any other `init_type` weights the density by the largest
+        transmittance `weight_init_cams` see in front of the vertex first (sparse_grid_weight_render, :3118-3147).
+        The visibility / mask-pruning passes need sparse_grid_visbility_render_surf / sparse_grid_mask_render
+        (N4, not built)."""
+        if visibility_pruning_scale > 0 or mask_pruning_rays is not None:
+            _next_row("N4", "init_surface_from_density with visibility / mask pruning")
+        if init_type != "density" and not weight_init_cams:
+            raise RuntimeError("init_surface_from_density: init_type != 'density' needs weight_init_cams")
         if self.opt.alpha_activation_type == CONSTANTS["SIGMOID_FN"]:
             raise NotImplementedError("init_surface_from_density: the reference raises for the sigmoid "
                                       "activation as well (svox2.py:3016)")
@@ -703,7 +721,15 @@ class SparseGrid(nn.Module):
             self.level_set_data = torch.tensor(density_lvs, device=device, dtype=torch.float32) - zero_lv_density
             self.surface_type = CONSTANTS["SURFACE_TYPE_SDF"] if self.surface_type == CONSTANTS["SURFACE_TYPE_NONE"] \
                 else self.surface_type
-            self.surface_data = nn.Parameter((self.density_data.detach().clone() - zero_lv_density).to(torch.float32))
+            surface = self.density_data.detach().clone()
+            if init_type != "density":
+                gsz = self._grid_size()
+                max_t = torch.zeros(tuple(self.links.shape), dtype=torch.float32, device=device)
+                for cam in weight_init_cams:
+                    _C.sparse_grid_weight_render(self._to_cpp(), cam._to_cpp(), 0.5, 0.0, self._offset * gsz,
+                                                 self._scaling * gsz, max_t)
+                surface = surface * max_t[self.links >= 0][:, None]
+            self.surface_data = nn.Parameter((surface - zero_lv_density).to(torch.float32))
             if "surface_data" not in self.trainable_data:
                 self.trainable_data.append("surface_data")
             self.prune_grid(prune_threshold, dilate, prune_surf=False)

@@ -38,6 +38,11 @@ class AsurfRayVox(C.Structure):
                 ("n_vox", C.c_int64)]
 
 
+class AsurfCamera(C.Structure):
+    _fields_ = [("c2w", C.c_float * 12), ("fx", C.c_float), ("fy", C.c_float), ("cx", C.c_float),
+                ("cy", C.c_float), ("width", C.c_int32), ("height", C.c_int32)]
+
+
 RENDER_OPTION_FIELDS = [
     ("background_brightness", C.c_float), ("step_size", C.c_float), ("sigma_thresh", C.c_float),
     ("stop_thresh", C.c_float), ("near_clip", C.c_float), ("use_spheric_clip", C.c_int32),
@@ -93,6 +98,7 @@ EXPORTS = [
     "asurf_render_eval_surf_trav", "asurf_dilate", "asurf_accel_dist_prop_tmp_bytes", "asurf_accel_dist_prop",
     "asurf_sample_plane", "asurf_sample_plane_backward",
     "asurf_volume_render_cuvol", "asurf_volume_render_cuvol_backward", "asurf_volume_render_cuvol_fused",
+    "asurf_grid_weight_render", "asurf_sparse_grid_weight_render",
 ]
 
 _lib = None
@@ -148,6 +154,8 @@ def lib():
         L.asurf_volume_render_cuvol.argtypes = [vp, vp, vp, vp, vp, C.c_size_t, vp]
         L.asurf_volume_render_cuvol_backward.argtypes = [vp, vp, vp, vp, vp, vp, vp, C.c_size_t, vp]
         L.asurf_volume_render_cuvol_fused.argtypes = [vp, vp, vp, vp, fl, fl, vp, vp, vp, C.c_size_t, vp]
+        L.asurf_grid_weight_render.argtypes = [vp, vp, vp, fl, fl, C.c_int32, vp, vp, vp, vp]
+        L.asurf_sparse_grid_weight_render.argtypes = [vp, vp, vp, vp, fl, fl, vp, vp, vp, vp]
         if L.asurf_abi_version() != 1:
             raise RuntimeError("libasurf_hip.so ABI version mismatch")
         _lib = L

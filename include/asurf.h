@@ -329,6 +329,29 @@ int asurf_volume_render_cuvol_fused(const asurf_grid* grid, const asurf_rays* ra
                                     float sparsity_loss, float* rgb_out, const asurf_grads* grads,
                                     void* workspace, size_t workspace_bytes, void* stream);
 
+/* Pinhole camera of the image-order entry points (CameraSpec, data_spec.hpp:84-112): c2w holds the
+ * rows of the 3x4 camera-to-world matrix (HOST values); NDC cameras are not built. */
+typedef struct asurf_camera {
+    float c2w[12];
+    float fx, fy, cx, cy;
+    int32_t width, height;
+} asurf_camera;
+
+/* grid_weight_render (svox2.cpp REG, misc_kernel.cu:186-284, 888-913, 1084-1111): marches every pixel
+ * ray of `cam` through the DENSE density volume data[X,Y,Z] and keeps, per vertex, the largest
+ * compositing weight of a sample in one of its 8 cells (max into grid_weight_out[X,Y,Z], which the
+ * caller zeroes before the first camera). */
+int asurf_grid_weight_render(const float* data, const int32_t size[3], const asurf_camera* cam,
+                             float step_size, float stop_thresh, int32_t last_sample_opaque,
+                             const float offset[3], const float scaling[3], float* grid_weight_out,
+                             void* stream);
+/* sparse_grid_weight_render (misc_kernel.cu:286-400, 915-937, 1113-1138): the same march through a
+ * sparse grid (missing corners read 0); the vertex keeps the largest TRANSMITTANCE in front of a sample. */
+int asurf_sparse_grid_weight_render(const int32_t* links, const float* density_data,
+                                    const int32_t size[3], const asurf_camera* cam, float step_size,
+                                    float stop_thresh, const float offset[3], const float scaling[3],
+                                    float* grid_weight_out, void* stream);
+
 /* Trilinear sampling of an [n_rows, n_cols] parameter plane at `points` float[n_points,3]
  * (sample_grid / sample_grid_sh_surf / sample_grid_raw_alpha, svox2_kernel.cu:11-150, 384-489):
  * p * scaling + offset, clamped to the grid, an empty corner reads as `empty_value`; out is

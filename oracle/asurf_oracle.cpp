@@ -2082,4 +2082,88 @@ int oracle_volume_render_cuvol_fused(const oracle_grid* grid, const oracle_rays*
     return 0;
 }
 
+/* grid_weight_render / sparse_grid_weight_render, misc_kernel.cu:186-400, 888-937 (cam2world_ray:
+ * render_util.cuh:599-617).  links == NULL: `data` is the dense [X,Y,Z] volume and the vertex keeps the largest
+ * weight; otherwise data = density rows and the vertex keeps the largest transmittance in front of a sample.
+ * PARITY UNPINNED: the reference has no second implementation of these two kernels to take vectors from. */
+int oracle_weight_render(const float* data, const int32_t* links, const int32_t* size, const float* c2w, float fx,
+                         float fy, float cx, float cy, int32_t width, int32_t height, float step_size,
+                         float stop_thresh, int32_t last_sample_opaque, const float* offset, const float* scaling,
+                         float* out) {
+    if (!data || !size || !c2w || !offset || !scaling || !out || !(step_size > 0.f)) return -1;
+    const int st0 = size[1] * size[2], st1 = size[2];
+    const bool sparse = links != nullptr;
+#pragma omp parallel for schedule(dynamic, 256)
+    for (int64_t tid = 0; tid < (int64_t)width * height; ++tid) {
+        const int iy = (int)(tid / width), ix = (int)(tid % width);
+        float x = ((float)ix + 0.5f - cx) / fx;
+        float y = ((float)iy + 0.5f - cy) / fy;
+        float z = sqrtf((float)((double)(x * x + y * y) + 1.0));
+        x /= z;
+        y /= z;
+        z = 1.0f / z;
+        float d[3], o[3];
+        for (int i = 0; i < 3; ++i) {
+            d[i] = c2w[4 * i] * x + c2w[4 * i + 1] * y + c2w[4 * i + 2] * z;
+            o[i] = fmaf(c2w[4 * i + 3], scaling[i], offset[i]);
+        }
+        for (int i = 0; i < 3; ++i) d[i] *= scaling[i];
+        const float rn = 1.f / sqrtf(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
+        for (int i = 0; i < 3; ++i) d[i] *= rn;
+        const float world_step = rn * step_size;
+        float t = 0.f, tmax = 2e3f;
+        for (int i = 0; i < 3; ++i) {
+            const float invdir = (float)(1.0 / (double)d[i]);
+            const float t1 = (-0.5f - o[i]) * invdir;
+            const float t2 = ((float)size[i] - 0.5f - o[i]) * invdir;
+            if (d[i] != 0.f) {
+                t = fmaxf(t, fminf(t1, t2));
+                tmax = fminf(tmax, fmaxf(t1, t2));
+            }
+        }
+        if (t > tmax) continue;
+        float lli = 0.f;
+        while (t <= tmax) {
+            float pos[3];
+            int32_t l[3];
+            for (int j = 0; j < 3; ++j) {
+                pos[j] = o[j] + t * d[j];
+                pos[j] = fminf(fmaxf(pos[j], 0.f), (float)size[j] - 1.f);
+                l[j] = std::min((int32_t)pos[j], size[j] - 2);
+                pos[j] -= (float)l[j];
+            }
+            const int idx = l[0] * st0 + l[1] * st1 + l[2];
+            const int offs[8] = {0, 1, st1, st1 + 1, st0, st0 + 1, st0 + st1, st0 + st1 + 1};
+            float v[8];
+            for (int i = 0; i < 8; ++i) {
+                if (sparse) {
+                    const int32_t lk = links[idx + offs[i]];
+                    v[i] = lk >= 0 ? data[lk] : 0.f;
+                } else {
+                    v[i] = data[idx + offs[i]];
+                }
+            }
+            float sigma = trilerp(v, pos);
+            if (!sparse && last_sample_opaque && t + step_size > tmax) {
+                sigma += 1e9f;
+                lli = 0.f;
+            }
+            if (sigma > 1e-8f) {
+                const float log_att = -world_step * sigma;
+                const float tr = expf(lli);
+                const float val = sparse ? tr : tr * (1.f - expf(log_att));
+                lli += log_att;
+                for (int i = 0; i < 8; ++i) {
+                    float* q = out + idx + offs[i];
+#pragma omp critical(oracle_weight_max)
+                    if (val > *q) *q = val;
+                }
+                if (expf(lli) < stop_thresh) break;
+            }
+            t += step_size;
+        }
+    }
+    return 0;
+}
+
 }  // extern "C"

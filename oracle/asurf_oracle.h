@@ -192,6 +192,13 @@ int oracle_volume_render_cuvol_fused(const oracle_grid* grid, const oracle_rays*
                                      float beta_loss, float sparsity_loss, float* rgb_out,
                                      const oracle_grads* grads);
 
+/* misc_kernel.cu:186-400, 888-937: per-vertex max of the compositing weight (links == NULL, data = dense
+ * [X,Y,Z] volume) or of the transmittance in front of a sample (sparse grid) over a camera's pixel rays */
+int oracle_weight_render(const float* data, const int32_t* links, const int32_t* size, const float* c2w,
+                         float fx, float fy, float cx, float cy, int32_t width, int32_t height,
+                         float step_size, float stop_thresh, int32_t last_sample_opaque,
+                         const float* offset, const float* scaling, float* out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -363,6 +363,23 @@ def cuvol_fused(sc, origins, dirs, opts, rgb_gt, beta_loss=0.0, sparsity_loss=0.
     return rgb, grads
 
 
+def weight_render(data, links, c2w, fx, fy, cx, cy, width, height, step_size, stop_thresh, last_sample_opaque,
+                  offset, scaling, out=None):
+    """grid_weight_render (links=None, data = dense [X,Y,Z] volume) / sparse_grid_weight_render
+    (data = density rows): max into `out` [X,Y,Z] (zeros when not given).  Parity unpinned (see the .h)."""
+    data = np.ascontiguousarray(data, np.float32)
+    size = np.asarray(data.shape if links is None else links.shape, np.int32)
+    out = np.zeros(tuple(size), np.float32) if out is None else out
+    lk = None if links is None else np.ascontiguousarray(links, np.int32)
+    c2w = np.ascontiguousarray(np.asarray(c2w, np.float32)[:3, :4])
+    off, scl = np.ascontiguousarray(offset, np.float32), np.ascontiguousarray(scaling, np.float32)
+    _check(lib().oracle_weight_render(
+        _f(data), None if lk is None else _i(lk), _i(size), _f(c2w), C.c_float(fx), C.c_float(fy), C.c_float(cx),
+        C.c_float(cy), C.c_int32(width), C.c_int32(height), C.c_float(step_size), C.c_float(stop_thresh),
+        C.c_int32(int(bool(last_sample_opaque))), _f(off), _f(scl), _f(out)), "weight_render")
+    return out
+
+
 def set_legacy_f64_surface_grad(on):
     lib().oracle_set_legacy_f64_surface_grad(int(bool(on)))
 
