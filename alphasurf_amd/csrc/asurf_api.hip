@@ -587,6 +587,18 @@ int cuvol_bwd(const Launch& L, const asurf_rays* rays, int last_opaque, const KG
     return launch_error("k_cuvol_bwd");
 }
 
+template <int MODE>
+int cuvol_eval(const Launch& L, const asurf_rays* rays, float param, int max_sample, float* out0, float* out1) {
+    if (L.coarse_in_lds)
+        hipLaunchKernelGGL((k_cuvol_eval<MODE, true>), L.ray_grid, dim3(kBlock), L.dyn_lds, L.stream, L.g, L.o,
+                           rays->origins, rays->dirs, (long long)rays->n_rays, param, max_sample, out0, out1);
+    else
+        hipLaunchKernelGGL((k_cuvol_eval<MODE, false>), L.ray_grid, dim3(kBlock), 0, L.stream, L.g, L.o,
+                           rays->origins, rays->dirs, (long long)rays->n_rays, param, max_sample, out0, out1);
+    prof_after("k_cuvol_eval", 1, L.stream);
+    return launch_error("k_cuvol_eval");
+}
+
 }  // namespace
 
 extern "C" {
@@ -1207,6 +1219,29 @@ int asurf_volume_render_cuvol_fused(const asurf_grid* grid, const asurf_rays* ra
     ASURF_DISPATCH_B(grid->basis_dim, (cuvol_bwd<B_>(L, rays, opt->last_sample_opaque, G, rgb_gt, rgb_out, 1, log_t,
                                                      beta_loss / (float)rays->n_rays, sparsity_loss)));
     return rc;
+}
+
+// render_lerp_kernel_cuvol.cu:1356-1442: mode 0 expected_term, 1 mode_term (param = weight_thresh), 2 med_term
+// (out0 = depths, out1 = sigmas, [Q, max_sample], zeroed by the caller), 3 sigma_thresh (param = the threshold)
+int asurf_render_eval_cuvol(const asurf_grid* grid, const asurf_rays* rays, const asurf_render_options* opt,
+                            int32_t mode, float param, int32_t max_sample, float* out0, float* out1,
+                            void* workspace, size_t workspace_bytes, void* stream) {
+    if (mode < 0 || mode > 3) return fail(ASURF_E_INVALID, "render_eval_cuvol: mode must be 0..3");
+    if (!opt) return fail(ASURF_E_INVALID, "opt is NULL");
+    if (!(opt->step_size > 0.f)) return fail(ASURF_E_INVALID, "cuvol: step_size must be > 0");
+    asurf_render_options o2 = *opt;
+    if (mode == 3) o2.sigma_thresh = param;
+    Launch L;
+    if (int e = prepare(grid, rays, &o2, 0, workspace, workspace_bytes, stream, L, true, true)) return e;
+    if (rays->n_rays == 0) return 0;
+    if (!out0 || (mode == 2 && (!out1 || max_sample < 1)))
+        return fail(ASURF_E_INVALID, "render_eval_cuvol: output tensor missing");
+    switch (mode) {
+        case 0: return cuvol_eval<0>(L, rays, param, max_sample, out0, out1);
+        case 1: return cuvol_eval<1>(L, rays, param, max_sample, out0, out1);
+        case 2: return cuvol_eval<2>(L, rays, param, max_sample, out0, out1);
+        default: return cuvol_eval<3>(L, rays, param, max_sample, out0, out1);
+    }
 }
 
 }  // extern "C"

@@ -635,4 +635,69 @@ k_cuvol_bwd(KGrid g, KOpt o, int last_sample_opaque, KGrads G, const float* __re
     }
 }
 
+// ------------------------------------------------------------------------------------
+// Depth renders of the cuvol march (render_lerp_kernel_cuvol.cu:127-370, kernels :929-1020): one ray
+// per lane, no colours.  MODE 0 expected termination, 1 depth of the heaviest sample (both 0 unless
+// the accumulated weight exceeds `param`), 2 the first max_sample (depth, sigma) pairs, 3 the first
+// sample whose density exceeds `param` (the host passes it in o.sigma_thresh, so the occupancy masks
+// are built for it).
+// ------------------------------------------------------------------------------------
+template <int MODE, bool CLDS>
+__global__ void __launch_bounds__(kBlock)
+k_cuvol_eval(KGrid g, KOpt o, const float* __restrict__ origins, const float* __restrict__ dirs, long long Q,
+             float param, int max_sample, float* __restrict__ out0, float* __restrict__ out1) {
+    extern __shared__ unsigned int s_coarse[];
+    const int tid = threadIdx.x;
+    if constexpr (CLDS) {
+        for (int i = tid; i < g.coarse_words; i += kBlock) s_coarse[i] = g.coarse[i];
+        __syncthreads();
+    }
+    const long long q = (long long)blockIdx.x * kBlock + tid;
+    if (q >= Q) return;
+    Ray r;
+    float world_step;
+    cuvol_ray(g, o, origins, dirs, q, true, r, &world_step);
+    setup_ray(g, o, r);
+    if (r.tmin > r.tmax) {
+        if (MODE != 2) out0[q] = 0.f;
+        return;
+    }
+    March m;
+    march_init(g, o, r, m);
+    CuvolGather st;
+    cuvol_gather_init(st);
+    float outv = 0.f, weight_acc = 0.f, max_weight = -1.f, log_transmit = 0.f;
+    int sample_i = 0;
+    int budget = 1 << 24;  // lattice points: tmax <= 2e3 bounds the march, this bounds a defect
+    while (true) {
+        float t, pos[3], sigma;
+        if (cuvol_next<CLDS>(g, o, s_coarse, m, st.cell, &t, pos, &sigma, budget) != 1) break;
+        const float depth = (t / o.step_size) * world_step;
+        if (MODE == 3) {
+            outv = depth;
+            break;
+        }
+        const float pcnt = world_step * sigma;
+        const float weight = expf(log_transmit) * (1.f - expf(-pcnt));
+        log_transmit -= pcnt;
+        if (MODE == 0) {
+            outv += weight * depth;
+            weight_acc += weight;
+        } else if (MODE == 1) {
+            weight_acc += weight;
+            if (weight > max_weight) {
+                max_weight = weight;
+                outv = depth;
+            }
+        } else if (sample_i < max_sample) {
+            out0[(size_t)q * max_sample + sample_i] = depth;
+            out1[(size_t)q * max_sample + sample_i] = sigma;
+            ++sample_i;
+        }
+        if (expf(log_transmit) < o.stop_thresh) break;
+    }
+    if (MODE == 3) out0[q] = outv;
+    if (MODE == 0 || MODE == 1) out0[q] = weight_acc > param ? outv : 0.f;
+}
+
 }  // namespace asurf

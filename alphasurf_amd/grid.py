@@ -758,7 +758,7 @@ class SparseGrid(nn.Module):
     # ---- evaluation renders (:3693-3961 -> surf_trav.cu:3944-4081) ----
     def _eval_backend(self, kwargs):
         if kwargs.get("no_surface", False):
-            _next_row("N4", "no_surface evaluation renders (cuvol renderer)")
+            _next_row("N4", "no_surface normal / alpha / point renders")
         self._check_backend()
         if self.opt.backend != "surf_trav":
             _next_row("N3", f"evaluation renders of backend {self.opt.backend!r}")
@@ -767,8 +767,23 @@ class SparseGrid(nn.Module):
                             weight_thresh: float = 0.0, **kwargs):
         """Depth along each ray (absolute length, not z-depth): expected termination, the max-weight
         sample (`depth_type='mode'`), or the first sample above `sigma_thresh` (:3693-3763)."""
-        self._eval_backend(kwargs)
         g, r, o = self._to_cpp(), rays._to_cpp(), self.opt._to_cpp()
+        if self._check_backend(kwargs.get("no_surface", False)) == "cuvol":  # :3736-3772
+            if sigma_thresh is not None:
+                return _C.volume_render_sigma_thresh(g, r, o, sigma_thresh)
+            if depth_type == "mean":
+                return _C.volume_render_expected_term(g, r, o, weight_thresh)
+            if depth_type == "mode":
+                return _C.volume_render_mode_term(g, r, o, weight_thresh)
+            if depth_type == "med":
+                depths, sigmas = _C.volume_render_med_term(g, r, o, 1024)
+                nan_mask = (depths == 0.0) | (sigmas < 0.5)
+                depths[nan_mask] = torch.nan
+                sigmas[nan_mask] = torch.nan
+                ids = torch.nanmedian(sigmas, dim=-1).indices
+                return depths[torch.arange(depths.shape[0], device=depths.device), ids]
+            raise NotImplementedError(f"depth_type {depth_type} not recognised!")
+        self._eval_backend(kwargs)
         if sigma_thresh is None:
             if depth_type == "mode":
                 return _C.volume_render_mode_term_surf_trav(g, r, o, weight_thresh)

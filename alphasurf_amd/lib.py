@@ -98,7 +98,7 @@ EXPORTS = [
     "asurf_render_eval_surf_trav", "asurf_dilate", "asurf_accel_dist_prop_tmp_bytes", "asurf_accel_dist_prop",
     "asurf_sample_plane", "asurf_sample_plane_backward",
     "asurf_volume_render_cuvol", "asurf_volume_render_cuvol_backward", "asurf_volume_render_cuvol_fused",
-    "asurf_grid_weight_render", "asurf_sparse_grid_weight_render",
+    "asurf_grid_weight_render", "asurf_sparse_grid_weight_render", "asurf_render_eval_cuvol",
 ]
 
 _lib = None
@@ -156,6 +156,7 @@ def lib():
         L.asurf_volume_render_cuvol_fused.argtypes = [vp, vp, vp, vp, fl, fl, vp, vp, vp, C.c_size_t, vp]
         L.asurf_grid_weight_render.argtypes = [vp, vp, vp, fl, fl, C.c_int32, vp, vp, vp, vp]
         L.asurf_sparse_grid_weight_render.argtypes = [vp, vp, vp, vp, fl, fl, vp, vp, vp, vp]
+        L.asurf_render_eval_cuvol.argtypes = [vp, vp, vp, C.c_int32, fl, C.c_int32, vp, vp, vp, C.c_size_t, vp]
         if L.asurf_abi_version() != 1:
             raise RuntimeError("libasurf_hip.so ABI version mismatch")
         _lib = L

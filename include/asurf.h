@@ -329,6 +329,16 @@ int asurf_volume_render_cuvol_fused(const asurf_grid* grid, const asurf_rays* ra
                                     float sparsity_loss, float* rgb_out, const asurf_grads* grads,
                                     void* workspace, size_t workspace_bytes, void* stream);
 
+/* Depth renders of the cuvol march (render_lerp_kernel_cuvol.cu:1356-1442).  mode 0
+ * volume_render_expected_term and 1 volume_render_mode_term (param = weight_thresh; out0[Q]),
+ * 2 volume_render_med_term (out0 = depths, out1 = sigmas, both [Q, max_sample] and zeroed by the
+ * caller), 3 volume_render_sigma_thresh (param = the threshold; out0[Q]).  Workspace as for
+ * asurf_volume_render_cuvol. */
+int asurf_render_eval_cuvol(const asurf_grid* grid, const asurf_rays* rays,
+                            const asurf_render_options* opt, int32_t mode, float param,
+                            int32_t max_sample, float* out0, float* out1, void* workspace,
+                            size_t workspace_bytes, void* stream);
+
 /* Pinhole camera of the image-order entry points (CameraSpec, data_spec.hpp:84-112): c2w holds the
  * rows of the 3x4 camera-to-world matrix (HOST values); NDC cameras are not built. */
 typedef struct asurf_camera {

@@ -2166,4 +2166,69 @@ int oracle_weight_render(const float* data, const int32_t* links, const int32_t*
     return 0;
 }
 
+/* render_lerp_kernel_cuvol.cu:127-370, 1356-1442: depth renders of the cuvol march.  mode 0 expected term,
+ * 1 mode term (param = weight_thresh), 2 med term (out0 depths / out1 sigmas, [Q, max_sample], zeroed here),
+ * 3 first sample above param. */
+int oracle_render_eval_cuvol(const oracle_grid* grid, const oracle_rays* rays, const oracle_render_options* opt,
+                             int32_t mode, float param, int32_t max_sample, float* out0, float* out1) {
+    if (int rc = cuvol_check(grid, rays, opt)) return rc;
+    if (mode < 0 || mode > 3 || !out0 || (mode == 2 && (!out1 || max_sample < 1))) return -1;
+    const oracle_grid& g = *grid;
+    const oracle_render_options& o = *opt;
+#pragma omp parallel for schedule(dynamic, 64)
+    for (int64_t q = 0; q < rays->n_rays; ++q) {
+        Ray r;
+        setup_ray(g, o, rays->origins + 3 * q, rays->dirs + 3 * q, r);
+        if (mode == 2)
+            for (int i = 0; i < max_sample; ++i) out0[q * max_sample + i] = out1[q * max_sample + i] = 0.f;
+        else
+            out0[q] = 0.f;
+        if (r.tmin > r.tmax) continue;
+        float t = r.tmin, outv = 0.f, weight_acc = 0.f, max_weight = -1.f, log_transmit = 0.f;
+        int sample_i = 0;
+        const float thresh = mode == 3 ? param : o.sigma_thresh;
+        while (t <= r.tmax) {
+            int32_t l[3], lk[8];
+            float pos[3];
+            cuvol_cell(g, r, t, l, pos);
+            const float skip = cuvol_skip_dist(g, r, l, pos);
+            if (skip >= o.step_size) {
+                t += ceilf(skip / o.step_size) * o.step_size;
+                continue;
+            }
+            cuvol_links(g, l, lk);
+            const float sigma = cuvol_lerp(g.density_data, 1, 0, lk, pos);
+            if (sigma > thresh) {
+                const float depth = (t / o.step_size) * r.world_step;
+                if (mode == 3) {
+                    outv = depth;
+                    break;
+                }
+                const float pcnt = r.world_step * sigma;
+                const float weight = expf(log_transmit) * (1.f - expf(-pcnt));
+                log_transmit -= pcnt;
+                if (mode == 0) {
+                    outv += weight * depth;
+                    weight_acc += weight;
+                } else if (mode == 1) {
+                    weight_acc += weight;
+                    if (weight > max_weight) {
+                        max_weight = weight;
+                        outv = depth;
+                    }
+                } else if (sample_i < max_sample) {
+                    out0[q * max_sample + sample_i] = depth;
+                    out1[q * max_sample + sample_i] = sigma;
+                    ++sample_i;
+                }
+                if (expf(log_transmit) < o.stop_thresh) break;
+            }
+            t += o.step_size;
+        }
+        if (mode == 3) out0[q] = outv;
+        if (mode == 0 || mode == 1) out0[q] = weight_acc > param ? outv : 0.f;
+    }
+    return 0;
+}
+
 }  // extern "C"

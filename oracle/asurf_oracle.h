@@ -199,6 +199,12 @@ int oracle_weight_render(const float* data, const int32_t* links, const int32_t*
                          float step_size, float stop_thresh, int32_t last_sample_opaque,
                          const float* offset, const float* scaling, float* out);
 
+/* render_lerp_kernel_cuvol.cu:127-370, 1356-1442: mode 0 expected term, 1 mode term (param = weight_thresh),
+ * 2 med term (out0 depths / out1 sigmas [Q, max_sample]), 3 first sample above param */
+int oracle_render_eval_cuvol(const oracle_grid* grid, const oracle_rays* rays,
+                             const oracle_render_options* opt, int32_t mode, float param,
+                             int32_t max_sample, float* out0, float* out1);
+
 #ifdef __cplusplus
 }
 #endif

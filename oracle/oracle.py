@@ -380,6 +380,21 @@ def weight_render(data, links, c2w, fx, fy, cx, cy, width, height, step_size, st
     return out
 
 
+CUVOL_EVAL_MODES = {"expected_term": 0, "mode_term": 1, "med_term": 2, "sigma_thresh": 3}
+
+
+def cuvol_eval(sc, origins, dirs, opts, what, param=0.0, max_sample=1):
+    """Depth renders of the cuvol march: what in CUVOL_EVAL_MODES; med_term returns (depths, sigmas)."""
+    r = _rays(origins, dirs)
+    mode = CUVOL_EVAL_MODES[what]
+    shape = (r.n_rays, max_sample) if mode == 2 else (r.n_rays,)
+    out0, out1 = np.zeros(shape, np.float32), np.zeros(shape if mode == 2 else (1,), np.float32)
+    g, o = _grid(sc), make_opts(opts)
+    _check(lib().oracle_render_eval_cuvol(C.byref(g), C.byref(r), C.byref(o), C.c_int32(mode), C.c_float(param),
+                                          C.c_int32(max_sample), _f(out0), _f(out1)), "cuvol eval")
+    return (out0, out1) if mode == 2 else out0
+
+
 def set_legacy_f64_surface_grad(on):
     lib().oracle_set_legacy_f64_surface_grad(int(bool(on)))
 

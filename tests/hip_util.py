@@ -202,6 +202,19 @@ def cuvol_fused(sc, origins, dirs, opts, rgb_gt, beta_loss=0.0, sparsity_loss=0.
     return rgb.cpu().numpy(), _cuvol_grads_np(gr)
 
 
+def cuvol_eval(sc, origins, dirs, opts, what, param=0.0, max_sample=1):
+    g, r, o = grid_spec(sc), rays_spec(origins, dirs), opt_spec(opts)
+    fn = {"expected_term": _C.volume_render_expected_term, "mode_term": _C.volume_render_mode_term,
+          "sigma_thresh": _C.volume_render_sigma_thresh}
+    if what == "med_term":
+        a, b = _C.volume_render_med_term(g, r, o, max_sample)
+        torch.cuda.synchronize()
+        return a.cpu().numpy(), b.cpu().numpy()
+    out = fn[what](g, r, o, param)
+    torch.cuda.synchronize()
+    return out.cpu().numpy()
+
+
 # ---- evaluation renders ----
 def render_eval(sc, origins, dirs, opts, what, param=0.0, max_sample=1):
     g, r, o = grid_spec(sc), rays_spec(origins, dirs), opt_spec(opts)

@@ -186,3 +186,44 @@ def test_sparse_grid_api(hip):
     assert sdf.surface_data.grad is None or not sdf.surface_data.grad.any()
     assert torch.equal(sdf.density_data.grad, grid.density_data.grad) or \
         torch.allclose(sdf.density_data.grad, grid.density_data.grad, rtol=1e-4, atol=1e-9)
+
+
+@pytest.mark.parametrize("optname", ["plenoxels", "gate", "opaque_end", "spheric"])
+def test_depth_renders_vs_oracle(hip, oracle, optname):
+    sc, o, d = cuvol_scene(4)
+    opt = OPTION_SETS[optname]
+    for what, param in (("expected_term", 0.0), ("expected_term", 0.6), ("mode_term", 0.1), ("sigma_thresh", 0.5),
+                        ("sigma_thresh", 4.0)):
+        got = hip.cuvol_eval(sc, o, d, opt, what, param)
+        ref = oracle.cuvol_eval(sc, o, d, opt, what, param)
+        assert (ref > 0).sum() > 200
+        if what == "mode_term":      # two samples of nearly equal weight may swap
+            assert (np.abs(got - ref) > 1e-5 * (1 + np.abs(ref))).mean() < 0.01
+        else:
+            np.testing.assert_allclose(got, ref, rtol=2e-5, atol=1e-6, err_msg=f"{what} {param}")
+    gd, gs = hip.cuvol_eval(sc, o, d, opt, "med_term", max_sample=48)
+    rd, rs_ = oracle.cuvol_eval(sc, o, d, opt, "med_term", max_sample=48)
+    np.testing.assert_allclose(gd, rd, rtol=1e-6, atol=1e-7)
+    np.testing.assert_allclose(gs, rs_, rtol=1e-5, atol=1e-6)
+
+
+def test_depth_through_the_grid_api(hip):
+    import torch
+    import svox2
+    from alphasurf_amd import synth
+    dev = torch.device("cuda:0")
+    grid = svox2.SparseGrid(reso=32, basis_dim=1, use_sphere_bound=True, device=dev,
+                            surface_type=svox2.SURFACE_TYPE_SDF, surface_init="sphere")
+    grid.opt.backend = "surf_trav"
+    grid.opt.sigma_thresh, grid.opt.stop_thresh, grid.opt.step_size = 1e-8, 1e-7, 0.5
+    ax = (torch.arange(32, dtype=torch.float32) + 0.5) / 16 - 1
+    r = torch.sqrt(ax[:, None, None] ** 2 + ax[None, :, None] ** 2 + ax[None, None, :] ** 2).to(dev)
+    grid.density_data.data[:] = torch.where(r < 0.5, 80.0, 0.0)[grid.links >= 0].view(-1, 1)
+    cam = svox2.Camera(torch.from_numpy(synth.look_at_c2w([2.5, 0.0, 0.0]).astype(np.float32)).to(dev), fx=60.0,
+                       width=48, height=48)
+    for kw in (dict(), dict(depth_type="mode"), dict(depth_type="med"), dict(sigma_thresh=10.0)):
+        depth = grid.volume_render_depth_image(cam, no_surface=True, **kw)
+        centre = float(depth[24, 24])
+        tol = 0.5 if kw.get("depth_type") == "med" else 0.12         # 'med' picks a sample inside the ball
+        assert depth.shape == (48, 48) and -0.05 < centre - 2.0 < tol, (kw, centre)   # eye at 2.5, ball radius 0.5
+        assert float(depth[0, 0]) == 0.0 or np.isnan(float(depth[0, 0]))

@@ -104,3 +104,30 @@ def test_cuvol_options(oracle):
     assert 1e-4 < np.abs(base - stop).max() < 0.25
     with pytest.raises(RuntimeError):
         oracle.cuvol_forward(sc, z["origins"], z["dirs"], dict(opt, step_size=0.0))
+
+
+def test_cuvol_depth_renders(oracle):
+    """The depth renders share the pinned march; their accumulators are checked against each other."""
+    z, sc, opt = load_cuvol(oracle, "cuvol_r16_sh9")
+    o, d = z["origins"], z["dirs"]
+    mean = oracle.cuvol_eval(sc, o, d, opt, "expected_term", 0.0)
+    mode = oracle.cuvol_eval(sc, o, d, opt, "mode_term", 0.0)
+    depths, sigmas = oracle.cuvol_eval(sc, o, d, opt, "med_term", max_sample=64)
+    first = oracle.cuvol_eval(sc, o, d, opt, "sigma_thresh", 0.0)
+    hit = sigmas[:, 0] > 0            # (a ray that starts inside the grid may have its first sample at t = 0)
+    assert hit.sum() > 100
+    np.testing.assert_array_equal(first[hit], depths[hit, 0])        # sigma_thresh == the gate: the first sample
+    assert not first[~hit].any() and not mean[~hit].any() and not mode[~hit].any()
+    n = (sigmas > 0).sum(1)
+    last = depths[np.arange(len(n)), np.maximum(n - 1, 0)]
+    full = hit & (n < 64)
+    assert (mean[full] <= last[full] * (1 + 1e-5)).all()             # a weighted sum with total weight <= 1
+    assert (np.diff(depths, axis=1)[:, :1][n > 1] > 0).all()         # increasing along the ray
+    assert ((mode[full] >= depths[full, 0] * (1 - 1e-6)) & (mode[full] <= last[full] * (1 + 1e-6))).all()
+    # weight gate: an impossible threshold zeroes everything; a higher sigma threshold is met later or never
+    assert not oracle.cuvol_eval(sc, o, d, opt, "expected_term", 1.0).any()
+    later = oracle.cuvol_eval(sc, o, d, opt, "sigma_thresh", 3.0)
+    assert ((later == 0) | (later >= first)).all() and (later > first).any()
+    # depth is the world distance: t / step * world_step with |dir| = 1
+    gsz = np.asarray(z["links"].shape, np.float32)
+    assert abs(float(first[hit].min())) < 4 * float(np.linalg.norm(o, axis=1).max())
