@@ -585,7 +585,7 @@ class SparseGrid(nn.Module):
         if use_z_order:
             _next_row("N4", "resample into Morton order")
         if self.surface_data is not None:
-            _next_row("N4", "resample of a surface grid (resample_surface)")
+            raise RuntimeError("resample() drops the surface plane: use resample_surface() on a surface grid")
         with torch.no_grad():
             device = self.links.device
             reso = [reso] * 3 if isinstance(reso, int) else list(reso)
@@ -635,6 +635,84 @@ class SparseGrid(nn.Module):
             self._data_to_links = None
             if accelerate:
                 self.accelerate()
+
+    def resample_surface(self, reso, alpha_thresh: float = 1e-6, weight_thresh: float = 0.01, dilate: int = 2,
+                         cameras=None, use_z_order: bool = False, accelerate: bool = True,
+                         weight_render_stop_thresh: float = 0.2, max_elements: int = 0, batch_size: int = 720720,
+                         alpha_empty_val: float = -20.0, non_expanding: bool = False):
+        """Resample a surface grid (raw opacity, SH and the surface field) onto resolution `reso` (:4172-4420):
+        vertices whose raw opacity reaches `alpha_thresh` (its logit under the sigmoid activation) -- or, given
+        `cameras`, whose largest compositing weight reaches `weight_thresh` -- are kept after `dilate` dilations;
+        `non_expanding` also drops vertices that fall into cells the old surface field does not cover.
+        Returns the kept fraction.  Morton order is not offered."""
+        if use_z_order:
+            _next_row("N4", "resample into Morton order")
+        if self.surface_data is None:
+            raise RuntimeError("resample_surface() needs a surface grid: use resample()")
+        with torch.no_grad():
+            device = self.links.device
+            reso = [reso] * 3 if isinstance(reso, int) else list(reso)
+            assert len(reso) == 3, "reso must be an integer or indexable object of 3 ints"
+            cur = self.links.shape
+            ax = [torch.linspace(0.0, cur[i] - 0.5, reso[i], dtype=torch.float32) for i in range(3)]  # :4225-4243
+            points = torch.stack(torch.meshgrid(*ax, indexing="ij"), dim=-1).view(-1, 3).to(device)
+            sigmoid = self.opt.alpha_activation_type == CONSTANTS["SIGMOID_FN"]
+            spec = self._to_cpp(grid_coords=True)
+            raw = torch.cat([_C.sample_grid_raw_alpha(spec, points[i:i + batch_size].contiguous(),
+                                                      alpha_empty_val if sigmoid else 0.0)
+                             for i in range(0, len(points), batch_size)], dim=0).view(reso)
+            if cameras is not None:
+                gsz = torch.tensor(reso, dtype=torch.float32)
+                max_wt = torch.zeros(reso, dtype=torch.float32, device=device)
+                raw = raw.contiguous()
+                for cam in cameras:
+                    _C.grid_weight_render(raw, cam._to_cpp(), 0.5, weight_render_stop_thresh, False,
+                                          self._offset * gsz - 0.5, self._scaling * gsz, max_wt)
+                mask = max_wt >= weight_thresh
+                if 0 < max_elements < max_wt.numel() and max_elements < int(torch.count_nonzero(mask)):
+                    bound = torch.topk(max_wt.view(-1), k=max_elements, sorted=False).values.min().item()
+                    weight_thresh = max(weight_thresh, bound)
+                    mask = max_wt >= weight_thresh
+                del max_wt
+            else:
+                if sigmoid:
+                    alpha_thresh = float(np.log(alpha_thresh / (1.0 - alpha_thresh)))
+                mask = raw >= alpha_thresh
+                if 0 < max_elements < raw.numel() and max_elements < int(torch.count_nonzero(mask)):
+                    bound = torch.topk(raw.view(-1), k=max_elements, sorted=False).values.min().item()
+                    alpha_thresh = max(alpha_thresh, bound)
+                    mask = raw >= alpha_thresh
+                if self.opt.last_sample_opaque:
+                    mask[:, :, -1] = True
+            for _ in range(int(dilate)):
+                mask = _C.dilate(mask.contiguous())
+            mask = mask.view(-1).bool()
+            raw = raw.view(-1)[mask]
+            kept_pts = points[mask]
+            default_surf = float("nan") if non_expanding else -1.0
+            parts = [self.sample_surface(kept_pts[i:i + batch_size], grid_coords=True, want_colors=True,
+                                         default_surf=default_surf) for i in range(0, len(kept_pts), batch_size)]
+            sh = torch.cat([p[0] for p in parts], dim=0) if parts else torch.empty_like(self.sh_data.data[:0])
+            surf = torch.cat([p[1] for p in parts], dim=0) if parts else torch.empty_like(self.surface_data.data[:0])
+            if non_expanding:  # :4357-4368
+                valid = ~torch.isnan(surf)[:, 0]
+                ids = torch.arange(mask.shape[0], device=device)[mask]
+                mask[ids] = valid
+                sh, surf, raw = sh[valid], surf[valid], raw[valid]
+            ratio = float(torch.count_nonzero(mask)) / mask.numel()
+            links = torch.cumsum(mask.to(torch.int32), dim=-1).int() - 1
+            links[~mask] = -1
+            self.density_data = nn.Parameter(raw.view(-1, 1).contiguous())
+            self.sh_data = nn.Parameter(sh.contiguous())
+            self.surface_data = nn.Parameter(surf.view(-1, 1).contiguous())
+            self.links = links.view(reso).contiguous()
+            self.capacity = int(raw.shape[0])
+            self.density_rms = self.sh_rms = self.surface_rms = None
+            self.sparse_grad_indexer = self.sparse_sh_grad_indexer = None
+            self._data_to_links = None
+            if accelerate:
+                self.accelerate()
+            return ratio
 
     # ---- grid maintenance (:2859-2957, 4483-4490 -> misc_kernel.cu) ----
     def accelerate(self):

@@ -92,7 +92,9 @@ def test_svox2_alias_presents_the_reference_names():
     with pytest.raises(NotImplementedError, match="N2"):
         g.inplace_tv_lumisphere_grad(None)
     with pytest.raises(NotImplementedError, match="N4"):
-        g.resample(None)
+        g.extract_mesh(None)
+    with pytest.raises(RuntimeError, match="resample_surface"):
+        g.resample(8)               # a surface grid goes through resample_surface
     # the N2 regularisers of the live config are built (tests/test_reg_gpu.py)
     for name in ["inplace_tv_grad", "inplace_tv_surface_grad", "inplace_surface_normal_grad",
                  "inplace_surface_eikonal_grad", "inplace_alpha_surf_sparsify_grad", "inplace_tv_color_grad",

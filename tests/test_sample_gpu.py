@@ -109,3 +109,49 @@ def test_grid_sample_autograd_and_resample(env):
     d2, _ = grid.sample(before_pts, want_colors=False)
     # (a trilinear resampling of a kinked radial field: close to the coarse value, not equal)
     np.testing.assert_allclose(d2.detach().cpu().numpy(), ref_d.cpu().numpy(), rtol=0.05, atol=1.0)
+
+
+def test_resample_surface():
+    """resample_surface (:4172-4420): a sphere SDF grid with opacity concentrated in a shell, 24^3 -> 40^3.  The
+    new vertices carry the trilinearly sampled fields; the zero level set stays where it was."""
+    import torch
+    import svox2
+    dev = torch.device("cuda:0")
+    grid = svox2.SparseGrid(reso=24, basis_dim=4, device=dev, surface_type=svox2.SURFACE_TYPE_SDF,
+                            surface_init="sphere")
+    lk = grid.links
+    ax = (torch.arange(24, dtype=torch.float32) + 0.5) / 12 - 1
+    r = torch.sqrt(ax[:, None, None] ** 2 + ax[None, :, None] ** 2 + ax[None, None, :] ** 2).to(dev)
+    grid.surface_data.data[:] = (r - 0.55)[lk >= 0].view(-1, 1)
+    grid.density_data.data[:] = torch.where((r - 0.55).abs() < 0.25, 2.0, 0.0)[lk >= 0].view(-1, 1)
+    gen = torch.Generator().manual_seed(1)
+    grid.sh_data.data[:] = torch.randn(grid.sh_data.shape, generator=gen).to(dev)
+    old = grid.sample_surface(torch.tensor([[0.55, 0.0, 0.0], [0.0, -0.3, 0.4]], device=dev))
+    ratio = grid.resample_surface(40, alpha_thresh=0.5, dilate=1, accelerate=False)
+    kept = int((grid.links >= 0).sum())
+    assert tuple(grid.links.shape) == (40, 40, 40) and 0.05 < ratio < 0.7 and abs(ratio - kept / 40 ** 3) < 1e-6
+    assert grid.density_data.shape == (kept, 1) and grid.surface_data.shape == (kept, 1) and \
+        grid.sh_data.shape == (kept, 12)
+    # rows are numbered in raster order
+    flat = grid.links.view(-1)
+    assert torch.equal(flat[flat >= 0], torch.arange(kept, dtype=torch.int32, device=dev))
+    # kept vertices lie around the shell, and the surface field there still measures r - 0.55
+    ax2 = torch.linspace(0.0, 23.5, 40)                      # new vertex positions in old grid coordinates
+    w = (ax2 + 0.5) / 12 - 1
+    r2 = torch.sqrt(w[:, None, None] ** 2 + w[None, :, None] ** 2 + w[None, None, :] ** 2).to(dev)
+    rk = r2[grid.links >= 0]
+    assert rk.min() > 0.15 and rk.max() < 0.95
+    surf = grid.surface_data.data[:, 0]
+    near = (rk - 0.55).abs() < 0.15
+    assert near.sum() > 1000 and (surf[near] - (rk[near] - 0.55)).abs().max() < 0.02
+    new = grid.sample_surface(torch.tensor([[0.55, 0.0, 0.0], [0.0, -0.3, 0.4]], device=dev))
+    assert (new[1] - old[1]).abs().max() < 0.02              # same field at the same world points
+    # the sigmoid activation thresholds the logit and pads missing opacity with alpha_empty_val
+    g2 = svox2.SparseGrid(reso=16, basis_dim=1, device=dev, surface_type=svox2.SURFACE_TYPE_SDF, surface_init="sphere",
+                          use_sphere_bound=True)
+    g2.opt.alpha_activation_type = svox2.SIGMOID_FN
+    g2.density_data.data[:] = 3.0
+    r0 = g2.resample_surface(20, alpha_thresh=0.5, dilate=0, accelerate=False, non_expanding=True)
+    assert 0.2 < r0 < 0.9 and not torch.isnan(g2.surface_data.data).any()
+    with pytest.raises(RuntimeError):
+        svox2.SparseGrid(reso=8, basis_dim=1, device=dev).resample_surface(8)
