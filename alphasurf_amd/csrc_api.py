@@ -516,6 +516,22 @@ def tv_grad_sparse(links, data, rand_cells, mask_out, start_dim, end_dim, scale,
                                                int(bool(ignore_last_z)), _ptr(grad_data), _stream(dev)))
 
 
+def tv_grad(links, data, start_dim, end_dim, scale, use_logalpha, logalpha_delta, ignore_edge, ndc_coeffx,
+            ndc_coeffy, grad_data):
+    """void tv_grad(...) -- loss_kernel.cu:120-190, 1249-1287: the dense form, every cell with x < X-1, y < Y-1,
+    z < Z-1 and scale / their number.  Served by the sparse kernel over that cell list (the same arithmetic:
+    no last-z rule, no mask)."""
+    lp, size = _links_args(links)
+    sx, sy, sz = links.shape
+    if min(sx, sy, sz) < 2:
+        return
+    dev = links.device
+    ax = [torch.arange(n - 1, dtype=torch.int32, device=dev) for n in (sx, sy, sz)]
+    cells = ((ax[0][:, None, None] * sy + ax[1][None, :, None]) * sz + ax[2][None, None, :]).reshape(-1).contiguous()
+    tv_grad_sparse(links, data, cells, None, start_dim, end_dim, scale, use_logalpha, logalpha_delta, ignore_edge,
+                   False, ndc_coeffx, ndc_coeffy, grad_data)
+
+
 def surf_tv_grad_sparse(links, data, density_data, rand_cells, mask_out, start_dim, end_dim, scale,
                         ignore_edge, edge_value, ignore_last_z, ndc_coeffx, ndc_coeffy, alpha_dependency,
                         grad_data):
@@ -917,7 +933,7 @@ for _name, _row in [
         ("volume_render_svox1_backward", "out of scope"), ("volume_render_svox1_fused", "out of scope"),
         ("sparse_grid_mask_render", "N4"),
         ("sparse_grid_visbility_render_surf", "N4"), ("cubic_extract_iso_pts", "N4"), ("sample_cubemap", "N4"),
-        ("tv", "N2"), ("tv_grad", "N2"), ("surface_normal_grad", "N2"), ("alpha_lap_grad_sparse", "N2"),
+        ("tv", "N2"), ("surface_normal_grad", "N2"), ("alpha_lap_grad_sparse", "N2"),
         ("lumisphere_tv_grad_sparse", "N2"), ("msi_tv_grad_sparse", "N2"), ("surf_sign_change_grad_sparse", "N2")]:
     globals()[_name] = _out_of_scope(_name, _row)
 del _name, _row

@@ -988,8 +988,11 @@ class SparseGrid(nn.Module):
         assert self.density_data.is_cuda and grad.is_cuda, "the HIP extension is required for total variation"
         assert not logalpha, "No longer supported"
         rand_cells = self._get_rand_cells(sparse_frac, contiguous=contiguous)
-        if rand_cells is None:
-            _next_row("N2", "dense tv_grad (sparse_frac >= 1)")
+        if rand_cells is None:  # :4977-4986
+            _C.tv_grad(self.links, self.density_data, 0, 1, scaling, logalpha, logalpha_delta, False, ndc_coeffs[0],
+                       ndc_coeffs[1], grad)
+            self.sparse_grad_indexer = None
+            return
         if rand_cells.size(0) > 0:
             _C.tv_grad_sparse(self.links, self.density_data, rand_cells, self._get_sparse_grad_indexer(), 0, 1,
                               scaling, logalpha, logalpha_delta, False, self.opt.last_sample_opaque,
@@ -1005,12 +1008,30 @@ class SparseGrid(nn.Module):
         end_dim = n if end_dim is None else (end_dim + n if end_dim < 0 else end_dim)
         start_dim = start_dim + n if start_dim < 0 else start_dim
         rand_cells = self._get_rand_cells(sparse_frac, contiguous=contiguous)
-        if rand_cells is None:
-            _next_row("N2", "dense tv_grad (sparse_frac >= 1)")
+        if rand_cells is None:  # :5813-5824
+            _C.tv_grad(self.links, self.sh_data, start_dim, end_dim, scaling, logalpha, logalpha_delta, True,
+                       ndc_coeffs[0], ndc_coeffs[1], grad)
+            self.sparse_sh_grad_indexer = None
+            return
         if rand_cells.size(0) > 0:
             _C.tv_grad_sparse(self.links, self.sh_data, rand_cells, self._get_sparse_sh_grad_indexer(),
                               start_dim, end_dim, scaling, logalpha, logalpha_delta, True, False,
                               ndc_coeffs[0], ndc_coeffs[1], grad)
+
+    def inplace_l2_color_grad(self, grad: torch.Tensor, start_dim: int = 0, end_dim: Optional[int] = None,
+                              scaling: float = 1.0):
+        """L2 penalty on SH coefficients [start_dim, end_dim) added into `grad`, over the rows the last render
+        touched (:5897-5928; plain tensor arithmetic in the reference too)."""
+        with torch.no_grad():
+            n = self.sh_data.size(1)
+            end_dim = n if end_dim is None else (end_dim + n if end_dim < 0 else end_dim)
+            start_dim = start_dim + n if start_dim < 0 else start_dim
+            if self.sparse_sh_grad_indexer is None:
+                grad[:, start_dim:end_dim] += (scaling / self.sh_data.size(0)) * self.sh_data[:, start_dim:end_dim]
+            else:
+                indexer = self._maybe_convert_sparse_grad_indexer(sh=True)
+                nz = int(torch.count_nonzero(indexer)) if indexer.dtype == torch.bool else indexer.size(0)
+                grad[indexer, start_dim:end_dim] += (scaling / nz) * self.sh_data[indexer, start_dim:end_dim]
 
     def inplace_tv_surface_grad(self, grad: torch.Tensor, scaling: float = 1.0, sparse_frac: float = 0.01,
                                 ndc_coeffs=(-1.0, -1.0), alpha_dependency: bool = True,

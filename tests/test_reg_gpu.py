@@ -168,3 +168,39 @@ def test_grid_methods(env, oracle):
     grid.inplace_tv_color_grad(grid.sh_data.grad, start_dim=1, scaling=1e-3, sparse_frac=0.01)
     assert grid.sh_data.grad[:, 1:].abs().sum().item() > 0 and grid.sh_data.grad[:, 0].abs().sum().item() == 0
     assert grid.sparse_grad_indexer.any()
+
+
+def test_dense_tv_and_l2_colour(env, oracle):
+    """sparse_frac >= 1 takes the dense tv_grad (loss_kernel.cu:120-190): every interior cell, no mask; the L2
+    colour penalty is tensor arithmetic over the rows the last render touched (svox2.py:5897-5928)."""
+    torch, _C = env
+    import svox2
+    from test_grid_api_gpu import make_grid
+    grid = make_grid(torch, svox2, 24, 4)
+    n = grid.capacity
+    for p in (grid.density_data, grid.sh_data):
+        p.grad = torch.zeros_like(p.data)
+    grid.sparse_grad_indexer = torch.zeros(n, dtype=torch.bool, device="cuda")
+    grid.inplace_tv_grad(grid.density_data.grad, scaling=1e-3, sparse_frac=1.0)
+    assert grid.sparse_grad_indexer is None
+    links = grid.links.cpu().numpy()
+    sx, sy, sz = links.shape
+    cells = np.arange(sx * sy * sz, dtype=np.int32).reshape(sx, sy, sz)[:-1, :-1, :-1].reshape(-1)
+    go, _ = oracle.tv_grad_sparse(links, grid.density_data.data.cpu().numpy(), cells, 1e-3)
+    grad_close(grid.density_data.grad.cpu().numpy(), go, 1e-4, "dense tv_grad")
+    grid.inplace_tv_color_grad(grid.sh_data.grad, start_dim=3, end_dim=9, scaling=1e-2, sparse_frac=1.0)
+    go, _ = oracle.tv_grad_sparse(links, grid.sh_data.data.cpu().numpy(), cells, 1e-2, start_dim=3, end_dim=9,
+                                  ignore_edge=True)
+    grad_close(grid.sh_data.grad.cpu().numpy(), go, 1e-4, "dense colour tv_grad")
+    # L2 colour: all rows, then the touched rows only (mask and index-list forms)
+    g = torch.zeros_like(grid.sh_data.data)
+    grid.sparse_sh_grad_indexer = None
+    grid.inplace_l2_color_grad(g, start_dim=1, scaling=2.0)
+    assert torch.allclose(g[:, 1:], 2.0 / n * grid.sh_data.data[:, 1:]) and not g[:, 0].any()
+    for frac in (0.5, 0.05):
+        mask = torch.rand(n, device="cuda") < frac
+        grid.sparse_sh_grad_indexer = mask
+        g = torch.zeros_like(grid.sh_data.data)
+        grid.inplace_l2_color_grad(g, scaling=3.0)
+        nz = int(mask.sum())
+        assert torch.allclose(g[mask], 3.0 / nz * grid.sh_data.data[mask]) and not g[~mask].any()
