@@ -280,7 +280,7 @@ def test_error_behaviour(hip):
     with pytest.raises(RuntimeError):
         _C.volume_render_surf_trav_fused(g, r, op, gt, *args, torch.zeros_like(gt), hip.zero_grads(g))
     with pytest.raises(NotImplementedError, match="N4"):
-        _C.grid_weight_render()
+        _C.sparse_grid_mask_render()
 
 
 def test_cubic_root_grad_kernel(hip, oracle):
