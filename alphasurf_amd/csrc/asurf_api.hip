@@ -54,6 +54,20 @@ struct MaskLayout {
 // work voxels per ray the three-kernel forward keeps; longer rays go to the one-kernel path
 constexpr int kPipeC1 = 32;
 
+// Lanes per ray in the walk.  k_walk's duration is that of its longest serial chains until the batch
+// fills the chip several times over: measured on the bench scene (ms per fused step, 1 / 4 / 8 lanes):
+// 1.3 k rays 0.64 / 0.48 / 0.39, 20 k 0.77 / 0.56 / 0.55, 80 k 0.86 / 0.64 / 0.67, 160 k 0.95 / 0.79 / 0.85,
+// 640 k 1.52 / 1.65 / 1.79.  ASURF_WALK_SEG = 1, 2, 4 or 8 overrides (tests, measurement).
+static int walk_segments(long long n_rays) {
+    if (const char* e = getenv("ASURF_WALK_SEG")) {
+        const int n = atoi(e);
+        if (n == 1 || n == 2 || n == 4 || n == 8) return n;
+    }
+    if (n_rays <= 8192) return 8;
+    if (n_rays <= 262144) return 4;
+    return 1;
+}
+
 // per-ray capacity of the sample records the fused forward leaves for the replaying
 // backward; rays with more samples fall back to the walking backward kernel
 constexpr int kRecDepth = 16;
@@ -347,7 +361,21 @@ int run_forward(const Launch& L, const asurf_rays* rays, float* rgb_out, int M, 
         P.list = reinterpret_cast<unsigned*>(L.ws + L.ML.off_p_list);
         if (hipMemsetAsync(P.counters, 0, kCtrTotal * sizeof(int), L.stream) != hipSuccess)
             return fail(ASURF_E_LAUNCH, "hipMemsetAsync failed");
-        if (L.coarse_in_lds)
+        const int seg = walk_segments(Q);
+        if (seg > 1) {
+            const dim3 seg_grid((unsigned)((Q * seg + kBlock - 1) / kBlock));
+#define ASURF_WALK_SEG(S_)                                                                                   \
+    if (L.coarse_in_lds)                                                                                     \
+        hipLaunchKernelGGL((k_walk_seg<true, S_>), seg_grid, dim3(kBlock), L.dyn_lds, L.stream, L.g, L.o,    \
+                           rays->origins, rays->dirs, Q, P, record ? 1 : 0);                                 \
+    else                                                                                                     \
+        hipLaunchKernelGGL((k_walk_seg<false, S_>), seg_grid, dim3(kBlock), 0, L.stream, L.g, L.o,           \
+                           rays->origins, rays->dirs, Q, P, record ? 1 : 0)
+            if (seg == 2) { ASURF_WALK_SEG(2); }
+            else if (seg == 4) { ASURF_WALK_SEG(4); }
+            else { ASURF_WALK_SEG(8); }
+#undef ASURF_WALK_SEG
+        } else if (L.coarse_in_lds)
             hipLaunchKernelGGL((k_walk<true>), L.ray_grid, dim3(kBlock), L.dyn_lds, L.stream, L.g, L.o,
                                rays->origins, rays->dirs, Q, P, record ? 1 : 0);
         else

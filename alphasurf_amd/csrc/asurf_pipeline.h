@@ -6,6 +6,8 @@
 //            re-walks once and appends the rest to a contiguous slice of a global spill list, so
 //            rays of any length stay on this path.  The occupied (slot, ray) cells of the table are
 //            also appended to a dense list (slot-major within a wave).
+//            Batches that do not fill the chip several times over use k_walk_seg: S lanes per ray, each
+//            walking one t-segment (the walk is a serial chain; see the kernel).
 //   k_geom : one WORK VOXEL per lane, a fixed grid of kListBlocks blocks striding over the dense
 //            list (and, in a second launch, over the spill list): every lane is busy no matter how
 //            the work voxels are spread over rays, and no block is dispatched only to exit.
@@ -184,6 +186,200 @@ k_walk(KGrid g, KOpt o, const float* __restrict__ origins, const float* __restri
             if ((tid & 63) == 0) base0 = atomicAdd(&P.counters[kCtrList], wave_total);
             base0 = __shfl(base0, 0);
             const unsigned long long below = (1ull << (tid & 63)) - 1ull;
+            for (int j = 0; __any(nt > j); ++j) {
+                const unsigned long long m = __ballot(nt > j);
+                if (nt > j) P.list[base0 + __popcll(m & below)] = ((unsigned)j << kListRayBits) | (unsigned)q;
+                base0 += __popcll(m);
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// k_walk with the ray cut into S segments walked by S neighbouring lanes.  A ray's walk is a serial
+// chain of a few hundred dependent iterations and k_walk's duration is that of its longest chains, not
+// of its instruction count; S lanes shorten them S-fold.  Exactness: walk_hier's decisions depend on
+// (next voxel, ray) only, so a lane may start anywhere the sequential walk provably is: at a parameter A
+// whose position o + A d lies inside the vertex lattice and at least 1/256 voxel away from every voxel
+// plane (the margin the brick jumps use for the same question), the walk is in voxel floor(o + A d).
+// Lane s starts there, does not report that voxel (its entry precedes A: the previous lane owns it),
+// and stops before the first voxel entered at or after A(s+1).  Flagged voxels are kept in LDS and
+// placed once the counts of the lanes in front are known; a lane with more than kSegCap of them walks
+// its segment once more for the rest.  A ray that offers no landing point is walked by its lane 0.
+// ------------------------------------------------------------------------------------
+constexpr int kSegCap = 8;
+
+template <bool CLDS, int S>
+__global__ void __launch_bounds__(kBlock)
+k_walk_seg(KGrid g, KOpt o, const float* __restrict__ origins, const float* __restrict__ dirs,
+           long long Q, PipeBuf P, int want_cut) {
+    static_assert(S == 2 || S == 4 || S == 8, "segments per ray");
+    extern __shared__ unsigned int s_coarse[];
+    __shared__ int s_tmp[kBlock * kSegCap];
+    const int tid = threadIdx.x;
+    if constexpr (CLDS) {
+        for (int i = tid; i < g.coarse_words; i += kBlock) s_coarse[i] = g.coarse[i];
+        __syncthreads();
+    }
+    constexpr int R = 64 / S;  // rays per wave
+    const int lane = tid & 63;
+    const int seg = lane & (S - 1), ri = lane / S;
+    const long long q = ((long long)blockIdx.x * (kBlock / 64) + (tid >> 6)) * R + ri;
+    const bool valid = q < Q;
+    Ray r;
+    r.tmin = 1.f;
+    r.tmax = 0.f;
+    if (valid) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            r.o[k] = origins[3 * q + k];
+            r.d[k] = dirs[3 * q + k];
+        }
+        setup_ray(g, o, r);
+    }
+    const bool hits_grid = valid && !(r.tmin > r.tmax);
+    Walk w0;
+    walk_init(g, r, w0);
+    // ---- where my segment starts ----
+    float a_start = r.tmin;
+    int v0x = -1, v0y = -1, v0z = -1;
+    bool fail = false;
+    if (hits_grid && seg > 0) {
+        const float len = r.tmax - r.tmin;
+        const float kEps = 1.f / 256.f;
+        float t = r.tmin + len * ((float)seg * (1.f / S));
+        bool ok = false;
+#pragma unroll
+        for (int attempt = 0; attempt < 3; ++attempt) {
+            if (!ok) {
+                if (attempt > 0) t += 0.37f;
+                const float px = fmaf(t, w0.dx, w0.ox), py = fmaf(t, w0.dy, w0.oy), pz = fmaf(t, w0.dz, w0.oz);
+                const float fx = floorf(px), fy = floorf(py), fz = floorf(pz);
+                const bool in_x = px > kEps && px < (float)w0.lim0 - kEps && (px - fx) > kEps && (px - fx) < 1.f - kEps;
+                const bool in_y = py > kEps && py < (float)w0.lim1 - kEps && (py - fy) > kEps && (py - fy) < 1.f - kEps;
+                const bool in_z = pz > kEps && pz < (float)w0.lim2 - kEps && (pz - fz) > kEps && (pz - fz) < 1.f - kEps;
+                ok = in_x && in_y && in_z && (t + 1.f < r.tmax);
+                v0x = (int)fx;
+                v0y = (int)fy;
+                v0z = (int)fz;
+            }
+        }
+        fail = !ok || !(len > 16.f) || !w0.straight;
+        a_start = t;
+    }
+    // a ray none of whose inner boundaries failed is split; otherwise its lane 0 walks all of it.
+    // (boundaries must also be increasing: the retries move a start by at most 0.74 < len / S)
+    const unsigned long long failed = __ballot(fail);
+    const unsigned long long mine = ((1ull << S) - 1ull) << (ri * S);
+    const bool unsplit = (failed & mine) != 0ull;
+    float a_end = __shfl_down(a_start, 1);
+    if (seg == S - 1 || unsplit) a_end = 3.0e38f;
+    const bool walks = hits_grid && (seg == 0 || !unsplit);
+    const bool skip_first = walks && seg > 0;
+    const bool jump = !(o.debug & 8);
+
+    int c = 0;                    // flagged voxels of my segment
+    int cut_local = 0x7fffffff;   // my count at the backward-quirk event (surf_trav.cu:1935-1936)
+    int offset = 0, total = 0, base = 0;
+    bool spill_ok = true;
+    // pass 0: walk, keep the first kSegCap flagged voxels in LDS; pass 1 (lanes with more): walk again and
+    // write the rest to their final places
+    auto place = [&](int slot, int voxel) {
+        if (slot < P.C1) {
+            P.items[(size_t)slot * Q + q] = voxel;
+        } else if (spill_ok) {
+            P.sp_items[base + slot - P.C1] = voxel;
+            P.sp_ray[base + slot - P.C1] = (int)q;
+        }
+    };
+    auto walk_segment = [&](int pass, bool run) {
+        if (!run) return;
+        Walk w = w0;
+        if (skip_first) {
+            w.nx = v0x;
+            w.ny = v0y;
+            w.nz = v0z;
+            w.t = a_start;
+        }
+        bool active = true;
+        int k = 0;
+        int guard = 4 * (g.size[0] + g.size[1] + g.size[2]) + 64;
+        while (active && --guard > 0) {
+            const int kind = walk_hier<CLDS>(g, s_coarse, w, o.step_size, r.tmax, jump);
+            const bool in_ray = (w.t <= r.tmax);
+            active = in_ray && (w.t < a_end);
+            const bool own = !(skip_first && w.vx == v0x && w.vy == v0y && w.vz == v0z);
+            if (kind == 2 && own) {
+                const int voxel = pack_voxel(w.vx, w.vy, w.vz);
+                if (pass == 0) {
+                    if (k < kSegCap) s_tmp[tid * kSegCap + k] = voxel;
+                } else if (k >= kSegCap) {
+                    place(offset + k, voxel);
+                }
+                ++k;
+            } else if (pass == 0 && kind == 1 && own && want_cut && in_ray && (w.t + o.step_size > r.tmax) &&
+                       cut_local == 0x7fffffff) {
+                if (!links_present(g, w)) cut_local = k;
+            }
+        }
+        if (pass == 0) c = k;
+    };
+    walk_segment(0, walks);
+    // ---- counts of the lanes in front, spill slice of the ray ----
+    {
+        int incl = c;
+#pragma unroll
+        for (int d = 1; d < S; d <<= 1) {
+            const int tv = __shfl_up(incl, d);
+            if (seg >= d) incl += tv;
+        }
+        offset = incl - c;
+        total = __shfl(incl, ri * S + S - 1);
+    }
+    int cutv = (cut_local == 0x7fffffff) ? 0x7fffffff : offset + cut_local;
+#pragma unroll
+    for (int d = 1; d < S; d <<= 1) cutv = min(cutv, __shfl_xor(cutv, d));
+    int cnt = total;
+    const int extra = (seg == 0 && cnt > P.C1) ? cnt - P.C1 : 0;
+    int wave_extra;
+    const int pre = wave_excl_scan(extra, &wave_extra);
+    if (wave_extra > 0) {
+        int base0 = 0;
+        if (lane == 0) base0 = atomicAdd(&P.counters[1], wave_extra);
+        base0 = __shfl(base0, 0);
+        base = __shfl(base0 + pre, ri * S);
+        const int ray_extra = __shfl(extra, ri * S);
+        spill_ok = base + ray_extra <= P.sp_cap;
+        if (seg == 0 && extra > 0) {
+            if (spill_ok) {
+                P.sp_base[q] = base;
+            } else {  // spill list exhausted: the one-kernel path renders this ray
+                P.flagged[atomicAdd(&P.counters[0], 1)] = (int)q;
+                for (int e2 = base; e2 < min(base + extra, P.sp_cap); ++e2) P.sp_ray[e2] = -1;
+            }
+        }
+        if (!spill_ok && cnt > P.C1) cnt = -1;
+    }
+    // ---- place what LDS holds, then the overflow ----
+    {
+        const int nk = min(c, kSegCap);
+        for (int j = 0; j < nk; ++j) place(offset + j, s_tmp[tid * kSegCap + j]);
+    }
+    if (__any(c > kSegCap)) walk_segment(1, walks && c > kSegCap);
+    if (valid && seg == 0) {
+        P.n_items[q] = cnt;
+        P.cut[q] = cutv;
+    }
+    // dense list of this wave's table cells (as k_walk)
+    {
+        const int nt = (valid && seg == 0 && cnt > 0) ? min(cnt, P.C1) : 0;
+        int wave_total;
+        wave_excl_scan(nt, &wave_total);
+        if (wave_total > 0) {
+            int base0 = 0;
+            if (lane == 0) base0 = atomicAdd(&P.counters[kCtrList], wave_total);
+            base0 = __shfl(base0, 0);
+            const unsigned long long below = (1ull << lane) - 1ull;
             for (int j = 0; __any(nt > j); ++j) {
                 const unsigned long long m = __ballot(nt > j);
                 if (nt > j) P.list[base0 + __popcll(m & below)] = ((unsigned)j << kListRayBits) | (unsigned)q;

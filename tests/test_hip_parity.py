@@ -354,14 +354,21 @@ def test_brick_skipping_is_exact(hip, monkeypatch):
         crop = dict(sc, links=np.ascontiguousarray(sc["links"][: reso - 5, : reso - 19, : reso // 2 + 3]))
         for scene, extra in ((sc, {}), (crop, dict(near_clip=0.3)), (sc, dict(use_spheric_clip=True))):
             op = dict(opts, **extra)
-            monkeypatch.setenv("ASURF_DEBUG", "8")        # per-voxel walk only
+            monkeypatch.setenv("ASURF_DEBUG", "8")        # per-voxel walk only,
+            monkeypatch.setenv("ASURF_WALK_SEG", "1")     # one lane per ray
             rgb_ref, g_ref = hip.render_fused(scene, o, d, op, gt, fused)
             monkeypatch.delenv("ASURF_DEBUG")
-            rgb, g = hip.render_fused(scene, o, d, op, gt, fused)
-            assert np.array_equal(rgb, rgb_ref), f"reso {reso} {extra}: {np.abs(rgb - rgb_ref).max()}"
-            assert (g["mask"] == g_ref["mask"]).all()
-            for k in ("sh", "density", "surface"):
-                grad_close(g[k], g_ref[k], 1e-5, f"reso {reso} {extra} grad_{k}")
+            monkeypatch.delenv("ASURF_WALK_SEG")
+            # ... against the hierarchical walk with the ray on 1, 2, 4 and 8 lanes (k_walk_seg: every lane but
+            # the first enters its segment at a landing point in the middle of the ray)
+            for seg in ("1", "2", "4", "8"):
+                monkeypatch.setenv("ASURF_WALK_SEG", seg)
+                rgb, g = hip.render_fused(scene, o, d, op, gt, fused)
+                monkeypatch.delenv("ASURF_WALK_SEG")
+                assert np.array_equal(rgb, rgb_ref), f"reso {reso} {extra} seg {seg}: {np.abs(rgb - rgb_ref).max()}"
+                assert (g["mask"] == g_ref["mask"]).all()
+                for k in ("sh", "density", "surface"):
+                    grad_close(g[k], g_ref[k], 1e-5, f"reso {reso} {extra} seg {seg} grad_{k}")
 
 
 def test_random_option_fuzz(hip, oracle):
