@@ -132,6 +132,8 @@ struct Walk {
     float ox, oy, oz, dx, dy, dz, t_leave;
     int lim0, lim1, lim2;
     int noskip_key;      // brick whose jump attempt was refused (walk_hier)
+    float rdx, rdy, rdz; // correctly rounded reciprocals of the direction (walk_hier's quotients)
+    bool fast_div;       // ... usable: no component is zero, subnormal or so small that x * (1/d) overflows
     bool straight;       // no direction component is ~0 (brick jumps allowed)
     // register cache of the occupancy pyramid
     int cur_key;         // packed brick coordinates
@@ -144,6 +146,17 @@ struct Walk {
 __device__ __forceinline__ float plane_time(int n, int s, float o, float d) {
     // ((float)far_plane - origin) / dir with far_plane = n + (dir > 0)
     return ((float)(n + ((s + 1) >> 1)) - o) / d;
+}
+
+// x / d from the correctly rounded reciprocal rd = RN(1 / d): q0 = RN(x rd) is within an ulp of x / d, the
+// residual x - q0 d comes out of one FMA exactly, and RN(q0 + residual * rd) is the correctly rounded quotient
+// (Markstein's correction step; the IEEE sequence the compiler emits for `/` is ten instructions).  Checked
+// against IEEE division on 2e8 operand pairs of the walk's ranges and on all-ones / power-of-two mantissas.
+// Not for d = 0, subnormal d or quotients near overflow: Walk::fast_div.
+__device__ __forceinline__ float quotient(float x, float d, float rd) {
+    const float q0 = x * rd;
+    const float e = fmaf(-q0, d, x);
+    return fmaf(e, rd, q0);
 }
 
 __device__ __forceinline__ void walk_init(const KGrid& g, const Ray& r, Walk& w) {
@@ -172,6 +185,10 @@ __device__ __forceinline__ void walk_init(const KGrid& g, const Ray& r, Walk& w)
     w.cur_key = -1;
     w.noskip_key = -1;
     w.straight = fminf(fminf(fabsf(w.dx), fabsf(w.dy)), fabsf(w.dz)) > 1e-5f;
+    w.rdx = 1.f / w.dx;
+    w.rdy = 1.f / w.dy;
+    w.rdz = 1.f / w.dz;
+    w.fast_div = fmaxf(fmaxf(fabsf(w.rdx), fabsf(w.rdy)), fabsf(w.rdz)) < 1e30f;  // false for inf and NaN too
     w.cur_brick = 0;
     w.cur_flag = 0;
     w.cur_lx = -1;
@@ -281,9 +298,16 @@ __device__ __forceinline__ int walk_hier(const KGrid& g, const unsigned int* lds
     const int ex = (sx > 0) ? min(nx | cell_x, l0 - 1) : (nx & ~cell_x);
     const int ey = (sy > 0) ? min(ny | cell_yz, l1 - 1) : (ny & ~cell_yz);
     const int ez = (sz > 0) ? min(nz | cell_yz, l2 - 1) : (nz & ~cell_yz);
-    const float Tx = plane_time(ex, sx, ox, dx);
-    const float Ty = plane_time(ey, sy, oy, dy);
-    const float Tz = plane_time(ez, sz, oz, dz);
+    float Tx, Ty, Tz;  // == plane_time(e, s, o, d) per axis
+    if (w.fast_div) {
+        Tx = quotient((float)(ex + ((sx + 1) >> 1)) - ox, dx, w.rdx);
+        Ty = quotient((float)(ey + ((sy + 1) >> 1)) - oy, dy, w.rdy);
+        Tz = quotient((float)(ez + ((sz + 1) >> 1)) - oz, dz, w.rdz);
+    } else {
+        Tx = plane_time(ex, sx, ox, dx);
+        Ty = plane_time(ey, sy, oy, dy);
+        Tz = plane_time(ez, sz, oz, dz);
+    }
     const float T = fminf(fminf(Tx, Ty), Tz);
     const bool a0 = (T == Tx);
     const bool a1 = !a0 && (T == Ty);
@@ -295,18 +319,22 @@ __device__ __forceinline__ int walk_hier(const KGrid& g, const unsigned int* lds
         // t <= ~2000 and |d| <= 1 at grid sizes <= 1024: T, o + T d and the plane times each carry
         // < 2.5e-4 voxel of float error, 6e-4 together; 1/256 leaves a 6x margin
         const float kEps = 1.f / 256.f;
-        const bool far_x = a0 || ((px - fx) > kEps && (px - fx) < 1.f - kEps);
-        const bool far_y = a1 || ((py - fy) > kEps && (py - fy) < 1.f - kEps);
-        const bool far_z = a2 || ((pz - fz) > kEps && (pz - fz) < 1.f - kEps);
+        // kEps < frac < 1 - kEps as one comparison (|frac - 1/2| below 1/2 - kEps: 0.5 and kEps are exact binary
+        // fractions, and a frac that close to a plane fails either form)
+        const bool far_x = a0 || fabsf((px - fx) - 0.5f) < 0.5f - kEps;
+        const bool far_y = a1 || fabsf((py - fy) - 0.5f) < 0.5f - kEps;
+        const bool far_z = a2 || fabsf((pz - fz) - 0.5f) < 0.5f - kEps;
         cx = (int)fx;
         cy = (int)fy;
         cz = (int)fz;
         // the other axes must land inside the cell and not behind the current voxel: while the
         // ray is still approaching the grid (indices clamped by walk_init) its position is not
         // inside the voxel the state names
-        const bool rx = a0 || (((cx ^ nx) & ~cell_x) == 0 && (cx - nx) * sx >= 0);
-        const bool ry = a1 || (((cy ^ ny) & ~cell_yz) == 0 && (cy - ny) * sy >= 0);
-        const bool rz = a2 || (((cz ^ nz) & ~cell_yz) == 0 && (cz - nz) * sz >= 0);
+        // ((c - n) ^ m) >= m with m = s >> 31 is (c - n) * s >= 0 without the quarter-rate multiply
+        const int mx_ = sx >> 31, my_ = sy >> 31, mz_ = sz >> 31;
+        const bool rx = a0 || (((cx ^ nx) & ~cell_x) == 0 && ((cx - nx) ^ mx_) >= mx_);
+        const bool ry = a1 || (((cy ^ ny) & ~cell_yz) == 0 && ((cy - ny) ^ my_) >= my_);
+        const bool rz = a2 || (((cz ^ nz) & ~cell_yz) == 0 && ((cz - nz) ^ mz_) >= mz_);
         const bool ok = far_x && far_y && far_z && rx && ry && rz && (T <= tmax) && !(T + step_size > tmax);
         if (!ok) {  // walk this brick voxel by voxel
             w.noskip_key = key;
