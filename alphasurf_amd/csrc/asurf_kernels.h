@@ -47,9 +47,14 @@ k_build_masks(KGrid g, float sigma_thresh, int need_surf, unsigned long long* fi
         if (bz >= g.nb[2]) break;
         const int x = bx * 8 + lx, y = by * 8 + ly, z = bz * 8 + lz;
         bool live = false, work = false;
-        if (x + 1 < g.size[0] && y + 1 < g.size[1] && z + 1 < g.size[2]) {
-            const int32_t* p = g.links + ((size_t)x * g.offx + (size_t)y * g.offy + z);
-            const int32_t l0 = p[0], l1 = p[1], l2 = p[g.offy], l3 = p[g.offy + 1];
+        const bool inside = x + 1 < g.size[0] && y + 1 < g.size[1] && z + 1 < g.size[2];
+        const int32_t* p = g.links + ((size_t)x * g.offx + (size_t)y * g.offy + z);
+        const int32_t l0 = inside ? p[0] : -1;
+        // most of a sparse grid is empty space: when no cell of the slab has its own vertex (and the surf_trav
+        // planes need all eight), the other seven loads are skipped for the whole wave
+        const bool slab_dead = need_surf != 2 && __ballot(l0 >= 0) == 0ull;
+        if (inside && !slab_dead) {
+            const int32_t l1 = p[1], l2 = p[g.offy], l3 = p[g.offy + 1];
             const int32_t l4 = p[g.offx], l5 = p[g.offx + 1], l6 = p[g.offx + g.offy],
                           l7 = p[g.offx + g.offy + 1];
             if (need_surf == 2) {
