@@ -107,6 +107,44 @@ def all_reduce_sparse(tensors, mask, group=None):
         mask.view(-1)[ids] = True
 
 
+class GradArena:
+    """The gradient buffers of one replica as views of ONE flat float32 allocation -- grad_sh [n, D] |
+    grad_density [n, 1] | grad_surface [n, 1] | touched [n] | grad_fake_sample_std [1, 1] -- so that the dense
+    exchange is a single ring all-reduce (and clearing them a single fill) instead of five collectives: over
+    xGMI a ring all-reduce pays its latency per call, and the two [n, 1] planes and the mask are small next to
+    it.  The kernels write `mask` (bool); `all_reduce` carries it through the `touched` plane."""
+
+    ALIGN = 64  # floats: every view starts on a 256-byte boundary
+
+    def __init__(self, n_rows, sh_dim, device):
+        def up(x):
+            return (x + self.ALIGN - 1) // self.ALIGN * self.ALIGN
+        sizes = [n_rows * sh_dim, n_rows, n_rows, n_rows, 1]
+        offs, total = [], 0
+        for sz in sizes:
+            offs.append(total)
+            total += up(sz)
+        self.flat = torch.zeros(total, dtype=torch.float32, device=device)
+        self.grad_sh = self.flat[offs[0]:offs[0] + sizes[0]].view(n_rows, sh_dim)
+        self.grad_density = self.flat[offs[1]:offs[1] + sizes[1]].view(n_rows, 1)
+        self.grad_surface = self.flat[offs[2]:offs[2] + sizes[2]].view(n_rows, 1)
+        self.touched = self.flat[offs[3]:offs[3] + sizes[3]]
+        self.grad_fake_sample_std = self.flat[offs[4]:offs[4] + 1].view(1, 1)
+        self.mask = torch.zeros(n_rows, dtype=torch.bool, device=device)
+
+    def zero_(self):
+        self.flat.zero_()
+        self.mask.zero_()
+
+    def all_reduce(self, group=None):
+        """Sum over the ranks in place; `mask` becomes the union of the ranks' masks."""
+        if _world(group) == 1:
+            return
+        self.touched.copy_(self.mask)
+        _reduce(self.flat, dist.ReduceOp.SUM, group)
+        torch.gt(self.touched, 0, out=self.mask)
+
+
 def all_reduce_grads(grad_sh, grad_density, grad_surface, mask, grad_fake_sample_std=None,
                      group=None, dense_threshold=0.125, mode="auto"):
     """Sum the sparse gradient buffers of a fused render across ranks.

@@ -128,22 +128,21 @@ def main():
     gt = torch.from_numpy(gt_np).to(dev)
     rgb = torch.zeros_like(gt)
     gr = _C.GridOutputGrads()
-    gr.grad_density_out = torch.zeros_like(g.density_data)
-    gr.grad_sh_out = torch.zeros_like(g.sh_data)
-    gr.grad_surface_out = torch.zeros_like(g.surface_data)
-    gr.mask_out = torch.zeros(g.density_data.shape[0], dtype=torch.bool, device=dev)
+    # one flat allocation: with more than one rank the dense exchange is a single all-reduce over it
+    arena = adist.GradArena(g.density_data.shape[0], g.sh_data.shape[1], dev)
+    gr.grad_density_out, gr.grad_sh_out, gr.grad_surface_out = arena.grad_density, arena.grad_sh, arena.grad_surface
+    gr.mask_out = arena.mask
     F = synth.SYN_FUSED
     M = F["l_dist_max_sample"]
     Q_global = Q * world
 
     def step(counters=None, exchange=True):
-        gr.mask_out.zero_()  # the reference allocates a fresh sparse_grad_indexer per call (svox2.py:3535)
         if world > 1:
             # the exchange sums whatever the buffers hold, so they must hold this step only
             # (in training the optimizer kernels zero them, optim_kernel.cu:24)
-            gr.grad_sh_out.zero_()
-            gr.grad_density_out.zero_()
-            gr.grad_surface_out.zero_()
+            arena.zero_()
+        else:
+            gr.mask_out.zero_()  # the reference allocates a fresh sparse_grad_indexer per call (svox2.py:3535)
         _C.volume_render_surf_trav_fused(
             g, r, opt, gt, 0.0, 0.0, 0.0, True, False, F["lambda_l2"], F["lambda_l1"], 0.0,
             F["lambda_l_entropy"], False, 0.0, 0.0, 0.0, 0.0, F["l_di_alpha_thresh"],
@@ -153,8 +152,11 @@ def main():
             # data-parallel exchange: sum of per-shard gradients == gradient of the global batch.
             # A view touches ~20 % of the rows here, so the dense ring all-reduce is chosen
             # (alphasurf_amd/dist.py switches to the sparse all-to-all below 1/8).
-            adist.all_reduce_grads(gr.grad_sh_out, gr.grad_density_out, gr.grad_surface_out, gr.mask_out,
-                                   mode=args.exchange)
+            if args.exchange == "dense":
+                arena.all_reduce()
+            else:
+                adist.all_reduce_grads(gr.grad_sh_out, gr.grad_density_out, gr.grad_surface_out, gr.mask_out,
+                                       mode=args.exchange)
 
     def barrier():
         if world > 1:
