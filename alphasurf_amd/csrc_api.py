@@ -916,6 +916,25 @@ def volume_render_sigma_thresh(grid, rays, opt, sigma_thresh):
     return _cuvol_eval(grid, rays, opt, 3, sigma_thresh)
 
 
+def ray_order(origins, dirs):
+    """int32[Q] permutation that makes a shuffled batch coherent (an extension: asurf_ray_order).  Rays of
+    equal origin (one camera) become contiguous, ordered along a Morton curve of the direction."""
+    _check_input(origins, "origins", torch.float32)
+    _check_input(dirs, "dirs", torch.float32)
+    if origins.dim() != 2 or origins.shape[1] != 3 or dirs.shape != origins.shape:
+        raise RuntimeError("origins / dirs must be [Q, 3]")
+    dev = origins.device
+    q = origins.shape[0]
+    with torch.cuda.device(dev):
+        perm = torch.empty(q, dtype=torch.int32, device=dev)
+        nb = int(_L.lib().asurf_ray_order_tmp_bytes(q))
+        tmp = torch.empty(max(nb, 1), dtype=torch.uint8, device=dev)
+        rc = _L.lib().asurf_ray_order(_ptr(origins), _ptr(dirs), q, _ptr(perm), _ptr(tmp), nb, _stream(dev))
+        if rc != 0:
+            raise RuntimeError(f"asurf_ray_order failed ({rc})")
+    return perm
+
+
 def _out_of_scope(name, row):
     def fn(*args, **kwargs):
         raise NotImplementedError(f"{name} is outside the hot-path scope (SURVEY.md section 8f, {row})")

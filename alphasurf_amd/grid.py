@@ -499,10 +499,23 @@ class SparseGrid(nn.Module):
                             l_di_alpha_thresh: float = 0.0, surf_sparse_alpha_thresh: float = 0.0,
                             lambda_inplace_surf_sparse: float = 0.0, lambda_inwards_norm_loss: float = 0.0,
                             lambda_conv_mode_samp: float = 0.0, l_dist_max_sample: int = 64,
-                            no_surface: bool = False, global_n_rays: int = 0):
+                            no_surface: bool = False, global_n_rays: int = 0, coherent_order: bool = False):
         """Render + fused loss gradients accumulated into the parameters' .grad (:3477-3638).
-        `global_n_rays` (extension) = ray count of the whole data-parallel batch."""
+        `global_n_rays` (extension) = ray count of the whole data-parallel batch; `coherent_order` (extension)
+        renders a shuffled batch in the order of _C.ray_order and returns the colours in the caller's order."""
         assert self.sh_data.is_cuda and rays.is_cuda, "the HIP extension is required for fused"
+        perm = None
+        if coherent_order and rays.origins.shape[0] > 1:
+            perm = _C.ray_order(rays.origins.contiguous(), rays.dirs.contiguous()).long()
+            rays = Rays(rays.origins[perm].contiguous(), rays.dirs[perm].contiguous())
+            rgb_gt = rgb_gt[perm].contiguous()
+
+        def finish(rgb_sorted):
+            if perm is None:
+                return {"rgb": rgb_sorted}
+            rgb = torch.empty_like(rgb_sorted)
+            rgb[perm] = rgb_sorted
+            return {"rgb": rgb}
         backend = self._check_backend(no_surface)
         grad = self._get_data_grads()
         rgb_out = torch.zeros_like(rgb_gt)
@@ -518,14 +531,14 @@ class SparseGrid(nn.Module):
             _C.volume_render_cuvol_fused(self._to_cpp(), rays._to_cpp(), self.opt._to_cpp(randomize=randomize),
                                          rgb_gt, beta_loss, sparsity_loss, rgb_out, holder)
             self.sparse_sh_grad_indexer = self.sparse_grad_indexer.clone()
-            return {"rgb": rgb_out}
+            return finish(rgb_out)
         if backend == "surface":  # :3560-3597
             ray_vox = self.ray_voxel_lists(rays)
             _C.volume_render_surface_fused(
                 self._to_cpp(), rays._to_cpp(), ray_vox._to_cpp(), self.opt._to_cpp(randomize=randomize),
                 rgb_gt, beta_loss, sparsity_loss, rgb_out, holder)
             self.sparse_sh_grad_indexer = self.sparse_grad_indexer.clone()
-            return {"rgb": rgb_out}
+            return finish(rgb_out)
         if "fake_sample_std" in grad:
             holder.grad_fake_sample_std_out = grad["fake_sample_std"]
         _C.volume_render_surf_trav_fused(
@@ -537,7 +550,7 @@ class SparseGrid(nn.Module):
             lambda_inwards_norm_loss, lambda_conv_mode_samp, l_dist_max_sample, rgb_out, holder,
             global_n_rays=global_n_rays)
         self.sparse_sh_grad_indexer = self.sparse_grad_indexer.clone()
-        return {"rgb": rgb_out}
+        return finish(rgb_out)
 
     def volume_render_image(self, camera: Camera, use_kernel: bool = True, randomize: bool = False,
                             batch_size: int = 5000, return_raylen: bool = False, debug_pixels=None,

@@ -34,6 +34,8 @@ def parse():
     ap.add_argument("--width", type=int, default=800)
     ap.add_argument("--band", type=float, default=3.0, help="half-thickness (voxels) of the active shell")
     ap.add_argument("--shuffle", action="store_true", help="training-order (shuffled) rays")
+    ap.add_argument("--sort", action="store_true",
+                    help="order the batch for coherence inside the timed step (asurf_ray_order), scatter rgb back")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-rays", type=int, default=40000)
     ap.add_argument("--exchange", default="dense", choices=["dense", "sparse", "auto"],
@@ -136,7 +138,23 @@ def main():
     M = F["l_dist_max_sample"]
     Q_global = Q * world
 
+    r_in, gt_in, rgb_user = r, gt, rgb
+    if args.sort:
+        r = _C.RaysSpec()
+        r.masks = r_in.masks
+        rgb_user = torch.empty_like(rgb)
+
     def step(counters=None, exchange=True):
+        nonlocal gt
+        if args.sort:  # order, gather, render, scatter back: all inside the timed step
+            perm = _C.ray_order(r_in.origins, r_in.dirs).long()
+            r.origins, r.dirs = r_in.origins[perm], r_in.dirs[perm]
+            gt = gt_in[perm]
+        _step(counters, exchange)
+        if args.sort:
+            rgb_user[perm] = rgb
+
+    def _step(counters=None, exchange=True):
         if world > 1:
             # the exchange sums whatever the buffers hold, so they must hold this step only
             # (in training the optimizer kernels zero them, optim_kernel.cu:24)
@@ -266,7 +284,8 @@ def main():
             "config": {"workload": f"{R}^3 sparse SDF grid ({g.density_data.shape[0]} active voxels, union of 16 "
                                    f"spheres), SH deg {int(round(B ** 0.5)) - 1} (basis_dim {B}), "
                                    f"{args.width}x{args.width} pinhole view per GPU "
-                                   f"({'shuffled' if args.shuffle else 'image-order'} rays), "
+                                   f"({'shuffled' if args.shuffle else 'image-order'} rays"
+                                   f"{', ordered per step' if args.sort else ''}), "
                                    "volume_render_surf_trav_fused fwd+bwd, surface_cuda_syn.yaml options",
                        "rays_per_step_per_gpu": Q, "active_voxels": int(g.density_data.shape[0]),
                        "avg_per_ray": {"V_t": round(v_t / Q, 2), "V_a": round(v_a / Q, 2), "S": round(s_cnt / Q, 3)},

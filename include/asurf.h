@@ -362,6 +362,14 @@ int asurf_sparse_grid_weight_render(const int32_t* links, const float* density_d
                                     float stop_thresh, const float offset[3], const float scaling[3],
                                     float* grid_weight_out, void* stream);
 
+/* Ray ordering for coherence (new; the reference renders a batch in the order it is given).  Writes a
+ * permutation perm_out[n_rays] (int32) that groups rays of equal origin and orders each group along a
+ * Morton curve of the unit direction: gather the rays (and rgb_gt) with it, render, scatter rgb_out back.
+ * tmp: asurf_ray_order_tmp_bytes(n_rays) bytes of device scratch. */
+size_t asurf_ray_order_tmp_bytes(int64_t n_rays);
+int asurf_ray_order(const float* origins, const float* dirs, int64_t n_rays, int32_t* perm_out, void* tmp,
+                    size_t tmp_bytes, void* stream);
+
 /* Trilinear sampling of an [n_rows, n_cols] parameter plane at `points` float[n_points,3]
  * (sample_grid / sample_grid_sh_surf / sample_grid_raw_alpha, svox2_kernel.cu:11-150, 384-489):
  * p * scaling + offset, clamped to the grid, an empty corner reads as `empty_value`; out is

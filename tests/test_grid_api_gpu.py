@@ -218,3 +218,41 @@ def test_training_iteration_through_the_mirror(env):
         grid.optim_fake_sample_std_step(1e-3, beta=0.95, optim="rmsprop")
         assert float(grid.sh_data.grad.abs().max()) == 0.0  # the step zeroes what it consumed
     assert losses[-1] < losses[0], losses
+
+
+def test_coherent_order_is_transparent(env):
+    """`coherent_order=True` renders a shuffled batch in the order of asurf_ray_order and hands the colours back in
+    the caller's order: the same picture (a ray may take the table path in one order and the one-kernel path in
+    the other: float rounding), the same gradients up to summation order."""
+    torch, svox2 = env
+    from alphasurf_amd import csrc_api as _C
+    grid = make_grid(torch, svox2, 32, 4, seed=3)
+    rs = np.random.RandomState(5)
+    eyes = rs.randn(6, 3)
+    eyes = 3.0 * eyes / np.linalg.norm(eyes, axis=1, keepdims=True)
+    o = np.repeat(eyes, 700, axis=0).astype(np.float32)
+    d = (-o + rs.randn(*o.shape) * 0.4).astype(np.float32)
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    p = rs.permutation(o.shape[0])
+    rays = svox2.Rays(torch.from_numpy(o[p]).cuda(), torch.from_numpy(d[p]).cuda())
+    gt = torch.rand(o.shape[0], 3, device="cuda")
+    grid.requires_grad_(True)
+    outs, grads = [], []
+    for flag in (False, True):
+        for prm in (grid.density_data, grid.surface_data, grid.sh_data):
+            prm.grad = None
+        outs.append(grid.volume_render_fused(rays, gt, lambda_l2=1.0, lambda_l_entropy=1e-4, coherent_order=flag)["rgb"])
+        grads.append([prm.grad.clone() for prm in (grid.density_data, grid.surface_data, grid.sh_data)])
+    assert torch.allclose(outs[0], outs[1], rtol=0, atol=2e-6)
+    for a, b in zip(*grads):
+        assert torch.allclose(a, b, rtol=1e-4, atol=1e-5 * float(a.abs().max()) + 1e-12)
+    perm = _C.ray_order(rays.origins, rays.dirs).long()
+    assert sorted(perm.tolist()) == list(range(o.shape[0]))
+    cam = torch.from_numpy(np.repeat(np.arange(6), 700)[p]).cuda()[perm]
+    assert int((cam[1:] != cam[:-1]).sum()) == 5                     # rays of one camera end up contiguous
+    dd = rays.dirs[perm]
+    same = cam[1:] == cam[:-1]
+    step_sorted = (dd[1:] - dd[:-1]).norm(dim=1)[same].mean()
+    step_given = (rays.dirs[1:] - rays.dirs[:-1]).norm(dim=1).mean()
+    assert float(step_sorted) < 0.2 * float(step_given)              # neighbours in the order are neighbours in direction
+    assert _C.ray_order(rays.origins[:0], rays.dirs[:0]).numel() == 0
