@@ -627,6 +627,17 @@ int cuvol_eval(const Launch& L, const asurf_rays* rays, float param, int max_sam
     return launch_error("k_cuvol_eval");
 }
 
+// test hook: walk_hier's quotient() next to IEEE division, element by element
+__global__ void __launch_bounds__(256)
+k_test_quotient(const float* __restrict__ x, const float* __restrict__ d, long long n, float* __restrict__ fast,
+                float* __restrict__ ieee) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float rd = 1.f / d[i];
+    fast[i] = quotient(x[i], d[i], rd);
+    ieee[i] = x[i] / d[i];
+}
+
 }  // namespace
 
 extern "C" {
@@ -1270,6 +1281,14 @@ int asurf_render_eval_cuvol(const asurf_grid* grid, const asurf_rays* rays, cons
         case 2: return cuvol_eval<2>(L, rays, param, max_sample, out0, out1);
         default: return cuvol_eval<3>(L, rays, param, max_sample, out0, out1);
     }
+}
+
+int asurf_test_quotient(const float* x, const float* d, int64_t n, float* fast_out, float* ieee_out, void* stream) {
+    if (n < 0 || (n > 0 && (!x || !d || !fast_out || !ieee_out))) return fail(ASURF_E_INVALID, "test_quotient: bad arguments");
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(k_test_quotient, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       x, d, (long long)n, fast_out, ieee_out);
+    return launch_error("k_test_quotient");
 }
 
 }  // extern "C"

@@ -99,7 +99,7 @@ EXPORTS = [
     "asurf_sample_plane", "asurf_sample_plane_backward",
     "asurf_volume_render_cuvol", "asurf_volume_render_cuvol_backward", "asurf_volume_render_cuvol_fused",
     "asurf_grid_weight_render", "asurf_sparse_grid_weight_render", "asurf_render_eval_cuvol",
-    "asurf_ray_order_tmp_bytes", "asurf_ray_order",
+    "asurf_ray_order_tmp_bytes", "asurf_ray_order", "asurf_test_quotient",
 ]
 
 _lib = None
@@ -161,6 +161,7 @@ def lib():
         L.asurf_ray_order_tmp_bytes.argtypes = [C.c_int64]
         L.asurf_ray_order_tmp_bytes.restype = C.c_size_t
         L.asurf_ray_order.argtypes = [vp, vp, C.c_int64, vp, vp, C.c_size_t, vp]
+        L.asurf_test_quotient.argtypes = [vp, vp, C.c_int64, vp, vp, vp]
         if L.asurf_abi_version() != 1:
             raise RuntimeError("libasurf_hip.so ABI version mismatch")
         _lib = L

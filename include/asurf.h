@@ -362,6 +362,11 @@ int asurf_sparse_grid_weight_render(const int32_t* links, const float* density_d
                                     float stop_thresh, const float offset[3], const float scaling[3],
                                     float* grid_weight_out, void* stream);
 
+/* Test hook: the walk's exit-plane quotient x / d formed from RN(1/d) (asurf_kernels.h `quotient`) and the
+ * IEEE division, element by element, for a bitwise comparison on the device. */
+int asurf_test_quotient(const float* x, const float* d, int64_t n, float* fast_out, float* ieee_out,
+                        void* stream);
+
 /* Ray ordering for coherence (new; the reference renders a batch in the order it is given).  Writes a
  * permutation perm_out[n_rays] (int32) that groups rays of equal origin and orders each group along a
  * Morton curve of the unit direction: gather the rays (and rgb_gt) with it, render, scatter rgb_out back.
