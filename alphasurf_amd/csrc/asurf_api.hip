@@ -754,9 +754,25 @@ static int optim_launch(bool rms_mode, float* data, float* rms, float* grad, int
     if (mode == 2 && n_indices == 0) return 0;  // empty index list: nothing to do
     const long long total = (mode == 2 ? n_indices : n_rows) * (long long)n_cols;
     if (total == 0) return 0;
+    auto* idx = reinterpret_cast<const long long*>(indices);
+    if (n_cols <= 64) {  // a row per power-of-two lane group: no division, masked-out rows cost one byte
+        int cp_shift = 0;
+        while ((1 << cp_shift) < n_cols) ++cp_shift;
+        const long long lanes = (mode == 2 ? n_indices : n_rows) << cp_shift;
+        long long blocks = (lanes + 255) / 256;
+        if (blocks > 256 * 32) blocks = 256 * 32;
+        if (rms_mode)
+            hipLaunchKernelGGL((k_optim_rows<true>), dim3((unsigned)blocks), dim3(256), 0,
+                               static_cast<hipStream_t>(stream), data, rms, grad, (long long)n_rows, n_cols, cp_shift,
+                               mode, mask, idx, (long long)n_indices, beta, lr, epsilon, minval, lr_last);
+        else
+            hipLaunchKernelGGL((k_optim_rows<false>), dim3((unsigned)blocks), dim3(256), 0,
+                               static_cast<hipStream_t>(stream), data, rms, grad, (long long)n_rows, n_cols, cp_shift,
+                               mode, mask, idx, (long long)n_indices, beta, lr, epsilon, minval, lr_last);
+        return launch_error("k_optim_rows");
+    }
     long long blocks = (total + 255) / 256;
     if (blocks > 256 * 16) blocks = 256 * 16;  // grid-stride beyond 16 blocks per CU
-    auto* idx = reinterpret_cast<const long long*>(indices);
     if (rms_mode)
         hipLaunchKernelGGL((k_optim_step<true>), dim3((unsigned)blocks), dim3(256), 0,
                            static_cast<hipStream_t>(stream), data, rms, grad, (long long)n_rows, n_cols,
