@@ -972,7 +972,7 @@ class SparseGrid(nn.Module):
                                   contiguous: bool = True):
         """:6354-6376: the same over the cells whose first corner exists."""
         grid_size = self.links.numel()
-        non_empty_ids = torch.where(self.links.view(-1) >= 0)[0].int()
+        non_empty_ids = self._non_empty_ids()
         if sparse_frac >= 1.0:
             return non_empty_ids
         non_empty_num = len(non_empty_ids)
@@ -985,6 +985,22 @@ class SparseGrid(nn.Module):
             return non_empty_ids[start:start + sparse_num].contiguous()
         return non_empty_ids[torch.randint(0, non_empty_num, (sparse_num,), dtype=torch.long,
                                            device=self.links.device)]
+
+    def _non_empty_ids(self):
+        """Flat ids of the cells whose first corner exists.  The reference recomputes this list in each of the
+        four regulariser calls of an iteration (a compare and a compaction over the whole link volume: 0.1 ms
+        each at 256^3); here it is kept until `links` is reassigned (__setattr__) or modified in place (_version)."""
+        key = (self.links._version, tuple(self.links.shape))
+        cached = self.__dict__.get("_non_empty_cache")
+        if cached is None or cached[0] != key:
+            cached = (key, torch.where(self.links.view(-1) >= 0)[0].int())
+            self.__dict__["_non_empty_cache"] = cached
+        return cached[1]
+
+    def __setattr__(self, name, value):
+        if name == "links":
+            self.__dict__["_non_empty_cache"] = None
+        super().__setattr__(name, value)
 
     def _get_data_to_links(self):
         """:6378-6382"""
@@ -1116,9 +1132,19 @@ class SparseGrid(nn.Module):
         indexer = self.sparse_sh_grad_indexer if sh else self.sparse_grad_indexer
         if indexer is None:
             return torch.empty((), device=self.density_data.device)
-        if indexer.dtype == torch.bool and torch.count_nonzero(indexer).item() < indexer.size(0) // 8:
-            indexer = torch.nonzero(indexer.flatten(), as_tuple=False).flatten()
-        return indexer
+        if indexer.dtype != torch.bool:
+            return indexer
+        # the count is a device -> host round trip; the density and the surface step of an iteration ask about the
+        # same mask, so the answer is kept while the mask is untouched
+        key = (indexer.data_ptr(), indexer._version)
+        cached = self.__dict__.get("_indexer_cache_sh" if sh else "_indexer_cache")
+        if cached is not None and cached[0] == key and cached[1] is indexer:
+            return cached[2]
+        out = indexer
+        if torch.count_nonzero(indexer).item() < indexer.size(0) // 8:
+            out = torch.nonzero(indexer.flatten(), as_tuple=False).flatten()
+        self.__dict__["_indexer_cache_sh" if sh else "_indexer_cache"] = (key, indexer, out)
+        return out
 
     def _optim_step(self, name, rms_name, indexer, lr, beta, epsilon, optim):
         p = getattr(self, name)

@@ -1,0 +1,72 @@
+"""One training iteration of opt.py with surface_cuda_syn.yaml's terms on the bench scene, through the SparseGrid
+mirror (Python overhead included): fused render of one 800x800 view (or --rays N shuffled rays), surface TV,
+normal loss, eikonal loss, alpha sparsify, the optimizer steps.  ms per iteration and rays/s."""
+import argparse, json, os, sys
+import numpy as np, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import svox2
+from alphasurf_amd import synth
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--rays", type=int, default=0, help="0: the whole 800x800 view in image order; N: N shuffled rays of it")
+ap.add_argument("--iters", type=int, default=30)
+args = ap.parse_args()
+dev = torch.device("cuda:0")
+sc = synth.make_sparse_scene(256, 9, trunc_a=5.0, **synth.BENCH_SCENE)
+grid = svox2.SparseGrid(reso=8, basis_dim=9, device=dev, surface_type=svox2.SURFACE_TYPE_SDF, surface_init="sphere")
+n = sc["density"].shape[0]
+import torch.nn as nn
+grid.links = torch.from_numpy(sc["links"]).to(dev)
+grid.density_data = nn.Parameter(torch.from_numpy(sc["density"]).to(dev))
+grid.surface_data = nn.Parameter(torch.from_numpy(sc["surface"]).to(dev))
+grid.sh_data = nn.Parameter(torch.from_numpy(sc["sh"]).to(dev))
+grid.level_set_data = torch.from_numpy(sc["level_set"]).to(dev)
+grid.capacity = n
+grid.truncated_vol_render_a = 5.0
+grid.opt.backend = "surf_trav"
+for k, v in synth.SYN_OPTS.items():
+    setattr(grid.opt, k, v)
+grid.density_rms = grid.sh_rms = grid.surface_rms = None
+grid._data_to_links = None
+o, d = synth.pinhole_rays(synth.orbit_camera(0), 800, 800)
+if args.rays:
+    idx = np.random.RandomState(0).permutation(o.shape[0])[: args.rays]
+    o, d = o[idx], d[idx]
+rays = svox2.Rays(torch.from_numpy(o).to(dev), torch.from_numpy(d).to(dev))
+gt = torch.rand(o.shape[0], 3, device=dev)
+grid.requires_grad_(True)
+F = synth.SYN_FUSED
+
+
+def iteration():
+    grid.volume_render_fused(rays, gt, lambda_l2=F["lambda_l2"], lambda_l1=F["lambda_l1"],
+                             lambda_l_entropy=F["lambda_l_entropy"], lambda_conv_mode_samp=F["lambda_conv_mode_samp"],
+                             l_dist_max_sample=F["l_dist_max_sample"], l_di_alpha_thresh=F["l_di_alpha_thresh"],
+                             surf_sparse_alpha_thresh=F["surf_sparse_alpha_thresh"])
+    grid.inplace_tv_surface_grad(grid.surface_data.grad, scaling=1e-3, sparse_frac=1, ignore_edge=True,
+                                 edge_value=-1.0, alpha_dependency=True)
+    grid.inplace_surface_normal_grad(grid.surface_data.grad, scaling=1e-6, sparse_frac=1, connectivity_check=True,
+                                     ignore_empty=False, use_l1=True)
+    grid.inplace_surface_eikonal_grad(grid.surface_data.grad, scaling=1e-4, sparse_frac=1, use_kernel=False)
+    grid.inplace_alpha_surf_sparsify_grad(grid.density_data.grad, grid.surface_data.grad, scaling_alpha=1e-9,
+                                          scaling_surf=0.0, sparse_frac=0.1)
+    grid.optim_density_step(1e-1, beta=0.95, optim="rmsprop")
+    grid.optim_surface_step(1e-5, beta=0.95, optim="rmsprop")
+    grid.optim_sh_step(1e-2, beta=0.95, optim="rmsprop")
+
+
+for _ in range(5):
+    iteration()
+torch.cuda.synchronize()
+a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+import time
+t0 = time.perf_counter()
+a.record()
+for _ in range(args.iters):
+    iteration()
+b.record()
+torch.cuda.synchronize()
+wall = (time.perf_counter() - t0) / args.iters * 1e3
+ms = a.elapsed_time(b) / args.iters
+print(json.dumps(dict(rays=o.shape[0], ms_per_iteration=round(ms, 3), wall_ms_per_iteration=round(wall, 3),
+                      iterations_per_s=round(1e3 / wall, 1), Mrays_per_s=round(o.shape[0] / wall / 1e3, 2))))
