@@ -560,24 +560,42 @@ k_comp(KGrid g, KOpt o, const float* __restrict__ dirs, long long Q, PipeBuf P,
 
     // the per-voxel candidate words of four consecutive slots are fetched together (independent
     // loads): the loop is otherwise one dependent memory round trip per slot
-    int ci4[4] = {0, 0, 0, 0};
+    int ci4[4] = {0, 0, 0, 0}, pv4[4] = {0, 0, 0, 0};
     for (int s = 0; __any(s < n_left); ++s) {
         const bool have = s < n_left;
         if ((s & 3) == 0) {
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const int su = s + u;
-                ci4[u] = 0;
-                if (su < n_left) ci4[u] = (su < P.C1) ? P.citem[(size_t)su * Q + q] : P.sp_citem[spb + su - P.C1];
+                ci4[u] = pv4[u] = 0;
+                if (su < n_left) {
+                    ci4[u] = (su < P.C1) ? P.citem[(size_t)su * Q + q] : P.sp_citem[spb + su - P.C1];
+                    pv4[u] = (su < P.C1) ? P.items[(size_t)su * Q + q] : P.sp_items[spb + su - P.C1];
+                }
             }
         }
         const int sel = s & 3;
         int ci = sel == 0 ? ci4[0] : sel == 1 ? ci4[1] : sel == 2 ? ci4[2] : ci4[3];
+        const int pv = sel == 0 ? pv4[0] : sel == 1 ? pv4[1] : sel == 2 ? pv4[2] : pv4[3];
         if (!have) ci = 0;
         const int nc = ci & 3;
         if (!__any(nc > 0)) continue;
         const int base = ci >> 2;
-        int pv = 0;
+        // the voxel's links are asked for together with its first candidate record (both addresses are known
+        // here), not after the record has arrived and passed the gates: one memory round trip less per sample
+        int lk8[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (nc > 0) {
+            const int vx = pv >> 20, vy = (pv >> 10) & 1023, vz = pv & 1023;
+            const int32_t* p = g.links + ((size_t)vx * g.offx + (size_t)vy * g.offy + vz);
+            lk8[0] = p[0];
+            lk8[1] = p[1];
+            lk8[2] = p[g.offy];
+            lk8[3] = p[g.offy + 1];
+            lk8[4] = p[g.offx];
+            lk8[5] = p[g.offx + 1];
+            lk8[6] = p[g.offx + g.offy];
+            lk8[7] = p[g.offx + g.offy + 1];
+        }
         bool links_loaded = false;
         bool composited = false;
 #pragma unroll
@@ -611,17 +629,8 @@ k_comp(KGrid g, KOpt o, const float* __restrict__ dirs, long long Q, PipeBuf P,
                 shade = true;
             }
             if (shade && !links_loaded) {
-                pv = (s < P.C1) ? P.items[(size_t)s * Q + q] : P.sp_items[spb + s - P.C1];
-                const int vx = pv >> 20, vy = (pv >> 10) & 1023, vz = pv & 1023;
-                const int32_t* p = g.links + ((size_t)vx * g.offx + (size_t)vy * g.offy + vz);
-                s_rec[tid].link[0] = p[0];
-                s_rec[tid].link[1] = p[1];
-                s_rec[tid].link[2] = p[g.offy];
-                s_rec[tid].link[3] = p[g.offy + 1];
-                s_rec[tid].link[4] = p[g.offx];
-                s_rec[tid].link[5] = p[g.offx + 1];
-                s_rec[tid].link[6] = p[g.offx + g.offy];
-                s_rec[tid].link[7] = p[g.offx + g.offy + 1];
+#pragma unroll
+                for (int k8 = 0; k8 < 8; ++k8) s_rec[tid].link[k8] = lk8[k8];
                 links_loaded = true;
             }
             const unsigned long long need = __ballot(shade);
