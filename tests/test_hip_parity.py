@@ -465,3 +465,32 @@ def test_walk_quotient_is_the_ieee_quotient(hip):
     check(q * dd, dd)                       # near-exact quotients
     check(torch.zeros(1000), dd[:1000])     # zero numerators
     assert total > 1.8e8 and bad == 0, (total, bad)
+
+
+def test_segmented_walk_with_long_voxel_lists(hip, oracle, monkeypatch):
+    """Every live voxel is a work voxel here (unrestricted fake samples) and the shell is thick: rays carry
+    40-100 work voxels, more than the 32-slot table (spill list) and more than the 8 a lane of k_walk_seg keeps
+    in LDS (second pass).  1, 4 and 8 lanes per ray must agree with each other and with the oracle."""
+    from alphasurf_amd import synth
+    sc = synth.make_sparse_scene(64, 4, seed=21, band=6.0, dilate=2, n_spheres=5, fake_sample_std=0.7)
+    o, d = synth.random_rays(3000, 77)
+    opts = dict(OPTION_SETS["fake_all"], step_size=0.5)
+    gt = np.random.RandomState(1).rand(o.shape[0], 3).astype(np.float32)
+    fused = dict(lambda_l2=1.0)
+    res = {}
+    for seg in ("1", "4", "8"):
+        monkeypatch.setenv("ASURF_WALK_SEG", seg)
+        res[seg] = hip.render_fused(sc, o, d, opts, gt, fused, counters=True)
+        monkeypatch.delenv("ASURF_WALK_SEG")
+    rgb1, g1, c1 = res["1"]
+    assert c1[1] / o.shape[0] > 20          # V_a: many active voxels per ray
+    for seg in ("4", "8"):
+        rgb, g, c = res[seg]
+        assert np.array_equal(rgb, rgb1), f"seg {seg}: {np.abs(rgb - rgb1).max()}"
+        assert (g["mask"] == g1["mask"]).all()
+        for k in ("sh", "density", "surface"):
+            grad_close(g[k], g1[k], 1e-5, f"seg {seg} grad_{k}")
+    rgb_o, go = oracle.render_fused(sc, o, d, opts, gt, fused)[:2]
+    assert np.abs(rgb1 - rgb_o).max() <= 2e-5
+    for k in ("sh", "density", "surface"):
+        grad_close(g1[k], go[k], 2e-4, f"grad_{k} vs oracle")
