@@ -588,14 +588,39 @@ int launch_eval(const Launch& L, const asurf_rays* rays, float param, int max_sa
     return launch_error("k_eval");
 }
 
+// Rays per wave of the cuvol kernels (asurf_cuvol.h).  Fused call on the bench scene, ms: 5 k rays 1.40 / 1.50 / 2.10 /
+// 2.89 / 8.07 with 1 / 2 / 4 / 8 / 64 rays per wave; 20 k rays 3.75 / 2.92 / 2.89 / 3.15 / 9.27 (1 / 2 / 4 / 8 / 64);
+// 80 k 6.26 / 6.48 / 7.06 / 9.86 (8 / 16 / 32 / 64); 160 k 10.8 / 10.3 / 11.0 / 11.7; 320 k 17.6 / 18.7 (32 / 64);
+// 640 k 32.4 / 31.9.  ASURF_CUVOL_RPW = 1 .. 64 (a power of two) overrides.
+static int cuvol_rays_per_wave(long long n_rays) {
+    if (const char* e = getenv("ASURF_CUVOL_RPW")) {
+        const int n = atoi(e);
+        if (n == 1 || n == 2 || n == 4 || n == 8 || n == 16 || n == 32 || n == 64) return n;
+    }
+    if (n_rays <= 6000) return 1;
+    if (n_rays <= 12000) return 2;
+    if (n_rays <= 30000) return 4;
+    if (n_rays <= 100000) return 8;
+    if (n_rays <= 200000) return 16;
+    if (n_rays <= 400000) return 32;
+    return 64;
+}
+
+static dim3 cuvol_grid(long long n_rays, int rpw) {
+    const long long per_block = (long long)rpw * (kBlock / 64);
+    return dim3((unsigned)((n_rays + per_block - 1) / per_block));
+}
+
 template <int B>
 int cuvol_fwd(const Launch& L, const asurf_rays* rays, int last_opaque, float* rgb_out, float* log_t) {
+    const int rpw = cuvol_rays_per_wave(rays->n_rays);
+    const dim3 grid = cuvol_grid(rays->n_rays, rpw);
     if (L.coarse_in_lds)
-        hipLaunchKernelGGL((k_cuvol_fwd<B, true>), L.ray_grid, dim3(kBlock), L.dyn_lds, L.stream, L.g, L.o,
-                           last_opaque, rays->origins, rays->dirs, (long long)rays->n_rays, rgb_out, log_t);
+        hipLaunchKernelGGL((k_cuvol_fwd<B, true>), grid, dim3(kBlock), L.dyn_lds, L.stream, L.g, L.o,
+                           last_opaque, rpw, rays->origins, rays->dirs, (long long)rays->n_rays, rgb_out, log_t);
     else
-        hipLaunchKernelGGL((k_cuvol_fwd<B, false>), L.ray_grid, dim3(kBlock), 0, L.stream, L.g, L.o,
-                           last_opaque, rays->origins, rays->dirs, (long long)rays->n_rays, rgb_out, log_t);
+        hipLaunchKernelGGL((k_cuvol_fwd<B, false>), grid, dim3(kBlock), 0, L.stream, L.g, L.o,
+                           last_opaque, rpw, rays->origins, rays->dirs, (long long)rays->n_rays, rgb_out, log_t);
     prof_after("k_cuvol_fwd", 1, L.stream);
     return launch_error("k_cuvol_fwd");
 }
@@ -603,13 +628,15 @@ int cuvol_fwd(const Launch& L, const asurf_rays* rays, int last_opaque, float* r
 template <int B>
 int cuvol_bwd(const Launch& L, const asurf_rays* rays, int last_opaque, const KGrads& G, const float* grad_in,
               const float* color_cache, int is_rgb, const float* log_t, float beta_loss, float sparsity_loss) {
+    const int rpw = cuvol_rays_per_wave(rays->n_rays);
+    const dim3 grid = cuvol_grid(rays->n_rays, rpw);
     if (L.coarse_in_lds)
-        hipLaunchKernelGGL((k_cuvol_bwd<B, true>), L.ray_grid, dim3(kBlock), L.dyn_lds, L.stream, L.g, L.o,
-                           last_opaque, G, rays->origins, rays->dirs, (long long)rays->n_rays, grad_in,
+        hipLaunchKernelGGL((k_cuvol_bwd<B, true>), grid, dim3(kBlock), L.dyn_lds, L.stream, L.g, L.o,
+                           last_opaque, rpw, G, rays->origins, rays->dirs, (long long)rays->n_rays, grad_in,
                            color_cache, is_rgb, log_t, beta_loss, sparsity_loss);
     else
-        hipLaunchKernelGGL((k_cuvol_bwd<B, false>), L.ray_grid, dim3(kBlock), 0, L.stream, L.g, L.o,
-                           last_opaque, G, rays->origins, rays->dirs, (long long)rays->n_rays, grad_in,
+        hipLaunchKernelGGL((k_cuvol_bwd<B, false>), grid, dim3(kBlock), 0, L.stream, L.g, L.o,
+                           last_opaque, rpw, G, rays->origins, rays->dirs, (long long)rays->n_rays, grad_in,
                            color_cache, is_rgb, log_t, beta_loss, sparsity_loss);
     prof_after("k_cuvol_bwd", 2, L.stream);
     return launch_error("k_cuvol_bwd");

@@ -327,7 +327,7 @@ __device__ __forceinline__ void cuvol_load_rows(const KGrid& g, int link, int ch
 
 template <int B, bool CLDS>
 __global__ void __launch_bounds__(kBlock)
-k_cuvol_fwd(KGrid g, KOpt o, int last_sample_opaque, const float* __restrict__ origins,
+k_cuvol_fwd(KGrid g, KOpt o, int last_sample_opaque, int rpw, const float* __restrict__ origins,
             const float* __restrict__ dirs, long long Q, float* __restrict__ rgb_out,
             float* __restrict__ log_transmit_out) {
     constexpr int SP = CuvolLay<B>::SP;
@@ -340,8 +340,11 @@ k_cuvol_fwd(KGrid g, KOpt o, int last_sample_opaque, const float* __restrict__ o
         for (int i = tid; i < g.coarse_words; i += kBlock) s_coarse[i] = g.coarse[i];
         __syncthreads();
     }
-    const long long q = (long long)blockIdx.x * kBlock + tid;
-    const bool valid = q < Q;
+    // rpw rays per wave (their lanes 0 .. rpw-1 march; all 64 lanes serve): a wave works its records off one pair
+    // after the other, so the length of that chain -- 64 rays x ~60 samples / 2 at ~1.5 us -- is the latency of a call
+    // that does not fill the chip; small batches spread their rays over more, shorter-lived waves
+    const long long q = ((long long)blockIdx.x * (kBlock / 64) + (tid >> 6)) * rpw + (tid & 63);
+    const bool valid = (tid & 63) < rpw && q < Q;
     Ray r;
     float world_step;
     cuvol_ray(g, o, origins, dirs, q, valid, r, &world_step);
@@ -439,7 +442,7 @@ k_cuvol_fwd(KGrid g, KOpt o, int last_sample_opaque, const float* __restrict__ o
 // ------------------------------------------------------------------------------------
 template <int B, bool CLDS>
 __global__ void __launch_bounds__(kBlock)
-k_cuvol_bwd(KGrid g, KOpt o, int last_sample_opaque, KGrads G, const float* __restrict__ origins,
+k_cuvol_bwd(KGrid g, KOpt o, int last_sample_opaque, int rpw, KGrads G, const float* __restrict__ origins,
             const float* __restrict__ dirs, long long Q, const float* __restrict__ grad_in,
             const float* __restrict__ color_cache, int grad_in_is_rgb,
             const float* __restrict__ log_transmit_in, float beta_loss, float sparsity_loss) {
@@ -454,8 +457,11 @@ k_cuvol_bwd(KGrid g, KOpt o, int last_sample_opaque, KGrads G, const float* __re
         for (int i = tid; i < g.coarse_words; i += kBlock) s_coarse[i] = g.coarse[i];
         __syncthreads();
     }
-    const long long q = (long long)blockIdx.x * kBlock + tid;
-    const bool valid = q < Q;
+    // rpw rays per wave (their lanes 0 .. rpw-1 march; all 64 lanes serve): a wave works its records off one pair
+    // after the other, so the length of that chain -- 64 rays x ~60 samples / 2 at ~1.5 us -- is the latency of a call
+    // that does not fill the chip; small batches spread their rays over more, shorter-lived waves
+    const long long q = ((long long)blockIdx.x * (kBlock / 64) + (tid >> 6)) * rpw + (tid & 63);
+    const bool valid = (tid & 63) < rpw && q < Q;
     Ray r;
     float world_step;
     cuvol_ray(g, o, origins, dirs, q, valid, r, &world_step);

@@ -227,3 +227,23 @@ def test_depth_through_the_grid_api(hip):
         tol = 0.5 if kw.get("depth_type") == "med" else 0.12         # 'med' picks a sample inside the ball
         assert depth.shape == (48, 48) and -0.05 < centre - 2.0 < tol, (kw, centre)   # eye at 2.5, ball radius 0.5
         assert float(depth[0, 0]) == 0.0 or np.isnan(float(depth[0, 0]))
+
+
+def test_rays_per_wave_is_transparent(hip, monkeypatch):
+    """Small batches spread their rays over more waves (1 .. 64 marching lanes per wave): the picture does not
+    depend on it, the gradients only through the order of the atomic sums."""
+    sc, o, d = cuvol_scene(9)
+    gt = np.random.RandomState(3).rand(o.shape[0], 3).astype(np.float32)
+    opts = OPTION_SETS["plenoxels"]
+    ref = None
+    for rpw in ("64", "16", "4", "1"):
+        monkeypatch.setenv("ASURF_CUVOL_RPW", rpw)
+        rgb, g = hip.cuvol_fused(sc, o, d, opts, gt, beta_loss=0.05, sparsity_loss=0.01)
+        monkeypatch.delenv("ASURF_CUVOL_RPW")
+        if ref is None:
+            ref = (rgb, g)
+            continue
+        assert np.array_equal(rgb, ref[0]), rpw
+        assert (g["mask"] == ref[1]["mask"]).all()
+        for k in ("sh", "density"):
+            grad_close(g[k], ref[1][k], 1e-5, f"rpw {rpw} grad_{k}")

@@ -1,10 +1,13 @@
 """Times the cuvol renderer (N4) on the bench scene: one 800x800 view of the 256^3 grid per call.
 Densities are the bench scene's raw opacities x60 (sigma ~ 30: sigma * world_step ~ 0.12 per sample)."""
-import json, os, sys
+import argparse, json, os, sys
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from alphasurf_amd import csrc_api as _C, synth
 
+ap = argparse.ArgumentParser()
+ap.add_argument("--width", type=int, default=800)
+args = ap.parse_args()
 dev = torch.device("cuda:0")
 sc = synth.make_sparse_scene(256, 9, trunc_a=5.0, **synth.BENCH_SCENE)
 g = _C.SparseGridSpec()
@@ -12,7 +15,7 @@ g.density_data = torch.from_numpy(sc["density"] * 60.0).to(dev)
 g.sh_data, g.links = torch.from_numpy(sc["sh"]).to(dev), torch.from_numpy(sc["links"]).to(dev)
 g._offset, g._scaling = torch.from_numpy(sc["offset"]), torch.from_numpy(sc["scaling"])
 g.basis_dim, g.basis_type, g.surface_type = 9, 1, 100
-o, d = synth.pinhole_rays(synth.orbit_camera(0), 800, 800)
+o, d = synth.pinhole_rays(synth.orbit_camera(0), args.width, args.width)
 r = _C.RaysSpec()
 r.origins, r.dirs = torch.from_numpy(o).to(dev), torch.from_numpy(d).to(dev)
 r.masks = torch.ones(o.shape[0], dtype=torch.bool, device=dev)
