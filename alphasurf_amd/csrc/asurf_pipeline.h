@@ -229,6 +229,11 @@ k_walk_seg(KGrid g, KOpt o, const float* __restrict__ origins, const float* __re
     Ray r;
     r.tmin = 1.f;
     r.tmax = 0.f;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        r.o[k] = 0.f;
+        r.d[k] = 1.f;
+    }
     if (valid) {
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
