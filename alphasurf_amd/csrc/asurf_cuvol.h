@@ -504,6 +504,12 @@ k_cuvol_bwd(KGrid g, KOpt o, int last_sample_opaque, int rpw, KGrads G, const fl
     const int chB = e / B;
     const int kB = e - chB * B;
     const bool onB = cs < C::CPR;
+    // density gradient of the previous record of this lane's ray, not yet written (see below)
+    bool pd_valid = false;
+    int pd_cid = 0;
+    int pd_link[8] = {-1, -1, -1, -1, -1, -1, -1, -1};
+    float pd_acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    float pd_keep[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     int held = -1;
     float val[B];
 #pragma unroll
@@ -630,14 +636,40 @@ k_cuvol_bwd(KGrid g, KOpt o, int last_sample_opaque, int rpw, KGrads G, const fl
                 }
             }
             if (G.grad_density != nullptr) {
+                // A ray's next record usually lies in a cell that shares a face with this one: the four rows of
+                // that face receive both records' terms in one atomic.  The previous record's sums wait in
+                // registers (pd_*); its far face is written out now, its near face is folded into this record.
+                const int diff = rec_cid - pd_cid;
+                const bool px = diff == g.offx, mx = diff == -g.offx, py = diff == g.offy, my = diff == -g.offy;
+                const bool pz = diff == 1, mz = diff == -1;
+                const bool adjacent = pd_valid && (px || mx || py || my || pz || mz);
+                // bit of the axis moved along, and whether the old cell's shared face is its high one
+                const int b = (px || mx) ? 4 : ((py || my) ? 2 : 1);
+                const bool high = px || py || pz;
 #pragma unroll
                 for (int i = 0; i < 8; ++i) {
-                    const int link = lr.link[i];
-                    if (link >= 0) atomicAdd(&G.grad_density[link], cw[i]);
+                    // old corner i lies on the shared face iff its bit b equals `high`; it is the new corner i ^ b
+                    const bool shared = adjacent && (((i & 4) && b == 4) || ((i & 2) && b == 2) || ((i & 1) && b == 1)) == high;
+                    if (pd_valid && !shared && pd_link[i] >= 0) atomicAdd(&G.grad_density[pd_link[i]], pd_acc[i]);
+                    pd_keep[i] = shared ? pd_acc[i] : 0.f;
                 }
+                // new corner j receives the old corner j ^ b when that one was shared
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float carry = b == 4 ? pd_keep[j ^ 4] : (b == 2 ? pd_keep[j ^ 2] : pd_keep[j ^ 1]);
+                    pd_acc[j] = cw[j] + (adjacent ? carry : 0.f);
+                    pd_link[j] = lr.link[j];
+                }
+                pd_cid = rec_cid;
+                pd_valid = true;
             }
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    }
+    if (pd_valid && G.grad_density != nullptr) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+            if (pd_link[i] >= 0) atomicAdd(&G.grad_density[pd_link[i]], pd_acc[i]);
     }
 }
 
