@@ -274,6 +274,7 @@ k_bwd_sh(KGrid g, KGrads G, int want_dpos, const float* __restrict__ dirs, long 
     __shared__ LaneRec s_rec[kBlock];
     __shared__ float4 s_smp[kBlock];  // position in the voxel | real sample?   (in), d/dpos (out)
     __shared__ float4 s_gch[kBlock];  // d(loss)/d(colour channel) | packed voxel
+    __shared__ float s_carry[(kBlock / 64) * 8 * C::D];  // per wave: the run's sums while they change corner slots
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int n_list = *S.n_list;
@@ -382,7 +383,38 @@ k_bwd_sh(KGrid g, KGrads G, int want_dpos, const float* __restrict__ dirs, long 
                 const int sl = h ? r1 : r0;
                 const int pv = __builtin_bit_cast(int, s_gch[wbase + sl].w);  // wave-uniform
                 if (pv != run_pv) {
-                    flush();
+                    // Neighbouring rays mostly step to a voxel that shares a FACE with the run's: the four rows of
+                    // that face keep accumulating (they are corners c ^ b of the new voxel) and only the four rows
+                    // of the far face are written out.  The sums change corner slot through LDS.
+                    const int diff = pv - run_pv;
+                    const int adiff = diff < 0 ? -diff : diff;
+                    const bool adjacent = run_pv >= 0 && (adiff == 1 || adiff == (1 << 10) || adiff == (1 << 20));
+                    if (adjacent && G.grad_sh != nullptr) {
+                        const int b = adiff == 1 ? 1 : (adiff == (1 << 10) ? 2 : 4);  // corner bit of the axis
+                        const bool high = diff > 0;  // the shared face is the old voxel's high one
+                        float* carry = s_carry + (tid >> 6) * (8 * C::D);
+#pragma unroll
+                        for (int rd = 0; rd < C::ROUNDS; ++rd) {
+                            const int c = rd * C::CPR + cs;
+                            if (on && c < 8) {
+                                const bool shared = ((c & b) != 0) == high;
+                                if (!shared) {
+                                    const int link = rec_wave[run_sl].link[c];
+                                    atomicAdd(&G.grad_sh[(size_t)link * C::D + e], run[rd]);
+                                }
+                                carry[c * C::D + e] = shared ? run[rd] : 0.f;
+                            }
+                        }
+                        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+#pragma unroll
+                        for (int rd = 0; rd < C::ROUNDS; ++rd) {
+                            const int c = rd * C::CPR + cs;
+                            run[rd] = (on && c < 8) ? carry[(c ^ b) * C::D + e] : 0.f;
+                        }
+                        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                    } else {
+                        flush();
+                    }
                     run_pv = pv;
                     run_sl = sl;
                 }
