@@ -601,9 +601,64 @@ k_bwd_geo(KGrid g, KOpt o, KLoss L, KGrads G, const float* __restrict__ origins,
             gs[c] += take ? b2 : 0.f;
         }
     }
-    if (mine && head) {
-        scatter8(G.grad_density, G.mask, lk8, gd);
-        scatter8(G.grad_surface, G.mask, lk8, gs);
+    // Successive runs mostly sit in voxels that share a face: the four rows of that face are handed to the next
+    // run's head lane (they are its corners c ^ b) and leave from there with that run's own terms -- one atomic per
+    // plane instead of two.  A row a head has itself received is not handed on.
+    {
+        const bool is_head = mine && head;
+        const unsigned long long H = __ballot(is_head);
+        const unsigned long long above = (lane < 63) ? (H & ~((2ull << lane) - 1ull)) : 0ull;
+        const unsigned long long below = H & ((1ull << lane) - 1ull);
+        const int nh = above ? __ffsll((long long)above) - 1 : -1;
+        const int ph = below ? 63 - __clzll((long long)below) : -1;
+        const int key_n = __shfl(key, nh >= 0 ? nh : lane);
+        const int key_p = __shfl(key, ph >= 0 ? ph : lane);
+        auto axis_bit = [](int ad) { return ad == 1 ? 1 : (ad == (1 << 10) ? 2 : (ad == (1 << 20) ? 4 : 0)); };
+        const int dn = key_n - key, dp = key - key_p;
+        const int bn = (is_head && nh >= 0) ? axis_bit(dn < 0 ? -dn : dn) : 0;   // 0: not face-adjacent
+        const int bp = (is_head && ph >= 0) ? axis_bit(dp < 0 ? -dp : dp) : 0;
+        const bool highn = dn > 0, highp = dp > 0;
+        // what the previous head hands over depends on what IT received: its own (bp, highp)
+        const int code = bp | (highp ? 8 : 0);
+        const int code_p = __shfl(code, ph >= 0 ? ph : lane);
+        const int bpp = code_p & 7;
+        const bool highpp = (code_p & 8) != 0;
+        float pd[8], ps[8];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            pd[c] = __shfl(gd[c], ph >= 0 ? ph : lane);
+            ps[c] = __shfl(gs[c], ph >= 0 ? ph : lane);
+        }
+        if (is_head) {
+            float od[8], os[8];
+            bool give[8];
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                // received into c: the previous head's corner c ^ bp, if that lies on its face towards this voxel and
+                // not on its face towards ITS predecessor
+                const int cp = c ^ bp;
+                const bool prev_shared = bp != 0 && ((cp & bp) != 0) == highp;
+                const bool prev_received = bpp != 0 && (((cp ^ bpp) & bpp) != 0) == highpp;
+                const bool recv = prev_shared && !prev_received;
+                const float rd_ = bp == 1 ? pd[c ^ 1] : (bp == 2 ? pd[c ^ 2] : pd[c ^ 4]);
+                const float rs_ = bp == 1 ? ps[c ^ 1] : (bp == 2 ? ps[c ^ 2] : ps[c ^ 4]);
+                od[c] = gd[c] + (recv ? rd_ : 0.f);
+                os[c] = gs[c] + (recv ? rs_ : 0.f);
+                // handed to the next head: on my face towards it, unless it also lies on my face towards the previous
+                // head (the same geometric rule the receiver applies to me: prev_received above)
+                const bool next_shared = bn != 0 && ((c & bn) != 0) == highn;
+                const bool on_prev_face = bp != 0 && (((c ^ bp) & bp) != 0) == highp;
+                give[c] = next_shared && !on_prev_face;
+            }
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                if (!give[c]) {
+                    if (G.grad_density != nullptr) atomicAdd(&G.grad_density[lk8[c]], od[c]);
+                    if (G.grad_surface != nullptr) atomicAdd(&G.grad_surface[lk8[c]], os[c]);
+                    if (G.mask != nullptr) G.mask[lk8[c]] = 1;
+                }
+            }
+        }
     }
     if (G.grad_fake_sample_std != nullptr) {
         const float tot = wave_sum(gstd_acc);
