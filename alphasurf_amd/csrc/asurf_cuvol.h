@@ -452,6 +452,7 @@ k_cuvol_bwd(KGrid g, KOpt o, int last_sample_opaque, int rpw, KGrads G, const fl
     __shared__ __attribute__((aligned(16))) float s_sph[kBlock * SP];
     __shared__ CuvolRec s_rec[kBlock];
     __shared__ float4 s_smp[kBlock * kCuvolK];
+    __shared__ float s_carry[(kBlock / 64) * 8 * C::D];  // per wave: SH sums changing corner slots (below)
     const int tid = threadIdx.x;
     if constexpr (CLDS) {
         for (int i = tid; i < g.coarse_words; i += kBlock) s_coarse[i] = g.coarse[i];
@@ -594,12 +595,43 @@ k_cuvol_bwd(KGrid g, KOpt o, int last_sample_opaque, int rpw, KGrads G, const fl
                     const int rb = wbase + (h ? r1 : r0);
                     const int cidb = s_rec[rb].cid;  // wave-uniform
                     if (cidb != heldB) {
-                        flush();
+                        // a cell that shares a face with the held one: the four rows of that face keep accumulating
+                        // (they are corners c ^ b of the new cell), only the far face is written out (as k_bwd_sh)
+                        const int diff = cidb - heldB;
+                        const int ad = diff < 0 ? -diff : diff;
+                        const int b = heldB < 0 ? 0 : (ad == 1 ? 1 : (ad == g.offy ? 2 : (ad == g.offx ? 4 : 0)));
+                        if (b != 0) {
+                            const bool high = diff > 0;
+                            float* carry = s_carry + (tid >> 6) * (8 * C::D);
+#pragma unroll
+                            for (int rd = 0; rd < C::ROUNDS; ++rd) {
+                                const int cb = rd * C::CPR + cs;
+                                if (onB && cb < 8) {
+                                    const bool shared = ((cb & b) != 0) == high;
+                                    if (!shared && link_h[rd] >= 0) {
+                                        if (G.mask != nullptr && e == 0) G.mask[link_h[rd]] = 1;
+                                        if (G.grad_sh != nullptr && gacc[rd] != 0.f)
+                                            atomicAdd(&G.grad_sh[(size_t)link_h[rd] * C::D + e], gacc[rd]);
+                                    }
+                                    carry[cb * C::D + e] = shared ? gacc[rd] : 0.f;
+                                }
+                            }
+                            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+#pragma unroll
+                            for (int rd = 0; rd < C::ROUNDS; ++rd) {
+                                const int cb = rd * C::CPR + cs;
+                                gacc[rd] = (onB && cb < 8) ? carry[(cb ^ b) * C::D + e] : 0.f;
+                            }
+                            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                        } else {
+                            flush();
+#pragma unroll
+                            for (int rd = 0; rd < C::ROUNDS; ++rd) gacc[rd] = 0.f;
+                        }
                         heldB = cidb;
 #pragma unroll
                         for (int rd = 0; rd < C::ROUNDS; ++rd) {
                             const int cb = rd * C::CPR + cs;
-                            gacc[rd] = 0.f;
                             link_h[rd] = (onB && cb < 8) ? s_rec[rb].link[cb] : -1;
                         }
                     }
