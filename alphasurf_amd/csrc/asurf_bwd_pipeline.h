@@ -386,18 +386,19 @@ k_bwd_sh(KGrid g, KGrads G, int want_dpos, const float* __restrict__ dirs, long 
                     // Neighbouring rays mostly step to a voxel that shares a FACE with the run's: the four rows of
                     // that face keep accumulating (they are corners c ^ b of the new voxel) and only the four rows
                     // of the far face are written out.  The sums change corner slot through LDS.
-                    const int diff = pv - run_pv;
-                    const int adiff = diff < 0 ? -diff : diff;
-                    const bool adjacent = run_pv >= 0 && (adiff == 1 || adiff == (1 << 10) || adiff == (1 << 20));
+                    // (the same holds for an edge or a corner: two rows or one)
+                    const int dx = (pv >> 20) - (run_pv >> 20), dy = ((pv >> 10) & 1023) - ((run_pv >> 10) & 1023),
+                              dz = (pv & 1023) - (run_pv & 1023);
+                    const bool adjacent = run_pv >= 0 && dx >= -1 && dx <= 1 && dy >= -1 && dy <= 1 && dz >= -1 && dz <= 1;
                     if (adjacent && G.grad_sh != nullptr) {
-                        const int b = adiff == 1 ? 1 : (adiff == (1 << 10) ? 2 : 4);  // corner bit of the axis
-                        const bool high = diff > 0;  // the shared face is the old voxel's high one
+                        const int b = (dx ? 4 : 0) | (dy ? 2 : 0) | (dz ? 1 : 0);            // axes moved along
+                        const int hi = (dx > 0 ? 4 : 0) | (dy > 0 ? 2 : 0) | (dz > 0 ? 1 : 0);  // ... upwards
                         float* carry = s_carry + (tid >> 6) * (8 * C::D);
 #pragma unroll
                         for (int rd = 0; rd < C::ROUNDS; ++rd) {
                             const int c = rd * C::CPR + cs;
                             if (on && c < 8) {
-                                const bool shared = ((c & b) != 0) == high;
+                                const bool shared = (c & b) == hi;  // on the old voxel's side towards the new one
                                 if (!shared) {
                                     const int link = rec_wave[run_sl].link[c];
                                     atomicAdd(&G.grad_sh[(size_t)link * C::D + e], run[rd]);
@@ -613,16 +614,20 @@ k_bwd_geo(KGrid g, KOpt o, KLoss L, KGrads G, const float* __restrict__ origins,
         const int ph = below ? 63 - __clzll((long long)below) : -1;
         const int key_n = __shfl(key, nh >= 0 ? nh : lane);
         const int key_p = __shfl(key, ph >= 0 ? ph : lane);
-        auto axis_bit = [](int ad) { return ad == 1 ? 1 : (ad == (1 << 10) ? 2 : (ad == (1 << 20) ? 4 : 0)); };
-        const int dn = key_n - key, dp = key - key_p;
-        const int bn = (is_head && nh >= 0) ? axis_bit(dn < 0 ? -dn : dn) : 0;   // 0: not face-adjacent
-        const int bp = (is_head && ph >= 0) ? axis_bit(dp < 0 ? -dp : dp) : 0;
-        const bool highn = dn > 0, highp = dp > 0;
-        // what the previous head hands over depends on what IT received: its own (bp, highp)
-        const int code = bp | (highp ? 8 : 0);
-        const int code_p = __shfl(code, ph >= 0 ? ph : lane);
-        const int bpp = code_p & 7;
-        const bool highpp = (code_p & 8) != 0;
+        // step from voxel a to voxel b: bits of the axes moved along (0: not a neighbour) | << 3 those moved upwards
+        auto step_code = [](int a, int b2) {
+            const int dx = (b2 >> 20) - (a >> 20), dy = ((b2 >> 10) & 1023) - ((a >> 10) & 1023), dz = (b2 & 1023) - (a & 1023);
+            const bool near = dx >= -1 && dx <= 1 && dy >= -1 && dy <= 1 && dz >= -1 && dz <= 1;
+            const int bb = (dx ? 4 : 0) | (dy ? 2 : 0) | (dz ? 1 : 0);
+            const int hh = (dx > 0 ? 4 : 0) | (dy > 0 ? 2 : 0) | (dz > 0 ? 1 : 0);
+            return near ? (bb | (hh << 3)) : 0;
+        };
+        const int cn = (is_head && nh >= 0) ? step_code(key, key_n) : 0;
+        const int cp = (is_head && ph >= 0) ? step_code(key_p, key) : 0;
+        const int bn = cn & 7, hin = cn >> 3, bp = cp & 7, hip = cp >> 3;
+        // what the previous head hands over depends on ITS step from its predecessor
+        const int cpp = __shfl(cp, ph >= 0 ? ph : lane);
+        const int bpp = cpp & 7, hipp = cpp >> 3;
         float pd[8], ps[8];
 #pragma unroll
         for (int c = 0; c < 8; ++c) {
@@ -636,18 +641,22 @@ k_bwd_geo(KGrid g, KOpt o, KLoss L, KGrads G, const float* __restrict__ origins,
             for (int c = 0; c < 8; ++c) {
                 // received into c: the previous head's corner c ^ bp, if that lies on its face towards this voxel and
                 // not on its face towards ITS predecessor
-                const int cp = c ^ bp;
-                const bool prev_shared = bp != 0 && ((cp & bp) != 0) == highp;
-                const bool prev_received = bpp != 0 && (((cp ^ bpp) & bpp) != 0) == highpp;
+                const int cq = c ^ bp;  // the previous voxel's corner at this vertex
+                const bool prev_shared = bp != 0 && (cq & bp) == hip;
+                const bool prev_received = bpp != 0 && ((cq ^ bpp) & bpp) == hipp;
                 const bool recv = prev_shared && !prev_received;
-                const float rd_ = bp == 1 ? pd[c ^ 1] : (bp == 2 ? pd[c ^ 2] : pd[c ^ 4]);
-                const float rs_ = bp == 1 ? ps[c ^ 1] : (bp == 2 ? ps[c ^ 2] : ps[c ^ 4]);
+                float rd_ = 0.f, rs_ = 0.f;
+#pragma unroll
+                for (int m = 1; m < 8; ++m) {
+                    rd_ = bp == m ? pd[c ^ m] : rd_;
+                    rs_ = bp == m ? ps[c ^ m] : rs_;
+                }
                 od[c] = gd[c] + (recv ? rd_ : 0.f);
                 os[c] = gs[c] + (recv ? rs_ : 0.f);
                 // handed to the next head: on my face towards it, unless it also lies on my face towards the previous
                 // head (the same geometric rule the receiver applies to me: prev_received above)
-                const bool next_shared = bn != 0 && ((c & bn) != 0) == highn;
-                const bool on_prev_face = bp != 0 && (((c ^ bp) & bp) != 0) == highp;
+                const bool next_shared = bn != 0 && (c & bn) == hin;
+                const bool on_prev_face = bp != 0 && ((c ^ bp) & bp) == hip;
                 give[c] = next_shared && !on_prev_face;
             }
 #pragma unroll
