@@ -1012,6 +1012,23 @@ int asurf_tv_grad_sparse(const int32_t* links, const int32_t size[3], const floa
     return launch_error("k_tv_grad_sparse");
 }
 
+int asurf_tv(const int32_t* links, const int32_t size[3], const float* data, int32_t n_cols,
+             int32_t start_dim, int32_t end_dim, int32_t ignore_edge, float* out, void* stream) {
+    RegGrid G;
+    if (int e = reg_grid(links, size, G)) return e;
+    if (start_dim < 0 || end_dim > n_cols || end_dim <= start_dim) return fail(ASURF_E_INVALID, "tv: bad dim range");
+    if (!out) return fail(ASURF_E_INVALID, "tv: NULL output");
+    if (size[0] < 2 || size[1] < 2 || size[2] < 2) return 0;
+    if (!data) return fail(ASURF_E_INVALID, "tv: NULL tensor");
+    const long long nl = (long long)(size[0] - 1) * (size[1] - 1) * (size[2] - 1);
+    const long long Q = nl * (end_dim - start_dim);
+    const long long want = (Q + 255) / 256;
+    const int blocks = (int)(want < 4096 ? want : 4096);  // grid-stride: a few thousand atomics at most
+    hipLaunchKernelGGL(k_tv_value, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(stream), G, data,
+                       (int)n_cols, (int)start_dim, (int)end_dim, 1.f / (float)nl, Q, (int)ignore_edge, out);
+    return launch_error("k_tv_value");
+}
+
 int asurf_surf_tv_grad_sparse(const int32_t* links, const int32_t size[3], const float* data,
                               int32_t n_cols, const float* density_data, int32_t density_cols,
                               const int32_t* rand_cells, int64_t n_cells, uint8_t* mask_out,

@@ -3,6 +3,7 @@
 // into the parameter gradients with atomics, touched rows marked in mask_out.
 //   k_tv_grad_sparse               loss_kernel.cu:739-808   (TV on raw opacity / any [N,C] plane)
 //   k_surf_tv_grad_sparse          loss_kernel.cu:810-895   (TV on the surface scalar)
+//   k_tv_value                     loss_kernel.cu:73-117    (the dense TV value, a reduction)
 //   k_surface_normal_grad_sparse   loss_kernel.cu:398-436 + render_util.cuh:1823-2130
 //   k_alpha_surf_sparsify          loss_kernel.cu:665-738
 //   k_surface_eikonal_grad_sparse  the reference evaluates this loss with PyTorch autograd
@@ -83,6 +84,44 @@ k_tv_grad_sparse(RegGrid G, const float* __restrict__ data, const float* __restr
     reg_add(grad_data, mask_out, l001, C, idx, dz, idelta);
     reg_add(grad_data, mask_out, l010, C, idx, dy, idelta);
     reg_add(grad_data, mask_out, l100, C, idx, dx, idelta);
+}
+
+// tv_kernel (loss_kernel.cu:73-117): the TV *value* over every cell with x < X-1, y < Y-1, z < Z-1 --
+// sum over (cell, channel) of sqrt(1e-5 + |scaled forward differences|^2) * scale.  One wave-level
+// DPP sum, one LDS pass over the block's four waves, one atomic per block.
+__global__ void __launch_bounds__(256)
+k_tv_value(RegGrid G, const float* __restrict__ data, int C, int start_dim, int end_dim, float scale,
+           long long Q, int ignore_edge, float* __restrict__ out) {
+    __shared__ float s_part[4];
+    const int nd = end_dim - start_dim;
+    const float sc0 = G.size[0] * (1.f / 256.f), sc1 = G.size[1] * (1.f / 256.f),
+                sc2 = G.size[2] * (1.f / 256.f);
+    float acc = 0.f;
+    for (long long tid = (long long)blockIdx.x * blockDim.x + threadIdx.x; tid < Q;
+         tid += (long long)gridDim.x * blockDim.x) {
+        const int idx = (int)(tid % nd) + start_dim;
+        const long long xyz = tid / nd;
+        const int z = (int)(xyz % (G.size[2] - 1));
+        const long long xy = xyz / (G.size[2] - 1);
+        const int y = (int)(xy % (G.size[1] - 1));
+        const int x = (int)(xy / (G.size[1] - 1));
+        const int32_t* lp = G.links + ((size_t)x * G.offx + (size_t)y * G.offy + z);
+        const int l000 = lp[0];
+        if (ignore_edge && l000 == 0) continue;
+        const int l001 = lp[1], l010 = lp[G.offy], l100 = lp[G.offx];
+        const float v000 = l000 >= 0 ? data[(size_t)l000 * C + idx] : 0.f;
+        const float null_val = ignore_edge ? v000 : 0.f;
+        const float v100 = l100 >= 0 ? data[(size_t)l100 * C + idx] : null_val;
+        const float v010 = l010 >= 0 ? data[(size_t)l010 * C + idx] : null_val;
+        const float v001 = l001 >= 0 ? data[(size_t)l001 * C + idx] : null_val;
+        const float dx = (v100 - v000) * sc0, dy = (v010 - v000) * sc1, dz = (v001 - v000) * sc2;
+        acc += sqrtf(1e-5f + dx * dx + dy * dy + dz * dz);
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) acc += __shfl_xor(acc, d);
+    if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(out, (s_part[0] + s_part[1] + s_part[2] + s_part[3]) * scale);
 }
 
 // ---- surface normal smoothness -------------------------------------------------------------

@@ -516,6 +516,20 @@ def tv_grad_sparse(links, data, rand_cells, mask_out, start_dim, end_dim, scale,
                                                int(bool(ignore_last_z)), _ptr(grad_data), _stream(dev)))
 
 
+def tv(links, data, start_dim, end_dim, use_logalpha, logalpha_delta, ignore_edge, ndc_coeffx, ndc_coeffy):
+    """Tensor tv(...) -- svox2.cpp:114, loss_kernel.cu:73-117, 1214-1247: the dense TV value, a 0-d tensor.
+    use_logalpha / logalpha_delta / ndc_coeff* are dead in the reference's kernel as well."""
+    lp, size = _links_args(links)
+    _check_input(data, "data", torch.float32)
+    if data.dim() != 2:
+        raise RuntimeError("data must be 2-D")
+    out = torch.zeros((), dtype=torch.float32, device=data.device)
+    with torch.cuda.device(data.device):
+        _L.check(_L.lib().asurf_tv(lp, size, _ptr(data), data.shape[1], int(start_dim), int(end_dim),
+                                   int(bool(ignore_edge)), _ptr(out), _stream(data.device)))
+    return out
+
+
 def tv_grad(links, data, start_dim, end_dim, scale, use_logalpha, logalpha_delta, ignore_edge, ndc_coeffx,
             ndc_coeffy, grad_data):
     """void tv_grad(...) -- loss_kernel.cu:120-190, 1249-1287: the dense form, every cell with x < X-1, y < Y-1,
@@ -952,7 +966,7 @@ for _name, _row in [
         ("volume_render_svox1_backward", "out of scope"), ("volume_render_svox1_fused", "out of scope"),
         ("sparse_grid_mask_render", "N4"),
         ("sparse_grid_visbility_render_surf", "N4"), ("cubic_extract_iso_pts", "N4"), ("sample_cubemap", "N4"),
-        ("tv", "N2"), ("surface_normal_grad", "N2"), ("alpha_lap_grad_sparse", "N2"),
+        ("surface_normal_grad", "N2"), ("alpha_lap_grad_sparse", "N2"),
         ("lumisphere_tv_grad_sparse", "N2"), ("msi_tv_grad_sparse", "N2"), ("surf_sign_change_grad_sparse", "N2")]:
     globals()[_name] = _out_of_scope(_name, _row)
 del _name, _row

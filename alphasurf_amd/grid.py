@@ -203,6 +203,30 @@ class _SurfTravRenderFunction(autograd.Function):
                 holder.grad_fake_sample_std_out if need[5] else None, None, None, None, None)
 
 
+class _TotalVariationFunction(autograd.Function):
+    """svox2.py:507-546: the dense TV value (_C.tv) with _C.tv_grad as its backward."""
+
+    @staticmethod
+    def forward(ctx, data, links, start_dim, end_dim, use_logalpha, logalpha_delta, ignore_edge, ndc_coeffs):
+        tv = _C.tv(links, data, start_dim, end_dim, use_logalpha, logalpha_delta, ignore_edge,
+                   ndc_coeffs[0], ndc_coeffs[1])
+        ctx.save_for_backward(links, data)
+        ctx.args = (start_dim, end_dim, use_logalpha, logalpha_delta, ignore_edge, ndc_coeffs)
+        return tv
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        links, data = ctx.saved_tensors
+        start_dim, end_dim, use_logalpha, logalpha_delta, ignore_edge, ndc_coeffs = ctx.args
+        if not ctx.needs_input_grad[0]:
+            return (None,) * 8
+        grad_grid = torch.zeros_like(data)
+        # the reference calls tv_grad with scale 1.0 and drops grad_out (svox2.py:534-538); kept
+        _C.tv_grad(links, data, start_dim, end_dim, 1.0, use_logalpha, logalpha_delta, ignore_edge,
+                   ndc_coeffs[0], ndc_coeffs[1], grad_grid)
+        return (grad_grid,) + (None,) * 7
+
+
 class _VolumeRenderFunction(autograd.Function):
     """Autograd bridge of the surface-less renderers (:280-347; here: `cuvol`)."""
 
@@ -1009,6 +1033,28 @@ class SparseGrid(nn.Module):
             d2l = torch.arange(self.links.numel(), dtype=torch.int, device=self.links.device)[self.links.view(-1) >= 0]
             self._data_to_links = d2l
         return d2l
+
+    def tv(self, logalpha: bool = False, logalpha_delta: float = 2.0, ndc_coeffs=(-1.0, -1.0)):
+        """svox2.py:4890-4909: total variation of the density plane (sum over channels, mean over cells)."""
+        assert self.sh_data.is_cuda, "the HIP extension is required for total variation (no CPU fallback)"
+        assert not logalpha, "No longer supported"
+        if self.surface_type != SURFACE_TYPE_NONE:
+            raise NotImplementedError
+        return _TotalVariationFunction.apply(self.density_data, self.links, 0, 1, logalpha, logalpha_delta,
+                                             False, ndc_coeffs)
+
+    def tv_color(self, start_dim: int = 0, end_dim: Optional[int] = None, logalpha: bool = False,
+                 logalpha_delta: float = 2.0, ndc_coeffs=(-1.0, -1.0)):
+        """svox2.py:4911-4938: total variation of SH channels [start_dim, end_dim), edges ignored."""
+        assert self.sh_data.is_cuda, "the HIP extension is required for total variation (no CPU fallback)"
+        assert not logalpha, "No longer supported"
+        n = self.sh_data.size(1)
+        if end_dim is None:
+            end_dim = n
+        end_dim = end_dim + n if end_dim < 0 else end_dim
+        start_dim = start_dim + n if start_dim < 0 else start_dim
+        return _TotalVariationFunction.apply(self.sh_data, self.links, start_dim, end_dim, logalpha,
+                                             logalpha_delta, True, ndc_coeffs)
 
     def inplace_tv_grad(self, grad: torch.Tensor, scaling: float = 1.0, sparse_frac: float = 0.01,
                         logalpha: bool = False, logalpha_delta: float = 2.0, ndc_coeffs=(-1.0, -1.0),

@@ -93,7 +93,7 @@ EXPORTS = [
     "asurf_test_cubic_root_grad", "asurf_profile_enable", "asurf_profile_read",
     "asurf_profile_read_spans",
     "asurf_rmsprop_step", "asurf_sgd_step", "asurf_ray_voxel_count", "asurf_ray_voxel_fill",
-    "asurf_tv_grad_sparse", "asurf_surf_tv_grad_sparse", "asurf_surface_normal_grad_sparse",
+    "asurf_tv", "asurf_tv_grad_sparse", "asurf_surf_tv_grad_sparse", "asurf_surface_normal_grad_sparse",
     "asurf_alpha_surf_sparsify_grad_sparse", "asurf_surface_eikonal_grad_sparse",
     "asurf_render_eval_surf_trav", "asurf_dilate", "asurf_accel_dist_prop_tmp_bytes", "asurf_accel_dist_prop",
     "asurf_sample_plane", "asurf_sample_plane_backward",
@@ -138,6 +138,7 @@ def lib():
         L.asurf_ray_voxel_count.argtypes = [vp, vp, vp, C.c_int32, vp, vp]
         L.asurf_ray_voxel_fill.argtypes = [vp, vp, vp, C.c_int32, vp, vp, vp]
         i32, i64 = C.c_int32, C.c_int64
+        L.asurf_tv.argtypes = [vp, vp, vp, i32, i32, i32, i32, vp, vp]
         L.asurf_tv_grad_sparse.argtypes = [vp, vp, vp, i32, vp, i64, vp, i32, i32, fl, i32, i32, vp, vp]
         L.asurf_surf_tv_grad_sparse.argtypes = [vp, vp, vp, i32, vp, i32, vp, i64, vp, i32, i32, fl, i32, fl,
                                                 i32, i32, vp, vp]

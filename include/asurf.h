@@ -265,6 +265,13 @@ int asurf_render_eval_surf_trav(const asurf_grid* grid, const asurf_rays* rays,
                                 int32_t max_sample, float* out0, float* out1, void* workspace,
                                 size_t workspace_bytes, void* stream);
 
+/* tv -- svox2.cpp:114, loss_kernel.cu:73-117, 1214-1247: the dense TV value (sum over channels
+ * [start_dim, end_dim), mean over the (X-1)(Y-1)(Z-1) cells) ADDED to the device float *out (the
+ * reference returns a fresh zero tensor: the caller zeroes).  use_logalpha / ndc arguments of the
+ * reference are dead in its kernel and not part of this signature. */
+int asurf_tv(const int32_t* links, const int32_t size[3], const float* data, int32_t n_cols,
+             int32_t start_dim, int32_t end_dim, int32_t ignore_edge, float* out, void* stream);
+
 /* Per-iteration regularisers.  `links` is the int32[size0,size1,size2]
  * link grid, `rand_cells` a device list of n_cells flat cell indices (svox2.py:6335-6383),
  * `mask_out` the bool[N] sparse_grad_indexer or NULL; gradients are ADDED to grad_*.

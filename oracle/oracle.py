@@ -363,6 +363,32 @@ def cuvol_fused(sc, origins, dirs, opts, rgb_gt, beta_loss=0.0, sparsity_loss=0.
     return rgb, grads
 
 
+def tv_value(links, data, start_dim, end_dim, ignore_edge):
+    """tv_kernel + its launcher (loss_kernel.cu:73-117, 1214-1247): mean over the (X-1)(Y-1)(Z-1) cells of
+    the per-channel sqrt(1e-5 + |scaled forward differences|^2), summed over channels; the sum itself in
+    float64 (the reference's float atomics have no fixed order).  PARITY UNPINNED: no golden vector -- the
+    reference's kernel needs CUDA and its tests hold no expected value."""
+    links = np.asarray(links)
+    data = np.asarray(data, np.float32)
+    X, Y, Z = links.shape
+    l000 = links[:-1, :-1, :-1]
+    sc = [np.float32(n) * np.float32(1.0 / 256.0) for n in (X, Y, Z)]
+    nb = [links[1:, :-1, :-1], links[:-1, 1:, :-1], links[:-1, :-1, 1:]]
+    keep = (l000 != 0) if ignore_edge else np.ones(l000.shape, bool)
+    total = 0.0
+    for idx in range(start_dim, end_dim):
+        col = data[:, idx]
+        v0 = np.where(l000 >= 0, col[np.maximum(l000, 0)], np.float32(0))
+        null = v0 if ignore_edge else np.zeros_like(v0)
+        acc = np.full(v0.shape, np.float32(1e-5), np.float32)
+        for k in range(3):
+            vk = np.where(nb[k] >= 0, col[np.maximum(nb[k], 0)], null).astype(np.float32)
+            d = ((vk - v0) * sc[k]).astype(np.float32)
+            acc = (acc + d * d).astype(np.float32)
+        total += float(np.sqrt(acc, dtype=np.float32)[keep].astype(np.float64).sum())
+    return total / float(l000.size)
+
+
 def weight_render(data, links, c2w, fx, fy, cx, cy, width, height, step_size, stop_thresh, last_sample_opaque,
                   offset, scaling, out=None):
     """grid_weight_render (links=None, data = dense [X,Y,Z] volume) / sparse_grid_weight_render

@@ -204,3 +204,45 @@ def test_dense_tv_and_l2_colour(env, oracle):
         grid.inplace_l2_color_grad(g, scaling=3.0)
         nz = int(mask.sum())
         assert torch.allclose(g[mask], 3.0 / nz * grid.sh_data.data[mask]) and not g[~mask].any()
+
+
+def test_tv_value_and_its_autograd(env, oracle):
+    """_C.tv (loss_kernel.cu:73-117): the dense TV value against the oracle, both edge rules, on grids with link 0
+    and empty cells; SparseGrid.tv_color differentiates through it with the dense tv_grad (svox2.py:507-546)."""
+    torch, _C = env
+    import svox2
+    from test_grid_api_gpu import make_grid
+    grid = make_grid(torch, svox2, 24, 4)
+    holes = torch.rand(grid.links.shape, device="cuda") < 0.3
+    holes[0, 0, 0] = False
+    grid.links = torch.where(holes, torch.full_like(grid.links, -1), grid.links).contiguous()
+    links = grid.links.cpu().numpy()
+    assert (links < 0).any() and (links == 0).any()
+    for data, dims, edge in ((grid.density_data.data, (0, 1), False), (grid.sh_data.data, (0, 12), True),
+                             (grid.sh_data.data, (3, 9), True), (grid.sh_data.data, (5, 6), False)):
+        got = float(_C.tv(grid.links, data, dims[0], dims[1], False, 2.0, edge, -1.0, -1.0).item())
+        want = oracle.tv_value(links, data.cpu().numpy(), dims[0], dims[1], edge)
+        assert abs(got - want) <= 2e-5 * abs(want), (dims, edge, got, want)
+    with pytest.raises(RuntimeError):
+        _C.tv(grid.links, grid.sh_data.data, 4, 4, False, 2.0, True, -1.0, -1.0)
+    # a grid of one cell per axis has one term; a flat grid has none
+    one = torch.zeros(2, 2, 2, dtype=torch.int32, device="cuda")
+    one[1, 0, 0] = 1
+    val = torch.tensor([[1.0], [3.0]], device="cuda")
+    got = float(_C.tv(one, val, 0, 1, False, 2.0, False, -1.0, -1.0).item())
+    assert abs(got - oracle.tv_value(one.cpu().numpy(), val.cpu().numpy(), 0, 1, False)) < 1e-6
+    flat = torch.zeros(1, 4, 4, dtype=torch.int32, device="cuda")
+    assert float(_C.tv(flat, val, 0, 1, False, 2.0, False, -1.0, -1.0).item()) == 0.0
+    # autograd: value + the dense gradient, as the reference's _TotalVariationFunction
+    with pytest.raises(NotImplementedError):
+        grid.tv()  # surface grids: the reference raises too (svox2.py:4904-4905)
+    grid.sh_data.grad = None
+    tvc = grid.tv_color(start_dim=3, end_dim=-3)
+    want = oracle.tv_value(links, grid.sh_data.data.cpu().numpy(), 3, 9, True)
+    assert abs(float(tvc.item()) - want) <= 2e-5 * abs(want)
+    tvc.backward()
+    sx, sy, sz = links.shape
+    cells = np.arange(sx * sy * sz, dtype=np.int32).reshape(sx, sy, sz)[:-1, :-1, :-1].reshape(-1)
+    go, _ = oracle.tv_grad_sparse(links, grid.sh_data.data.cpu().numpy(), cells, 1.0, start_dim=3, end_dim=9,
+                                  ignore_edge=True)
+    grad_close(grid.sh_data.grad.cpu().numpy(), go, 1e-4, "tv_color backward")
