@@ -840,6 +840,17 @@ def volume_render_cuvol_image(grid, cam, opt):
     return rgb.view(cam.height, cam.width, 3)
 
 
+def volume_render_cuvol_image_backward(grid, cam, opt, grad_out, color_cache, grads):
+    """void volume_render_cuvol_image_backward(grid, cam, opt, grad_out[H,W,3], color_cache[H,W,3], grads) --
+    svox2.cpp:98-100 (declared; the reference's build leaves it unregistered, :179-180), called by
+    _VolumeRenderImageFunction.backward (svox2.py).  The per-pixel rays of the forward, then the ray backward."""
+    n = cam.height * cam.width
+    if grad_out.numel() != 3 * n or color_cache.numel() != 3 * n:
+        raise RuntimeError("grad_out / color_cache must be [height, width, 3]")
+    volume_render_cuvol_backward(grid, _camera_rays(cam), opt, grad_out.reshape(n, 3).contiguous(),
+                                 color_cache.reshape(n, 3).contiguous(), grads)
+
+
 # ---- weight renders (SURVEY.md section 8f, N4; misc_kernel.cu:186-400, 888-937, 1084-1138) ----
 def _pack_camera(cam):
     if cam.ndc_coeffx > 0.0:
@@ -959,7 +970,6 @@ def _out_of_scope(name, row):
 # The rest of the reference's binding table (svox2.cpp:139-225): named, so that a caller learns which
 # SURVEY.md section 8(f) row the missing piece belongs to instead of an AttributeError.
 for _name, _row in [
-        ("volume_render_cuvol_image_backward", "N4"),
         ("volume_render_surf_trav_image", "N4"), ("volume_render_surface_image", "N4"),
         ("volume_render_nvol", "out of scope"), ("volume_render_nvol_backward", "out of scope"),
         ("volume_render_nvol_fused", "out of scope"), ("volume_render_svox1", "out of scope"),

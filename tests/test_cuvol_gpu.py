@@ -188,6 +188,48 @@ def test_sparse_grid_api(hip):
         torch.allclose(sdf.density_data.grad, grid.density_data.grad, rtol=1e-4, atol=1e-9)
 
 
+def test_image_backward_is_the_ray_backward(hip):
+    """volume_render_cuvol_image_backward (svox2.cpp:98-100): the gradient of an image render equals the ray
+    backward over the camera's per-pixel rays, bit for bit when the atomics land in the same order or within
+    float summation noise otherwise."""
+    import torch
+    import svox2
+    import svox2.csrc as _C
+    dev = torch.device("cuda:0")
+    grid = svox2.SparseGrid(reso=32, basis_dim=4, use_sphere_bound=True, device=dev,
+                            surface_type=svox2.SURFACE_TYPE_NONE)
+    grid.opt.backend = "cuvol"
+    grid.opt.sigma_thresh, grid.opt.stop_thresh, grid.opt.step_size = 1e-8, 1e-7, 0.5
+    gen = torch.Generator(device="cpu").manual_seed(1)
+    grid.density_data.data[:] = (torch.randn(grid.density_data.shape, generator=gen) * 2 + 1).to(dev)
+    grid.sh_data.data[:] = (torch.randn(grid.sh_data.shape, generator=gen) * 0.2).to(dev)
+    c2w = torch.eye(4, device=dev)
+    c2w[2, 3] = -2.5
+    cam = svox2.Camera(c2w, fx=30.0, width=20, height=14)
+    g, o = grid._to_cpp(), grid.opt._to_cpp()
+    img = _C.volume_render_cuvol_image(g, cam._to_cpp(), o)
+    assert img.shape == (14, 20, 3)
+    grad_out = torch.randn(14, 20, 3, generator=gen).to(dev)
+
+    def holder():
+        h = _C.GridOutputGrads()
+        h.grad_density_out = torch.zeros_like(grid.density_data.data)
+        h.grad_sh_out = torch.zeros_like(grid.sh_data.data)
+        return h
+    a, b = holder(), holder()
+    _C.volume_render_cuvol_image_backward(g, cam._to_cpp(), o, grad_out, img, a)
+    from alphasurf_amd import csrc_api
+    rays = csrc_api._camera_rays(cam._to_cpp())  # the pixel rays of the image entry points
+    assert torch.equal(_C.volume_render_cuvol(g, rays, o).view(14, 20, 3), img)
+    _C.volume_render_cuvol_backward(g, rays, o, grad_out.view(-1, 3), img.view(-1, 3), b)
+    assert torch.allclose(grid.volume_render(cam.gen_rays())["rgb"].detach().view(14, 20, 3), img, atol=1e-5)
+    assert a.grad_sh_out.abs().sum() > 0
+    for x, y in ((a.grad_density_out, b.grad_density_out), (a.grad_sh_out, b.grad_sh_out)):
+        assert torch.allclose(x, y, rtol=1e-4, atol=1e-6 * float(y.abs().max()))
+    with pytest.raises(RuntimeError):
+        _C.volume_render_cuvol_image_backward(g, cam._to_cpp(), o, grad_out[:4], img, a)
+
+
 @pytest.mark.parametrize("optname", ["plenoxels", "gate", "opaque_end", "spheric"])
 def test_depth_renders_vs_oracle(hip, oracle, optname):
     sc, o, d = cuvol_scene(4)
