@@ -840,6 +840,18 @@ def volume_render_cuvol_image(grid, cam, opt):
     return rgb.view(cam.height, cam.width, 3)
 
 
+def volume_render_surf_trav_image(grid, cam, opt):
+    """Tensor[H,W,3] volume_render_surf_trav_image(grid, cam, opt) -- declared at svox2.cpp:34-35 (the reference's
+    build leaves it unregistered, :153): the camera's per-pixel rays through volume_render_surf_trav."""
+    return volume_render_surf_trav(grid, _camera_rays(cam), opt).view(cam.height, cam.width, 3)
+
+
+def volume_render_surface_image(grid, cam, ray_vox, opt):
+    """Tensor[H,W,3] volume_render_surface_image(grid, cam, ray_vox, opt) -- declared at svox2.cpp:26-27
+    (unregistered, :149); `ray_vox` lists the voxels of the camera's rays in pixel order."""
+    return volume_render_surface(grid, _camera_rays(cam), ray_vox, opt).view(cam.height, cam.width, 3)
+
+
 def volume_render_cuvol_image_backward(grid, cam, opt, grad_out, color_cache, grads):
     """void volume_render_cuvol_image_backward(grid, cam, opt, grad_out[H,W,3], color_cache[H,W,3], grads) --
     svox2.cpp:98-100 (declared; the reference's build leaves it unregistered, :179-180), called by
@@ -970,7 +982,6 @@ def _out_of_scope(name, row):
 # The rest of the reference's binding table (svox2.cpp:139-225): named, so that a caller learns which
 # SURVEY.md section 8(f) row the missing piece belongs to instead of an AttributeError.
 for _name, _row in [
-        ("volume_render_surf_trav_image", "N4"), ("volume_render_surface_image", "N4"),
         ("volume_render_nvol", "out of scope"), ("volume_render_nvol_backward", "out of scope"),
         ("volume_render_nvol_fused", "out of scope"), ("volume_render_svox1", "out of scope"),
         ("volume_render_svox1_backward", "out of scope"), ("volume_render_svox1_fused", "out of scope"),

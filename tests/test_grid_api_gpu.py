@@ -140,6 +140,17 @@ def test_autograd_path(env, oracle):
         c2w[2, 3] = -2.5
         img = grid.volume_render_image(svox2.Camera(c2w, fx=40.0, width=24, height=20), batch_size=100)
     assert img.shape == (20, 24, 3) and torch.isfinite(img).all()
+    # the image entry points of the binding table: the camera's pixel rays through the ray renderer
+    import svox2.csrc as _C
+    from alphasurf_amd import csrc_api
+    cam = svox2.Camera(c2w, fx=40.0, width=24, height=20)
+    g, o = grid._to_cpp(), grid.opt._to_cpp()
+    img2 = _C.volume_render_surf_trav_image(g, cam._to_cpp(), o)
+    # (not bit-equal run to run: which rays the pipeline hands to the one-kernel path depends on atomics)
+    assert torch.allclose(img2.view(-1, 3), _C.volume_render_surf_trav(g, csrc_api._camera_rays(cam._to_cpp()), o),
+                          atol=2e-6)
+    diff = (img2 - img).abs()  # gen_rays() rounds its rays differently: a few pixels at root boundaries move
+    assert float(diff.median()) < 1e-5 and float(diff.mean()) < 2e-3
 
 
 def _rmsprop_ref(data, rms, grad, rows, beta, lr, eps, minval, lr_last):
