@@ -1199,6 +1199,24 @@ int asurf_sample_plane(const int32_t* links, const int32_t size[3], const float*
     return launch_error("k_sample_plane");
 }
 
+int asurf_cubic_extract_iso_pts(const int32_t* links, const int32_t size[3], const float* level_data,
+                                const float* mask_data, const int32_t* cell_ids, int64_t n_cells,
+                                int32_t n_sample, float density_thresh, float* out, void* stream) {
+    if (!links || !size || size[0] < 1 || size[1] < 1 || size[2] < 1)
+        return fail(ASURF_E_INVALID, "cubic_extract_iso_pts: bad link grid");
+    if (n_cells < 0 || n_sample < 2 || n_sample > 1024)
+        return fail(ASURF_E_INVALID, "cubic_extract_iso_pts: n_cells < 0 or n_sample outside [2, 1024]");
+    if (n_cells == 0) return 0;
+    if (!level_data || !mask_data || !cell_ids || !out)
+        return fail(ASURF_E_INVALID, "cubic_extract_iso_pts: NULL tensor");
+    const long long threads = (long long)n_cells * n_sample * n_sample;
+    if (threads > (1ll << 40)) return fail(ASURF_E_INVALID, "cubic_extract_iso_pts: batch too large");
+    hipLaunchKernelGGL(k_iso_pts, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), links, (int)size[0], (int)size[1], (int)size[2],
+                       level_data, mask_data, cell_ids, (long long)n_cells, (int)n_sample, density_thresh, out);
+    return launch_error("k_iso_pts");
+}
+
 int asurf_sample_plane_backward(const int32_t* links, const int32_t size[3], int32_t n_cols,
                                 const float* points, int64_t n_points, const float offset[3],
                                 const float scaling[3], const float* grad_out, float* grad_plane,

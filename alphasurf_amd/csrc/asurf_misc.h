@@ -261,4 +261,57 @@ k_sample_plane_backward(const int32_t* __restrict__ links, SampleXf X, int C, co
     add(offx + offy + 1, t * zb);
 }
 
+// cubic_extract_iso_pts_kernel (svox2_kernel.cu:248-372): iso-surface points of the listed cells along
+// n x n axis-parallel lines per direction.  One thread per (cell, i, j) -- the reference runs one per cell --
+// so a 100 k-cell batch fills the chip; the three directions of a line pair share the cell's 16 loads.
+__global__ void __launch_bounds__(256)
+k_iso_pts(const int32_t* __restrict__ links, int sx, int sy, int sz, const float* __restrict__ level_data,
+          const float* __restrict__ mask_data, const int32_t* __restrict__ cell_ids, long long Q, int n_sample,
+          float density_thresh, float* __restrict__ out) {
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int nn = n_sample * n_sample;
+    if (t >= Q * nn) return;
+    const long long tid = t / nn;
+    const int ij = (int)(t - tid * nn), i = ij / n_sample, j = ij - i * n_sample;
+    const int xyz = cell_ids[tid];
+    const int z = xyz % sz, xy = xyz / sz, y = xy % sy, x = xy / sy;
+    if (x >= sx - 1 || y >= sy - 1 || z >= sz - 1) return;
+    float surf[8], mask[8];
+    bool ok = true;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        const int lk = links[((size_t)(x + ((c >> 2) & 1)) * sy + (y + ((c >> 1) & 1))) * sz + (z + (c & 1))];
+        ok = ok && lk >= 0;
+        surf[c] = lk >= 0 ? level_data[lk] : 0.f;
+        mask[c] = lk >= 0 ? mask_data[lk] : 0.f;
+    }
+    if (!ok) return;
+    const float step = 1.f / (float)(n_sample - 1);
+    const float pos1 = i * step, pos2 = j * step;
+#pragma unroll
+    for (int dir_id = 0; dir_id < 3; ++dir_id) {
+        double o[3] = {0., 0., 0.};
+        float d[3] = {0.f, 0.f, 0.f};
+        d[dir_id] = 1.f;
+        o[dir_id == 0 ? 1 : 0] = pos1;
+        o[dir_id == 2 ? 1 : 2] = pos2;
+        double fs[4], st[3] = {-1, -1, -1};
+        surface_cubic(surf, o, d, fs);
+        solve_cubic_vieta(fs[0], fs[1], fs[2], fs[3], st);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            if (!(st[k] >= 0. && st[k] <= 1.)) continue;
+            const float pt[3] = {(float)(o[0] + (double)d[0] * st[k]), (float)(o[1] + (double)d[1] * st[k]),
+                                 (float)(o[2] + (double)d[2] * st[k])};
+            if (trilerp8(mask, pt) >= density_thresh) {
+                float* dst = out + ((size_t)tid * 3 * nn + (size_t)(i * n_sample * 3 + j * 3 + dir_id)) * 3;
+                dst[0] = pt[0] + x;
+                dst[1] = pt[1] + y;
+                dst[2] = pt[2] + z;
+                break;
+            }
+        }
+    }
+}
+
 }  // namespace asurf

@@ -516,6 +516,26 @@ def tv_grad_sparse(links, data, rand_cells, mask_out, start_dim, end_dim, scale,
                                                int(bool(ignore_last_z)), _ptr(grad_data), _stream(dev)))
 
 
+def cubic_extract_iso_pts(links, level_data, mask_data, cell_ids, n_sample, density_thresh):
+    """Tensor cubic_extract_iso_pts(links, level_data, mask_data, cell_ids, n_sample, density_thresh) --
+    svox2.cpp:21-22, svox2_kernel.cu:542-583: float[n_cells, 3 n_sample^2, 3] grid-space iso-surface points,
+    zero rows where a line has no accepted root."""
+    lp, size = _links_args(links)
+    _check_input(level_data, "level_data", torch.float32)
+    _check_input(mask_data, "mask_data", torch.float32)
+    _check_cells(cell_ids)
+    if level_data.numel() != mask_data.numel():
+        raise RuntimeError("level_data and mask_data must hold one value per grid row")
+    n_sample = int(n_sample)
+    dev = level_data.device
+    out = torch.zeros((cell_ids.shape[0], 3 * n_sample * n_sample, 3), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        _L.check(_L.lib().asurf_cubic_extract_iso_pts(lp, size, _ptr(level_data), _ptr(mask_data), _ptr(cell_ids),
+                                                      cell_ids.shape[0], n_sample, float(density_thresh),
+                                                      _ptr(out), _stream(dev)))
+    return out
+
+
 def tv(links, data, start_dim, end_dim, use_logalpha, logalpha_delta, ignore_edge, ndc_coeffx, ndc_coeffy):
     """Tensor tv(...) -- svox2.cpp:114, loss_kernel.cu:73-117, 1214-1247: the dense TV value, a 0-d tensor.
     use_logalpha / logalpha_delta / ndc_coeff* are dead in the reference's kernel as well."""
@@ -986,7 +1006,7 @@ for _name, _row in [
         ("volume_render_nvol_fused", "out of scope"), ("volume_render_svox1", "out of scope"),
         ("volume_render_svox1_backward", "out of scope"), ("volume_render_svox1_fused", "out of scope"),
         ("sparse_grid_mask_render", "N4"),
-        ("sparse_grid_visbility_render_surf", "N4"), ("cubic_extract_iso_pts", "N4"), ("sample_cubemap", "N4"),
+        ("sparse_grid_visbility_render_surf", "N4"), ("sample_cubemap", "N4"),
         ("surface_normal_grad", "N2"), ("alpha_lap_grad_sparse", "N2"),
         ("lumisphere_tv_grad_sparse", "N2"), ("msi_tv_grad_sparse", "N2"), ("surf_sign_change_grad_sparse", "N2")]:
     globals()[_name] = _out_of_scope(_name, _row)

@@ -416,6 +416,29 @@ class SparseGrid(nn.Module):
         rscaling = 2.0 * self.radius / gsz
         return torch.addcmul(roffset.to(points.device), points, rscaling.to(points.device))
 
+    def sample_surf_pts(self, cell_ids, n_sample: int = 5, density_thresh: float = 0, surf_lv_set: float = 0.):
+        """Iso-surface points inside the listed cells along axis-parallel lines (:4525-4550 ->
+        cubic_extract_iso_pts); a surface-less grid extracts the density level set at density_thresh."""
+        has_surf = self.surface_data is not None
+        level = (self.surface_data.data - surf_lv_set) if has_surf else (self.density_data.data - density_thresh)
+        pts = _C.cubic_extract_iso_pts(self.links, level.contiguous(), self.density_data.data,
+                                       cell_ids.to(device=self.links.device, dtype=torch.int).contiguous(),
+                                       n_sample, density_thresh if has_surf else -100.)
+        pts = pts.view(-1, 3)
+        return pts[~((pts == 0.).all(dim=-1))]
+
+    def extract_pts(self, density_thresh: float = 0, n_sample: int = 5, batch_size: int = 100000,
+                    scene_scale: float = 1., to_world: bool = False, surf_lv_set: float = 0.):
+        """Point cloud of the surface over every non-empty cell (:4552-4580)."""
+        with torch.no_grad():
+            cell_ids = self._non_empty_ids()
+            parts = [self.sample_surf_pts(cell_ids[i:i + batch_size], n_sample, density_thresh, surf_lv_set)
+                     for i in range(0, cell_ids.shape[0], batch_size)]
+            pts = torch.cat(parts, dim=0) if parts else torch.zeros(0, 3, device=self.links.device)
+            if to_world:
+                pts = self.grid2world(pts) / scene_scale
+            return pts
+
     def trunc_vol_render_rw(self, intersect_ids):
         """Truncated-hann re-weighting of the i-th intersection (:4740-4746)."""
         u = torch.clamp(self.truncated_vol_render_a - intersect_ids, 0.0, 1.0)

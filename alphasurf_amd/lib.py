@@ -96,7 +96,7 @@ EXPORTS = [
     "asurf_tv", "asurf_tv_grad_sparse", "asurf_surf_tv_grad_sparse", "asurf_surface_normal_grad_sparse",
     "asurf_alpha_surf_sparsify_grad_sparse", "asurf_surface_eikonal_grad_sparse",
     "asurf_render_eval_surf_trav", "asurf_dilate", "asurf_accel_dist_prop_tmp_bytes", "asurf_accel_dist_prop",
-    "asurf_sample_plane", "asurf_sample_plane_backward",
+    "asurf_sample_plane", "asurf_sample_plane_backward", "asurf_cubic_extract_iso_pts",
     "asurf_volume_render_cuvol", "asurf_volume_render_cuvol_backward", "asurf_volume_render_cuvol_fused",
     "asurf_grid_weight_render", "asurf_sparse_grid_weight_render", "asurf_render_eval_cuvol",
     "asurf_ray_order_tmp_bytes", "asurf_ray_order", "asurf_test_quotient",
@@ -139,6 +139,7 @@ def lib():
         L.asurf_ray_voxel_fill.argtypes = [vp, vp, vp, C.c_int32, vp, vp, vp]
         i32, i64 = C.c_int32, C.c_int64
         L.asurf_tv.argtypes = [vp, vp, vp, i32, i32, i32, i32, vp, vp]
+        L.asurf_cubic_extract_iso_pts.argtypes = [vp, vp, vp, vp, vp, i64, i32, fl, vp, vp]
         L.asurf_tv_grad_sparse.argtypes = [vp, vp, vp, i32, vp, i64, vp, i32, i32, fl, i32, i32, vp, vp]
         L.asurf_surf_tv_grad_sparse.argtypes = [vp, vp, vp, i32, vp, i32, vp, i64, vp, i32, i32, fl, i32, fl,
                                                 i32, i32, vp, vp]

@@ -395,6 +395,15 @@ int asurf_sample_plane_backward(const int32_t* links, const int32_t size[3], int
                                 const float scaling[3], const float* grad_out, float* grad_plane,
                                 void* stream);
 
+/* cubic_extract_iso_pts -- svox2.cpp:21-22, svox2_kernel.cu:248-372, 542-583: for each listed cell whose 8
+ * vertices exist, n_sample x n_sample axis-parallel lines per direction; the first root in [0,1] of
+ * `level_data` (float[N], surface minus level set) along a line whose trilinear `mask_data` (float[N], the
+ * density) reaches density_thresh becomes a grid-space point of out float[n_cells, 3 n_sample^2, 3]
+ * (rows without a point stay as the caller's zeros; cell ids with a coordinate on the last layer are skipped). */
+int asurf_cubic_extract_iso_pts(const int32_t* links, const int32_t size[3], const float* level_data,
+                                const float* mask_data, const int32_t* cell_ids, int64_t n_cells,
+                                int32_t n_sample, float density_thresh, float* out, void* stream);
+
 /* Measurement hooks (no reference counterpart; used by bench.py).  When enabled, the
  * surf_trav launchers record a hipEvent on the call's stream after every kernel launch.
  * asurf_profile_read() waits for the last call and returns, in milliseconds,

@@ -2231,4 +2231,61 @@ int oracle_render_eval_cuvol(const oracle_grid* grid, const oracle_rays* rays, c
     return 0;
 }
 
+// cubic_extract_iso_pts (svox2_kernel.cu:248-372, 542-583): per listed cell, n_sample x n_sample axis-parallel
+// lines in each of the three directions; the first root of the level field in [0,1] whose trilinear mask value
+// reaches density_thresh is written as a grid-space point.  `out` [n_cells, 3 n^2, 3] is zeroed by the caller.
+int oracle_cubic_extract_iso_pts(const int32_t* links, const int32_t* size, const float* level_data,
+                                 const float* mask_data, const int32_t* cell_ids, int64_t n_cells,
+                                 int32_t n_sample, float density_thresh, float* out) {
+    const int X = size[0], Y = size[1], Z = size[2];
+    const float step = 1.f / (float)(n_sample - 1);
+    for (int64_t tid = 0; tid < n_cells; ++tid) {
+        const int xyz = cell_ids[tid];
+        const int z = xyz % Z, xy = xyz / Z, y = xy % Y, x = xy / Y;
+        if (x >= X - 1 || y >= Y - 1 || z >= Z - 1) continue;
+        int lk[8];
+        bool ok = true;
+        for (int c = 0; c < 8; ++c) {
+            lk[c] = links[((int64_t)(x + ((c >> 2) & 1)) * Y + (y + ((c >> 1) & 1))) * Z + (z + (c & 1))];
+            ok = ok && lk[c] >= 0;
+        }
+        if (!ok) continue;
+        double surf[8];
+        float mask[8];
+        for (int c = 0; c < 8; ++c) {
+            surf[c] = level_data[lk[c]];
+            mask[c] = mask_data[lk[c]];
+        }
+        for (int i = 0; i < n_sample; ++i) {
+            const float pos1 = i * step;
+            for (int j = 0; j < n_sample; ++j) {
+                const float pos2 = j * step;
+                for (int dir_id = 0; dir_id < 3; ++dir_id) {
+                    double d[3] = {0., 0., 0.}, o[3] = {0., 0., 0.};
+                    d[dir_id] = 1.;
+                    o[dir_id == 0 ? 1 : 0] = pos1;
+                    o[dir_id == 2 ? 1 : 2] = pos2;
+                    double fs[4], st[3] = {-1, -1, -1};
+                    surface_cubic(surf, o, d, fs);
+                    solve_cubic_vieta(fs[0], fs[1], fs[2], fs[3], 1e-10, st);
+                    for (int k = 0; k < 3; ++k) {
+                        if (!(st[k] >= 0. && st[k] <= 1.)) continue;
+                        const float pt[3] = {(float)(o[0] + d[0] * st[k]), (float)(o[1] + d[1] * st[k]),
+                                             (float)(o[2] + d[2] * st[k])};
+                        if (trilerp(mask, pt) >= density_thresh) {
+                            float* dst = out + ((int64_t)tid * 3 * n_sample * n_sample + (i * n_sample * 3 + j * 3 + dir_id)) * 3;
+                            dst[0] = pt[0] + x;
+                            dst[1] = pt[1] + y;
+                            dst[2] = pt[2] + z;
+                            break;
+                        }
+                    }
+                }
+            }
+        }
+    }
+    return 0;
+}
+
+
 }  // extern "C"

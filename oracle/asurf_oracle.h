@@ -192,6 +192,13 @@ int oracle_volume_render_cuvol_fused(const oracle_grid* grid, const oracle_rays*
                                      float beta_loss, float sparsity_loss, float* rgb_out,
                                      const oracle_grads* grads);
 
+/* svox2_kernel.cu:248-372, 542-583 (cubic_extract_iso_pts): iso-surface points of the listed cells along
+ * axis-parallel lines; out [n_cells, 3 n_sample^2, 3] zeroed by the caller.  PARITY UNPINNED as a whole (the
+ * reference's kernel needs CUDA); its cubic, root solver and trilerp are the pinned ones of the renderer. */
+int oracle_cubic_extract_iso_pts(const int32_t* links, const int32_t* size, const float* level_data,
+                                 const float* mask_data, const int32_t* cell_ids, int64_t n_cells,
+                                 int32_t n_sample, float density_thresh, float* out);
+
 /* misc_kernel.cu:186-400, 888-937: per-vertex max of the compositing weight (links == NULL, data = dense
  * [X,Y,Z] volume) or of the transmittance in front of a sample (sparse grid) over a camera's pixel rays */
 int oracle_weight_render(const float* data, const int32_t* links, const int32_t* size, const float* c2w,

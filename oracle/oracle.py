@@ -406,6 +406,21 @@ def weight_render(data, links, c2w, fx, fy, cx, cy, width, height, step_size, st
     return out
 
 
+def cubic_extract_iso_pts(links, level_data, mask_data, cell_ids, n_sample, density_thresh):
+    """cubic_extract_iso_pts (svox2_kernel.cu:248-372): [n_cells, 3 n_sample^2, 3] grid-space points, zeros where
+    no root passes.  Parity unpinned as a whole (see the .h)."""
+    lk = np.ascontiguousarray(links, np.int32)
+    size = np.asarray(lk.shape, np.int32)
+    lv = np.ascontiguousarray(level_data, np.float32).reshape(-1)
+    mk = np.ascontiguousarray(mask_data, np.float32).reshape(-1)
+    ids = np.ascontiguousarray(cell_ids, np.int32)
+    out = np.zeros((ids.shape[0], 3 * n_sample * n_sample, 3), np.float32)
+    _check(lib().oracle_cubic_extract_iso_pts(_i(lk), _i(size), _f(lv), _f(mk), _i(ids), C.c_int64(ids.shape[0]),
+                                              C.c_int32(n_sample), C.c_float(density_thresh), _f(out)),
+           "cubic_extract_iso_pts")
+    return out
+
+
 CUVOL_EVAL_MODES = {"expected_term": 0, "mode_term": 1, "med_term": 2, "sigma_thresh": 3}
 
 

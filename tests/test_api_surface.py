@@ -142,7 +142,7 @@ def test_every_reference_binding_is_named():
             stubs.append(name)
         except Exception:       # built: fails on the missing arguments
             pass
-    assert len(REFERENCE_BINDINGS) == 55 and len(stubs) == 15, (len(REFERENCE_BINDINGS), sorted(stubs))
+    assert len(REFERENCE_BINDINGS) == 55 and len(stubs) == 14, (len(REFERENCE_BINDINGS), sorted(stubs))
 
 
 def test_constructor_matches_reference_layouts():
