@@ -245,12 +245,14 @@ struct Launch {
 };
 
 // --- optional per-kernel timing (asurf_profile_enable): one hipEvent after every launch ---
+// The state is per host thread (like g_err): a thread that enables profiling times its own calls and reads
+// its own spans; calls made by other threads (e.g. an autograd backward thread) are not timed.
 constexpr int kMaxSpans = 24;
-bool g_prof_on = false;
-hipEvent_t g_ev[kMaxSpans + 1] = {};
-const char* g_span_name[kMaxSpans] = {};
-int g_span_group[kMaxSpans] = {};  // 0 occupancy pass, 1 forward, 2 backward
-int g_spans = -1;                  // spans recorded by the last call (-1: none)
+thread_local bool g_prof_on = false;
+thread_local hipEvent_t g_ev[kMaxSpans + 1] = {};
+thread_local const char* g_span_name[kMaxSpans] = {};
+thread_local int g_span_group[kMaxSpans] = {};  // 0 occupancy pass, 1 forward, 2 backward
+thread_local int g_spans = -1;                  // spans recorded by the last call (-1: none)
 
 void prof_begin(hipStream_t s) {
     g_spans = -1;

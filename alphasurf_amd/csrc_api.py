@@ -10,6 +10,7 @@ Functions outside the build's scope raise NotImplementedError naming the SURVEY.
 section 8(f) row they belong to.
 """
 import ctypes as C
+import threading
 
 import torch
 
@@ -225,16 +226,20 @@ def _pack_grads(grads, grid):
 
 
 _ws_cache = {}
+_ws_lock = threading.Lock()
 
 
 def _workspace(device, nbytes):
-    """Scratch for one call.  A per-device buffer is grown on demand and reused: the
-    launches are stream-ordered, so back-to-back calls on one stream may share it."""
+    """Scratch for one call.  A per-(device, stream) buffer is grown on demand and reused: the launches are
+    stream-ordered, so calls on one stream may share it whichever host thread issues them (a caller that was
+    handed the old buffer keeps it alive until its own launches are queued; the caching allocator does not
+    reuse the block before the stream has passed them).  The lock only guards the dictionary."""
     key = (device.type, device.index, torch.cuda.current_stream(device).cuda_stream)
-    buf = _ws_cache.get(key)
-    if buf is None or buf.numel() < nbytes:
-        buf = torch.empty(int(nbytes), dtype=torch.uint8, device=device)
-        _ws_cache[key] = buf
+    with _ws_lock:
+        buf = _ws_cache.get(key)
+        if buf is None or buf.numel() < nbytes:
+            buf = torch.empty(int(nbytes), dtype=torch.uint8, device=device)
+            _ws_cache[key] = buf
     return buf
 
 

@@ -28,6 +28,32 @@ def _reduce(t, op, group):
         dist.all_reduce(t, op=op, group=group)
 
 
+def _staged(t, group):
+    return t.is_cuda and dist.get_backend(group) == "gloo"
+
+
+def _all_to_all(out, inp, out_splits, in_splits, group):
+    """all_to_all_single; device tensors go through host memory with the gloo backend."""
+    if _staged(inp, group):
+        h = torch.empty(out.shape, dtype=out.dtype)
+        dist.all_to_all_single(h, inp.cpu(), output_split_sizes=out_splits, input_split_sizes=in_splits,
+                               group=group)
+        out.copy_(h)
+    else:
+        dist.all_to_all_single(out, inp, output_split_sizes=out_splits, input_split_sizes=in_splits, group=group)
+
+
+def _all_gather(outs, inp, group):
+    """all_gather into the list `outs`; device tensors go through host memory with the gloo backend."""
+    if _staged(inp, group):
+        hs = [torch.empty(o.shape, dtype=o.dtype) for o in outs]
+        dist.all_gather(hs, inp.cpu(), group=group)
+        for o, h in zip(outs, hs):
+            o.copy_(h)
+    else:
+        dist.all_gather(outs, inp, group=group)
+
+
 def all_reduce_dense(tensors, mask=None, group=None):
     """Plain sum all-reduce of every gradient buffer + OR of the mask."""
     if _world(group) == 1:
@@ -66,12 +92,12 @@ def all_reduce_sparse(tensors, mask, group=None):
     owner_cuts = torch.searchsorted(idx, torch.tensor(bounds, device=dev))
     send_counts = (owner_cuts[1:] - owner_cuts[:-1]).to(torch.int64)
     recv_counts = torch.empty_like(send_counts)
-    dist.all_to_all_single(recv_counts, send_counts, group=group)
+    _all_to_all(recv_counts, send_counts, None, None, group)
     sc, rc = send_counts.tolist(), recv_counts.tolist()
     recv_idx = torch.empty(sum(rc), dtype=idx.dtype, device=dev)
     recv_rows = torch.empty((sum(rc), W), dtype=rows.dtype, device=dev)
-    dist.all_to_all_single(recv_idx, idx, output_split_sizes=rc, input_split_sizes=sc, group=group)
-    dist.all_to_all_single(recv_rows, rows, output_split_sizes=rc, input_split_sizes=sc, group=group)
+    _all_to_all(recv_idx, idx, rc, sc, group)
+    _all_to_all(recv_rows, rows, rc, sc, group)
     # owner-side reduction over its range
     lo, hi = bounds[rank], bounds[rank + 1]
     acc = torch.zeros((hi - lo, W), dtype=rows.dtype, device=dev)
@@ -84,7 +110,7 @@ def all_reduce_sparse(tensors, mask, group=None):
     # publish the summed rows
     cnt = torch.tensor([own_idx.numel()], dtype=torch.int64, device=dev)
     cnts = [torch.zeros_like(cnt) for _ in range(world)]
-    dist.all_gather(cnts, cnt, group=group)
+    _all_gather(cnts, cnt, group)
     cnts = [int(c.item()) for c in cnts]
     mx = max(max(cnts), 1)
     pad_idx = torch.zeros(mx, dtype=own_idx.dtype, device=dev)
@@ -93,8 +119,8 @@ def all_reduce_sparse(tensors, mask, group=None):
     pad_rows[: own_idx.numel()] = own_rows
     all_idx = [torch.empty_like(pad_idx) for _ in range(world)]
     all_rows = [torch.empty_like(pad_rows) for _ in range(world)]
-    dist.all_gather(all_idx, pad_idx, group=group)
-    dist.all_gather(all_rows, pad_rows, group=group)
+    _all_gather(all_idx, pad_idx, group)
+    _all_gather(all_rows, pad_rows, group)
     for r in range(world):
         k = cnts[r]
         if k == 0:
@@ -155,11 +181,11 @@ def all_reduce_grads(grad_sh, grad_density, grad_surface, mask, grad_fake_sample
     if _world(group) == 1:
         return "single"
     if grad_fake_sample_std is not None:
-        dist.all_reduce(grad_fake_sample_std, group=group)
+        _reduce(grad_fake_sample_std, dist.ReduceOp.SUM, group)
     tensors = [grad_sh, grad_density, grad_surface]
     if mode == "auto":
         frac = mask.float().mean().reshape(1)
-        dist.all_reduce(frac, op=dist.ReduceOp.MAX, group=group)
+        _reduce(frac, dist.ReduceOp.MAX, group)
         mode = "sparse" if float(frac.item()) < dense_threshold else "dense"
     if mode == "sparse":
         all_reduce_sparse(tensors, mask, group=group)

@@ -574,6 +574,7 @@ class SparseGrid(nn.Module):
             holder.grad_surface_out = grad["surface_data"]
         holder.grad_sh_out = grad["sh_data"]
         holder.mask_out = self.sparse_grad_indexer
+        self._masks_written()
         if backend == "cuvol":  # :3625-3634
             _C.volume_render_cuvol_fused(self._to_cpp(), rays._to_cpp(), self.opt._to_cpp(randomize=randomize),
                                          rgb_gt, beta_loss, sparsity_loss, rgb_out, holder)
@@ -781,6 +782,7 @@ class SparseGrid(nn.Module):
         out, surf_trav.cu:31), so rendering is unchanged by it."""
         assert self.links.is_cuda, "the HIP extension is required for accelerate"
         _C.accel_dist_prop(self.links)
+        self.__dict__["_non_empty_cache"] = None  # links were rewritten through a raw pointer
 
     def safe_fetch_data(self, xyz, data, default=0):
         """data rows at integer grid coordinates, `default` outside the grid / at empty links (:2859-2872)."""
@@ -988,12 +990,20 @@ class SparseGrid(nn.Module):
         """:6295-6299"""
         if self.sparse_grad_indexer is None:
             return torch.empty((0,), dtype=torch.bool, device=self.density_data.device)
+        self._masks_written()  # the caller hands it to a kernel, which writes through the raw pointer
         return self.sparse_grad_indexer
 
     def _get_sparse_sh_grad_indexer(self):
         if self.sparse_sh_grad_indexer is None:
             return torch.empty((0,), dtype=torch.bool, device=self.density_data.device)
+        self._masks_written()
         return self.sparse_sh_grad_indexer
+
+    def _masks_written(self):
+        """The HIP kernels set mask bytes through raw pointers, which torch's `_version` does not see: every
+        method that hands a mask to a kernel bumps this generation, and the mask -> index-list cache of
+        `_maybe_convert_sparse_grad_indexer` is keyed on it."""
+        self.__dict__["_mask_gen"] = self.__dict__.get("_mask_gen", 0) + 1
 
     def _get_h(self):
         """:3228-3232"""
@@ -1021,7 +1031,7 @@ class SparseGrid(nn.Module):
         grid_size = self.links.numel()
         non_empty_ids = self._non_empty_ids()
         if sparse_frac >= 1.0:
-            return non_empty_ids
+            return non_empty_ids.clone()  # never the cached tensor itself
         non_empty_num = len(non_empty_ids)
         if frac_of_remaining:
             sparse_num = int(non_empty_num * sparse_frac)
@@ -1029,7 +1039,7 @@ class SparseGrid(nn.Module):
             sparse_num = min(int(sparse_frac * grid_size), int(non_empty_num))
         if contiguous:
             start = np.random.randint(0, non_empty_num - sparse_num + 1)
-            return non_empty_ids[start:start + sparse_num].contiguous()
+            return non_empty_ids[start:start + sparse_num].clone()
         return non_empty_ids[torch.randint(0, non_empty_num, (sparse_num,), dtype=torch.long,
                                            device=self.links.device)]
 
@@ -1205,7 +1215,7 @@ class SparseGrid(nn.Module):
             return indexer
         # the count is a device -> host round trip; the density and the surface step of an iteration ask about the
         # same mask, so the answer is kept while the mask is untouched
-        key = (indexer.data_ptr(), indexer._version)
+        key = (indexer.data_ptr(), indexer._version, self.__dict__.get("_mask_gen", 0))
         cached = self.__dict__.get("_indexer_cache_sh" if sh else "_indexer_cache")
         if cached is not None and cached[0] == key and cached[1] is indexer:
             return cached[2]
@@ -1269,23 +1279,48 @@ class SparseGrid(nn.Module):
 
     @classmethod
     def load(cls, path: str, device: Union[torch.device, str] = "cpu"):
-        z = np.load(path)
+        """svox2.py:4749-4838, same keys.  The throw-away constructor grid is 2^3 instead of the reference's
+        dense `list(links.shape)` volume (every tensor it would allocate is replaced below)."""
+        z = np.load(path, allow_pickle=True)
+        surface_type = CONSTANTS["SURFACE_TYPE_NONE"]
+        surface_data = None
+        if "data" in z.files:  # :4755-4759, the pre-surface layout: one array, density first
+            all_data = z["data"]
+            sh_data, density_data = all_data[..., 1:], all_data[..., :1]
+        else:
+            sh_data, density_data = z["sh_data"], z["density_data"]
+            surface_type = int(z["surface_type"].item()) if "surface_type" in z.files else surface_type
+            if surface_type != CONSTANTS["SURFACE_TYPE_NONE"]:
+                surface_data = z["surface_data"]
+        if "background_data" in z.files and z["background_data"].size > 0:
+            _next_row("N4", "MSI background layers in a checkpoint")
+        basis_type = int(z["basis_type"].item()) if "basis_type" in z.files else CONSTANTS["BASIS_TYPE_SH"]
+        if "basis_data" in z.files and z["basis_data"].size > 0:
+            basis_type = CONSTANTS["BASIS_TYPE_3D_TEXTURE"]  # :4819-4824
         links = z["links"]
-        surface_type = int(z["surface_type"]) if "surface_type" in z else CONSTANTS["SURFACE_TYPE_NONE"]
-        grid = cls(1, radius=z["radius"].tolist(), center=z["center"].tolist(),
-                   basis_dim=z["sh_data"].shape[1] // 3, device="cpu", surface_type=surface_type,
-                   trainable_fake_sample_std="fake_sample_std" in z and np.ndim(z["fake_sample_std"]) > 0)
-        grid.capacity = z["density_data"].shape[0]
-        grid.density_data = nn.Parameter(torch.from_numpy(z["density_data"].astype(np.float32)).to(device))
-        grid.sh_data = nn.Parameter(torch.from_numpy(z["sh_data"].astype(np.float32)).to(device))
-        grid.links = torch.from_numpy(links).to(device)
-        if "surface_data" in z:
-            grid.surface_data = nn.Parameter(torch.from_numpy(z["surface_data"].astype(np.float32)).to(device))
-            grid.level_set_data = torch.from_numpy(z["level_set_data"].astype(np.float32)).to(device)
-        if grid.fake_sample_std is not None:
-            grid.fake_sample_std = nn.Parameter(torch.from_numpy(
-                np.asarray(z["fake_sample_std"], np.float32).reshape(1, 1)).to(device))
-        grid.step_id = int(z["step_id"]) if "step_id" in z else 0
+        grid = cls(2, radius=z["radius"].tolist() if "radius" in z.files else [1.0, 1.0, 1.0],
+                   center=z["center"].tolist() if "center" in z.files else [0.0, 0.0, 0.0],
+                   basis_dim=sh_data.shape[1] // 3, use_z_order=False, device=device, basis_type=basis_type,
+                   mlp_posenc_size=int(z["mlp_posenc_size"].item()) if "mlp_posenc_size" in z.files else 0,
+                   mlp_width=int(z["mlp_width"].item()) if "mlp_width" in z.files else 16,
+                   background_nlayers=0, surface_type=surface_type)
+        if "step_id" in z.files:
+            grid.step_id = int(z["step_id"].item())
+
+        def dev(a):
+            return torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(device=device)
+        grid.sh_data = nn.Parameter(dev(sh_data))
+        grid.density_data = nn.Parameter(dev(density_data))
+        if surface_data is not None:
+            grid.surface_data = nn.Parameter(dev(surface_data))
+        if "level_set_data" in z.files:
+            grid.level_set_data = dev(z["level_set_data"])
+        if "fake_sample_std" in z.files:  # any rank; a plain tensor, as in the reference (:4808-4809)
+            grid.fake_sample_std = dev(z["fake_sample_std"])
+        grid.links = torch.from_numpy(np.ascontiguousarray(links)).to(device=device)
+        grid.capacity = grid.sh_data.size(0)
+        if grid.links.is_cuda:
+            grid.accelerate()
         return grid
 
     def __repr__(self):

@@ -72,14 +72,35 @@ def algorithmic_bytes_per_kernel(n_rays, v_t, v_a, s, D, stat_loss, M):
     }
 
 
+def spawn_ranks(args):
+    """`python bench.py --gpus N` without a launcher: start one rank per GPU as CHILD processes through
+    torch.distributed.run (nothing in this process has touched the GPU yet), pass their output through
+    and return their exit code."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd)
+
+
 def main():
     args = parse()
+    if args.gpus < 1:
+        sys.exit("bench.py: --gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(spawn_ranks(args))
     import torch
     import torch.distributed as dist
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        sys.exit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch one rank per GPU "
+                 f"(python -m torch.distributed.run --nproc-per-node {args.gpus} bench.py --gpus {args.gpus} ...)")
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         # ASURF_DIST_BACKEND=gloo: rehearsal of the N > 1 control flow on fewer GPUs than ranks
