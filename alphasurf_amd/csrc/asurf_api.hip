@@ -8,6 +8,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -16,6 +17,7 @@
 #include "asurf_kernels.h"
 #include "asurf_optim.h"
 #include "asurf_pipeline.h"
+#include "asurf_sweep.h"
 #include "asurf_bwd_pipeline.h"
 #include "asurf_legacy.h"
 #include "asurf_reg.h"
@@ -42,17 +44,14 @@ struct MaskLayout {
     int nwz;
     size_t n_bricks;
     size_t coarse_words;
-    size_t off_fine_work, off_fine_live, off_coarse_work, off_coarse_live;
+    size_t off_fine_work, off_fine_live, off_coarse_work, off_coarse_live, off_fine_y, off_fine_z;
     size_t off_cache_a, off_cache_w, off_cache_t, off_cache_n;
     size_t off_rec_v, off_rec_m, off_rec_n, off_rec_neff, off_rec_sws, off_rec_f;
     size_t off_p_items, off_p_citem, off_p_nitems, off_p_cut, off_p_flagged, off_p_counters, off_p_pool;
     size_t off_p_spbase, off_p_spill, off_p_list, off_rec_list;
-    int pool_shard_cap, sp_cap;
+    int pool_shard_cap, sp_cap, list_cap;
     size_t total;
 };
-
-// work voxels per ray the three-kernel forward keeps; longer rays go to the one-kernel path
-constexpr int kPipeC1 = 32;
 
 // Lanes per ray in the walk.  k_walk's duration is that of its longest serial chains until the batch
 // fills the chip several times over: measured on the bench scene (ms per fused step, 1 / 4 / 8 lanes):
@@ -89,6 +88,10 @@ MaskLayout layout_for(const int32_t size[3], int64_t n_rays, int32_t M) {
     off = align_up(off + L.coarse_words * 4, 256);
     L.off_coarse_live = off;
     off = align_up(off + L.coarse_words * 4, 256);
+    L.off_fine_y = off;  // the plane the walk tests, cut along y and along z (k_sweep)
+    off = align_up(off + L.n_bricks * 64, 256);
+    L.off_fine_z = off;
+    off = align_up(off + L.n_bricks * 64, 256);
     const size_t plane = (size_t)(M > 0 ? M : 0) * (size_t)(n_rays > 0 ? n_rays : 0) * 4;
     L.off_cache_a = off;
     off = align_up(off + plane, 256);
@@ -131,8 +134,11 @@ MaskLayout layout_for(const int32_t size[3], int64_t n_rays, int32_t M) {
     L.sp_cap = (int)(4 * nr) + 256;  // spilled work voxels (beyond kPipeC1 per ray), all rays together
     L.off_p_spill = off;             // sp_items | sp_citem | sp_ray
     off = align_up(off + (size_t)L.sp_cap * 3 * 4, 256);
-    L.off_p_list = off;      // dense list of occupied table cells (k_walk -> k_geom)
-    off = align_up(off + iplane, 256);
+    L.off_p_list = off;      // dense list of occupied table cells (k_walk / k_sweep -> k_geom), kListShards segments:
+                             // producer block b fills segment b % kListShards, so a segment holds the cells of at most
+                             // nr / kListShards + 2 * (rays per producer block <= 256) rays
+    L.list_cap = kPipeC1 * (int)((nr + kListShards - 1) / kListShards + 512);
+    off = align_up(off + (size_t)L.list_cap * kListShards * 4, 256);
     L.off_rec_list = off;    // dense list of visited records (k_bwd_seq -> k_bwd_geo)
     off = align_up(off + rplane, 256);
     L.off_p_counters = off;  // n_flagged, spill cursor, kPoolShards pool cursors, 2 list lengths
@@ -202,6 +208,8 @@ KGrid make_kgrid(const asurf_grid* g, const MaskLayout& ML, char* ws, bool use_l
     auto* cl = reinterpret_cast<unsigned int*>(ws + ML.off_coarse_live);
     k.fine = use_live_plane ? fl : fw;
     k.fine_live = fl;
+    k.fine_y = reinterpret_cast<unsigned long long*>(ws + ML.off_fine_y);
+    k.fine_z = reinterpret_cast<unsigned long long*>(ws + ML.off_fine_z);
     k.coarse = use_live_plane ? cl : cw;
     k.nwz = ML.nwz;
     k.coarse_words = (int)ML.coarse_words;
@@ -242,7 +250,17 @@ struct Launch {
     int coarse_in_lds;
     size_t dyn_lds;
     dim3 ray_grid;
+    bool sweep;  // the forward pipeline finds its work voxels with k_sweep instead of k_walk
 };
+
+// k_sweep serves the calls whose walk tests the sparse `work` plane (on the `live` plane nearly every voxel
+// of the shell is flagged and listing them per slab has no advantage over stepping); ASURF_WALK=step and
+// ASURF_DEBUG & 8 (the per-voxel reference walk of the tests) keep k_walk.
+bool want_sweep(bool use_live, const KOpt& o) {
+    if (use_live || (o.debug & 8)) return false;
+    const char* e = getenv("ASURF_WALK");
+    return !(e && strcmp(e, "step") == 0);
+}
 
 // --- optional per-kernel timing (asurf_profile_enable): one hipEvent after every launch ---
 // The state is per host thread (like g_err): a thread that enables profiling times its own calls and reads
@@ -303,13 +321,17 @@ int prepare(const asurf_grid* grid, const asurf_rays* rays, const asurf_render_o
     L.coarse_in_lds = (L.ML.coarse_words * 4 <= kMaxCoarseLds) ? 1 : 0;
     L.dyn_lds = L.coarse_in_lds ? L.ML.coarse_words * 4 : 0;
     L.ray_grid = dim3((unsigned)((rays->n_rays + kBlock - 1) / kBlock));
+    L.sweep = !cuvol && !masks_only && want_sweep(use_live, L.o);
     prof_begin(L.stream);
     hipLaunchKernelGGL(k_build_masks, dim3((unsigned)L.ML.coarse_words), dim3(512), 0, L.stream, L.g,
                        opt->sigma_thresh, cuvol ? 2 : (need_surf ? 1 : 0),  // 2: cuvol cells (asurf_cuvol.h)
                        reinterpret_cast<unsigned long long*>(L.ws + L.ML.off_fine_work),
                        reinterpret_cast<unsigned long long*>(L.ws + L.ML.off_fine_live),
                        reinterpret_cast<unsigned int*>(L.ws + L.ML.off_coarse_work),
-                       reinterpret_cast<unsigned int*>(L.ws + L.ML.off_coarse_live));
+                       reinterpret_cast<unsigned int*>(L.ws + L.ML.off_coarse_live),
+                       L.sweep ? reinterpret_cast<unsigned long long*>(L.ws + L.ML.off_fine_y) : nullptr,
+                       L.sweep ? reinterpret_cast<unsigned long long*>(L.ws + L.ML.off_fine_z) : nullptr,
+                       use_live ? 1 : 0);
     prof_after("k_build_masks", 0, L.stream);
     return launch_error("k_build_masks");
 }
@@ -361,10 +383,34 @@ int run_forward(const Launch& L, const asurf_rays* rays, float* rgb_out, int M, 
         P.shard_cap = L.ML.pool_shard_cap;
         P.C1 = kPipeC1;
         P.list = reinterpret_cast<unsigned*>(L.ws + L.ML.off_p_list);
+        P.list_cap = L.ML.list_cap;
         if (hipMemsetAsync(P.counters, 0, kCtrTotal * sizeof(int), L.stream) != hipSuccess)
             return fail(ASURF_E_LAUNCH, "hipMemsetAsync failed");
         const int seg = walk_segments(Q);
-        if (seg > 1) {
+        if (L.sweep) {
+            int nbmax = 1;
+            for (int k = 0; k < 3; ++k) nbmax = std::max(nbmax, ((L.g.size[k] - 2) >> 3) + 1);
+            int lpr_log2 = 0;
+            while ((1 << lpr_log2) < nbmax) ++lpr_log2;
+            int sweep_threads = kSweepThreads;
+            if (const char* e = getenv("ASURF_SWEEP_THREADS")) {  // measurement
+                const int n = atoi(e);
+                if (n == 64 || n == 128 || n == 256 || n == 512) sweep_threads = n;
+            }
+            int sweep_lanes = kSweepLanes;
+            if (const char* e = getenv("ASURF_SWEEP_LANES")) {  // measurement
+                const int n = atoi(e);
+                if (n == 128 || n == 256 || n == 512 || n == 1024) sweep_lanes = n;
+            }
+            const int rpb = std::max(1, std::min(sweep_lanes >> lpr_log2, kSweepMaxRays));
+            sweep_threads = std::min(sweep_threads, std::max(64, rpb << lpr_log2));
+            const int K = kSweepKeys / rpb;
+            const int task_cap = (rpb << lpr_log2) * kSweepTasksPerLane2 / 2;
+            const size_t lds = (size_t)rpb * sizeof(SweepRay) + (size_t)task_cap * 8 + (size_t)kSweepKeys * 4;
+            const dim3 sgrid((unsigned)((Q + rpb - 1) / rpb));
+            hipLaunchKernelGGL(k_sweep, sgrid, dim3(sweep_threads), lds, L.stream, L.g, L.o, rays->origins,
+                               rays->dirs, Q, P, lpr_log2, rpb, K, record ? 1 : 0, task_cap);
+        } else if (seg > 1) {
             const dim3 seg_grid((unsigned)((Q * seg + kBlock - 1) / kBlock));
 #define ASURF_WALK_SEG(S_)                                                                                   \
     if (L.coarse_in_lds)                                                                                     \
@@ -383,7 +429,7 @@ int run_forward(const Launch& L, const asurf_rays* rays, float* rgb_out, int M, 
         else
             hipLaunchKernelGGL((k_walk<false>), L.ray_grid, dim3(kBlock), 0, L.stream, L.g, L.o,
                                rays->origins, rays->dirs, Q, P, record ? 1 : 0);
-        prof_after("k_walk", 1, L.stream);
+        prof_after(L.sweep ? "k_sweep" : "k_walk", 1, L.stream);
         hipLaunchKernelGGL((k_geom<false>), dim3(kListBlocks), dim3(kBlock), 0, L.stream, L.g,
                            L.o, rays->origins, rays->dirs, Q, P);
         prof_after("k_geom", 1, L.stream);
@@ -398,6 +444,16 @@ int run_forward(const Launch& L, const asurf_rays* rays, float* rgb_out, int M, 
                                rays->dirs, Q, P, rgb_out, M, ca, cw, ct, cn, rv, rm, rn, kRecDepth, rf);
         prof_after("k_comp", 1, L.stream);
         if (int e = launch_error("forward pipeline")) return e;
+        if (L.o.debug & 16) {  // diagnostics: what the pipeline's counters hold after this call
+            int h[kCtrTotal];
+            if (hipStreamSynchronize(L.stream) == hipSuccess &&
+                hipMemcpy(h, P.counters, sizeof(h), hipMemcpyDeviceToHost) == hipSuccess) {
+                long long pool = 0;
+                for (int i = 0; i < kPoolShards; ++i) pool += h[2 + i];
+                fprintf(stderr, "[asurf] rays %lld: handed back %d, spilled voxels %d, table cells %d, candidates %lld\n",
+                        Q, h[0], h[1], [&] { int t = 0; for (int i = 0; i < kListShards; ++i) t += h[kCtrListShard0 + i * kCtrShardStride]; return t; }(), pool);
+            }
+        }
         ray_list = P.flagged;
         n_list = P.counters;
     }

@@ -46,6 +46,10 @@ struct KGrid {
     const unsigned long long* __restrict__ fine;       // plane the walk tests (work or live)
     const unsigned long long* __restrict__ fine_live;  // links + density gate only (counters)
     const unsigned int* __restrict__ coarse;           // one bit per 8^3 brick, for `fine`
+    // `fine` again with the brick's 8 words cut along y resp. z instead of x (asurf_sweep.h): word = the
+    // voxel's index along axis a, bit = 8 * (index along axis a+1) + (index along axis a+2), axes mod 3
+    const unsigned long long* __restrict__ fine_y;
+    const unsigned long long* __restrict__ fine_z;
     int nb[3];   // bricks per axis
     int nwz;     // 32-bit coarse words per (bx,by) row
     int coarse_words;

@@ -33,7 +33,8 @@ namespace asurf {
 __global__ void __launch_bounds__(512)
 k_build_masks(KGrid g, float sigma_thresh, int need_surf, unsigned long long* fine_work,
               unsigned long long* fine_live, unsigned int* coarse_work,
-              unsigned int* coarse_live) {
+              unsigned int* coarse_live, unsigned long long* fine_y, unsigned long long* fine_z,
+              int orient_live) {
     const int t = threadIdx.x;
     const int lx = t >> 6, ly = (t >> 3) & 7, lz = t & 7;
     const int wz = blockIdx.x % g.nwz;
@@ -41,6 +42,7 @@ k_build_masks(KGrid g, float sigma_thresh, int need_surf, unsigned long long* fi
     const int by = bxy % g.nb[1];
     const int bx = bxy / g.nb[1];
     __shared__ unsigned s_work[8], s_live[8];
+    __shared__ unsigned char s_flag[512];  // the plane the sweep tests, one byte per voxel of the brick
     unsigned word_work = 0, word_live = 0;
     for (int bi = 0; bi < 32; ++bi) {
         const int bz = wz * 32 + bi;
@@ -92,14 +94,26 @@ k_build_masks(KGrid g, float sigma_thresh, int need_surf, unsigned long long* fi
             }
         }
         const unsigned long long bw = __ballot(work), bl = __ballot(live);
+        const size_t brick = ((size_t)bx * g.nb[1] + by) * g.nb[2] + bz;
         if ((t & 63) == 0) {
-            const size_t brick = ((size_t)bx * g.nb[1] + by) * g.nb[2] + bz;
             fine_work[brick * 8 + lx] = bw;
             fine_live[brick * 8 + lx] = bl;
             s_work[lx] = bw != 0;
             s_live[lx] = bl != 0;
         }
+        if (fine_y) s_flag[t] = (orient_live ? live : work) ? 1 : 0;
         __syncthreads();
+        if (fine_y) {
+            // the same 512 bits cut along y and along z: wave w gathers the voxels whose y (z) index is w,
+            // lane = 8 * (next axis) + (axis after that), cyclically (y: z, x; z: x, y)
+            const int w = t >> 6, l = t & 63;
+            const unsigned long long by_ = __ballot(s_flag[((l & 7) << 6) | (w << 3) | (l >> 3)] != 0);
+            const unsigned long long bz_ = __ballot(s_flag[((l >> 3) << 6) | ((l & 7) << 3) | w] != 0);
+            if (l == 0) {
+                fine_y[brick * 8 + w] = by_;
+                fine_z[brick * 8 + w] = bz_;
+            }
+        }
         if (t == 0) {
             unsigned aw = 0, al = 0;
 #pragma unroll
@@ -374,11 +388,14 @@ __device__ __forceinline__ bool live_test(const KGrid& g, const Walk& w) {
 }
 
 // all 8 corner links present?  (only needed for the backward loop quirk, surf_trav.cu:1925-1937)
-__device__ __forceinline__ bool links_present(const KGrid& g, const Walk& w) {
-    if (w.vx + 1 >= g.size[0] || w.vy + 1 >= g.size[1] || w.vz + 1 >= g.size[2]) return false;
-    const int32_t* p = g.links + ((size_t)w.vx * g.offx + (size_t)w.vy * g.offy + w.vz);
+__device__ __forceinline__ bool links_present_at(const KGrid& g, int vx, int vy, int vz) {
+    if (vx + 1 >= g.size[0] || vy + 1 >= g.size[1] || vz + 1 >= g.size[2]) return false;
+    const int32_t* p = g.links + ((size_t)vx * g.offx + (size_t)vy * g.offy + vz);
     return (p[0] | p[1] | p[g.offy] | p[g.offy + 1] | p[g.offx] | p[g.offx + 1] |
             p[g.offx + g.offy] | p[g.offx + g.offy + 1]) >= 0;
+}
+__device__ __forceinline__ bool links_present(const KGrid& g, const Walk& w) {
+    return links_present_at(g, w.vx, w.vy, w.vz);
 }
 
 // ------------------------------------------------------------------------------------
@@ -402,22 +419,117 @@ __device__ __forceinline__ int pack_voxel(int x, int y, int z) { return (x << 20
 
 // Entry/exit times are recomputed from the voxel coordinates with the DDA's own expressions
 // (surf_trav.cu:162-184), so they are bit-identical to what the walk saw.
-__device__ __forceinline__ void load_voxel(const KGrid& g, const Ray& r, int packed, Vox& v) {
-    v.vx = packed >> 20;
-    v.vy = (packed >> 10) & 1023;
-    v.vz = packed & 1023;
-    {
-        const float tc0 = ((float)(r.d[0] > 0.f ? v.vx : v.vx + 1) - r.o[0]) / r.d[0];
-        const float tc1 = ((float)(r.d[1] > 0.f ? v.vy : v.vy + 1) - r.o[1]) / r.d[1];
-        const float tc2 = ((float)(r.d[2] > 0.f ? v.vz : v.vz + 1) - r.o[2]) / r.d[2];
-        v.t_close = fmaxf(fmaxf(fmaxf(tc0, tc1), tc2), 0.f);
-        const float tf0 = ((float)(r.d[0] > 0.f ? v.vx + 1 : v.vx) - r.o[0]) / r.d[0];
-        const float tf1 = ((float)(r.d[1] > 0.f ? v.vy + 1 : v.vy) - r.o[1]) / r.d[1];
-        const float tf2 = ((float)(r.d[2] > 0.f ? v.vz + 1 : v.vz) - r.o[2]) / r.d[2];
-        v.t_far = fminf(fminf(tf0, tf1), tf2);
+__device__ __forceinline__ void voxel_times(const Ray& r, int vx, int vy, int vz, float* tc, float* tf) {
+    tc[0] = ((float)(r.d[0] > 0.f ? vx : vx + 1) - r.o[0]) / r.d[0];
+    tc[1] = ((float)(r.d[1] > 0.f ? vy : vy + 1) - r.o[1]) / r.d[1];
+    tc[2] = ((float)(r.d[2] > 0.f ? vz : vz + 1) - r.o[2]) / r.d[2];
+    tf[0] = ((float)(r.d[0] > 0.f ? vx + 1 : vx) - r.o[0]) / r.d[0];
+    tf[1] = ((float)(r.d[1] > 0.f ? vy + 1 : vy) - r.o[1]) / r.d[1];
+    tf[2] = ((float)(r.d[2] > 0.f ? vz + 1 : vz) - r.o[2]) / r.d[2];
+}
+
+// Rays whose walk the closed-form tests below describe: finite origin, direction and bounds.  A ZERO direction
+// component is fine: its plane times are +-inf (or NaN, which the reference's fminf / fmaxf / == ignore, i.e.
+// "never crossed"; walk_visits reads a NaN the same way).  With -0 the axis is simply never stepped; with +0
+// the reference steps down that axis at t = -inf until it leaves the grid and every voxel it sees has
+// t_close = +inf (no sample): the closed form keeps the start voxel only, which yields no sample either.
+__device__ __forceinline__ bool ray_is_regular(const Ray& r) {
+    bool ok = true;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) ok = ok && (fabsf(r.d[k]) < 3.0e38f) && (fabsf(r.o[k]) < 3.0e38f);
+    return ok && (fabsf(r.tmin) < 3.0e38f) && (fabsf(r.tmax) < 3.0e38f);
+}
+
+// first voxel of the walk (surf_trav.cu:75-79)
+__device__ __forceinline__ void walk_start(const KGrid& g, const Ray& r, int* n0) {
+#pragma unroll
+    for (int k = 0; k < 3; ++k) n0[k] = min(max((int)fmaf(r.tmin, r.d[k], r.o[k]), 0), g.size[k] - 2);
+}
+
+// Does the reference's walk (surf_trav.cu:86-197) visit voxel v?  The walk is a three-way merge: per axis
+// the far-plane crossing times of the successive indices form an increasing sequence (the same float
+// expression of the plane index however it is reached), each step takes the smallest pending one (equal
+// times: the lowest axis), and it stops at the first step whose time exceeds tmax or that leaves the
+// lattice.  A merge passes through the state v exactly when every crossing that leads to v -- on an axis
+// where v differs from the start voxel n0, the near plane of v -- comes before every crossing that leads
+// past it -- the far planes of v on the other axes -- in (time, axis) order; v is then entered at the
+// latest of those near-plane times, which must not exceed tmax.  tc / tf: voxel_times(v).
+// *t_entry = that time (tmin for the start voxel).
+__device__ __forceinline__ bool walk_visits(const Ray& r, const int* n0, const int* v, const float* tc_in,
+                                            const float* tf_in, float* t_entry) {
+    bool ok = true;
+    bool moved[3];
+    float tc[3], tf[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {  // 0 / 0 on an axis the ray does not move along: a crossing that never comes
+        tc[a] = (tc_in[a] != tc_in[a]) ? -INFINITY : tc_in[a];
+        tf[a] = (tf_in[a] != tf_in[a]) ? INFINITY : tf_in[a];
     }
-    struct { int vx, vy, vz; } w = {v.vx, v.vy, v.vz};
-    const int32_t* p = g.links + ((size_t)w.vx * g.offx + (size_t)w.vy * g.offy + w.vz);
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        const int dlt = (r.d[a] > 0.f) ? v[a] - n0[a] : n0[a] - v[a];
+        ok = ok && (dlt >= 0);
+        moved[a] = dlt > 0;
+    }
+    float te = r.tmin;
+    bool any = false;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+#pragma unroll
+        for (int b = 0; b < 3; ++b) {
+            if (a == b) continue;
+            const bool before = (tc[a] < tf[b]) || (tc[a] == tf[b] && a < b);
+            ok = ok && (!moved[a] || before);
+        }
+        te = (moved[a] && (!any || tc[a] > te)) ? tc[a] : te;
+        any = any || moved[a];
+    }
+    *t_entry = te;
+    return ok && (!any || te <= r.tmax);
+}
+
+// The reference's BACKWARD loop adds step_size to t after a voxel with a missing corner link before it tests
+// t <= tmax (surf_trav.cu:1925-1937), so it may stop up to step_size before the forward loop does.  Is the
+// visited voxel v cut off that way, i.e. does the walk pass, before v, through a voxel with a missing link
+// whose exit time T satisfies T + step_size > tmax?  Exit times grow along the walk, so only the voxels
+// right before v matter: the walk is retraced from v -- the predecessor lies across the near plane crossed
+// last, in (time, axis) order -- while T + step_size > tmax.
+__device__ __forceinline__ bool walk_cut_before(const KGrid& g, const Ray& r, float step_size, const int* n0,
+                                                const int* v, const float* tc_v) {
+    int c[3] = {v[0], v[1], v[2]};
+    float tc[3] = {tc_v[0], tc_v[1], tc_v[2]};
+    for (int guard = 0; guard < 4096; ++guard) {
+        int best = -1;
+        float T = 0.f;
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            if (c[a] != n0[a] && (best < 0 || tc[a] >= T)) {  // >=: equal times, the higher axis came later
+                best = a;
+                T = tc[a];
+            }
+        }
+        if (best < 0) return false;               // reached the start voxel
+        if (!(T + step_size > r.tmax)) return false;
+        // (indexing r.d / c by `best` would put them in scratch: select instead)
+        const float o_b = best == 0 ? r.o[0] : (best == 1 ? r.o[1] : r.o[2]);
+        const float d_b = best == 0 ? r.d[0] : (best == 1 ? r.d[1] : r.d[2]);
+        const int s = (d_b > 0.f) ? 1 : -1;
+        const int p0 = c[0] - (best == 0 ? s : 0), p1 = c[1] - (best == 1 ? s : 0), p2 = c[2] - (best == 2 ? s : 0);
+        if (!links_present_at(g, p0, p1, p2)) return true;
+        c[0] = p0;
+        c[1] = p1;
+        c[2] = p2;
+        const int c_b = best == 0 ? p0 : (best == 1 ? p1 : p2);
+        const float tcn = ((float)(d_b > 0.f ? c_b : c_b + 1) - o_b) / d_b;
+        tc[0] = best == 0 ? tcn : tc[0];
+        tc[1] = best == 1 ? tcn : tc[1];
+        tc[2] = best == 2 ? tcn : tc[2];
+    }
+    return false;
+}
+
+__device__ __forceinline__ void load_voxel_links(const KGrid& g, Vox& v) {
+    const int32_t* p = g.links + ((size_t)v.vx * g.offx + (size_t)v.vy * g.offy + v.vz);
     v.lk[0] = p[0];
     v.lk[1] = p[1];
     v.lk[2] = p[g.offy];
@@ -426,6 +538,14 @@ __device__ __forceinline__ void load_voxel(const KGrid& g, const Ray& r, int pac
     v.lk[5] = p[g.offx + 1];
     v.lk[6] = p[g.offx + g.offy];
     v.lk[7] = p[g.offx + g.offy + 1];
+}
+
+// the corner values and the cubic, once the links are there
+__device__ __forceinline__ void load_voxel_values(const KGrid& g, const Ray& r, const float* tc, const float* tf,
+                                                  Vox& v) {
+    v.t_close = fmaxf(fmaxf(fmaxf(tc[0], tc[1]), tc[2]), 0.f);
+    v.t_far = fminf(fminf(tf[0], tf[1]), tf[2]);
+    struct { int vx, vy, vz; } w = {v.vx, v.vy, v.vz};
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
         v.dens[i] = g.density[v.lk[i]];
@@ -446,6 +566,16 @@ __device__ __forceinline__ void load_voxel(const KGrid& g, const Ray& r, int pac
         v.smin = fminf(v.smin, v.surf[i]);
         v.smax = fmaxf(v.smax, v.surf[i]);
     }
+}
+
+__device__ __forceinline__ void load_voxel(const KGrid& g, const Ray& r, int packed, Vox& v) {
+    v.vx = packed >> 20;
+    v.vy = (packed >> 10) & 1023;
+    v.vz = packed & 1023;
+    float tc[3], tf[3];
+    voxel_times(r, v.vx, v.vy, v.vz, tc, tf);
+    load_voxel_links(g, v);
+    load_voxel_values(g, r, tc, tf, v);
 }
 
 // sample position of root st inside the voxel; false when outside [0,1]^3 (surf_trav.cu:322-340)

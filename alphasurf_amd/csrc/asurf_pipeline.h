@@ -48,9 +48,17 @@ __device__ __forceinline__ void cand_put(CandRec& dst, const CandRec& src, bool 
 
 // The candidate pool is cut into shards with their own cursors so that the allocating
 // atomics of k_geom do not serialise on one address.
+// work voxels per ray the table keeps (lane-coalesced planes); the rest of a longer ray goes to the spill list
+constexpr int kPipeC1 = 32;
 constexpr int kPoolShards = 256;
-constexpr int kCtrList = 2 + kPoolShards;
-constexpr int kCtrTotal = kCtrList + 2;
+constexpr int kCtrList = 2 + kPoolShards;   // [kCtrList + 1]: entries in the backward's list
+// The dense list of table cells is cut into shards too (producer block b appends to shard b % kListShards, one
+// atomic per block): 4 * 10^4 blocks adding to ONE address took 0.3 ms of k_sweep's 0.5 (each add is a round
+// trip to the memory side, ~8 ns apiece when they queue on one line).  Counters sit 64 bytes apart.
+constexpr int kListShards = 16;
+constexpr int kCtrShardStride = 16;
+constexpr int kCtrListShard0 = kCtrList + 2;
+constexpr int kCtrTotal = kCtrListShard0 + kListShards * kCtrShardStride;
 constexpr int kListRayBits = 27;  // rays per call < 2^27 for the list-driven kernels
 // The kernels that work through a dense list are launched with a fixed number of blocks and
 // stride over it: the list length is only known on the device, and tens of thousands of
@@ -69,7 +77,9 @@ struct PipeBuf {
     int* flagged;    // [Q] compacted ids of the rays handed back
     int* counters;   // [0] n_flagged, [1] spill cursor, [2 .. 2+kPoolShards) pool cursors,
                      // [kCtrList] entries in `list`, [kCtrList + 1] entries in the backward's list
-    unsigned* list;  // dense list of the occupied (slot, ray) cells of `items`: slot << 27 | ray
+    unsigned* list;  // dense list of the occupied (slot, ray) cells of `items`: slot << 27 | ray; kListShards
+                     // segments of list_cap cells
+    int list_cap;
     CandRec* pool;
     int shard_cap;   // records per pool shard
     int sp_cap;
@@ -183,7 +193,9 @@ k_walk(KGrid g, KOpt o, const float* __restrict__ origins, const float* __restri
         wave_excl_scan(nt, &wave_total);
         if (wave_total > 0) {
             int base0 = 0;
-            if ((tid & 63) == 0) base0 = atomicAdd(&P.counters[kCtrList], wave_total);
+            const int shard = blockIdx.x % kListShards;
+            if ((tid & 63) == 0)
+                base0 = shard * P.list_cap + atomicAdd(&P.counters[kCtrListShard0 + shard * kCtrShardStride], wave_total);
             base0 = __shfl(base0, 0);
             const unsigned long long below = (1ull << (tid & 63)) - 1ull;
             for (int j = 0; __any(nt > j); ++j) {
@@ -382,7 +394,9 @@ k_walk_seg(KGrid g, KOpt o, const float* __restrict__ origins, const float* __re
         wave_excl_scan(nt, &wave_total);
         if (wave_total > 0) {
             int base0 = 0;
-            if (lane == 0) base0 = atomicAdd(&P.counters[kCtrList], wave_total);
+            const int shard = blockIdx.x % kListShards;
+            if (lane == 0)
+                base0 = shard * P.list_cap + atomicAdd(&P.counters[kCtrListShard0 + shard * kCtrShardStride], wave_total);
             base0 = __shfl(base0, 0);
             const unsigned long long below = (1ull << lane) - 1ull;
             for (int j = 0; __any(nt > j); ++j) {
@@ -404,8 +418,22 @@ template <bool SPILL>
 __global__ void __launch_bounds__(kBlock, ASURF_GEOM_WAVES)
 k_geom(KGrid g, KOpt o, const float* __restrict__ origins, const float* __restrict__ dirs,
        long long Q, PipeBuf P) {
-    const int n_list = SPILL ? min(P.counters[1], P.sp_cap) : P.counters[kCtrList];
     const int lane = threadIdx.x & 63;
+    // the table cells come as kListShards segments: their lengths' running sums (wave-uniform) turn a position in the
+    // concatenation into (segment, offset)
+    int seg_end[kListShards];
+    int n_list;
+    if constexpr (SPILL) {
+        n_list = min(P.counters[1], P.sp_cap);
+    } else {
+        int acc = 0;
+#pragma unroll
+        for (int sh = 0; sh < kListShards; ++sh) {
+            acc += min(P.counters[kCtrListShard0 + sh * kCtrShardStride], P.list_cap);
+            seg_end[sh] = acc;
+        }
+        n_list = acc;
+    }
     const unsigned wave_id = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
     const int stride = (int)gridDim.x * kBlock;
     unsigned turn = 0;
@@ -422,7 +450,13 @@ k_geom(KGrid g, KOpt o, const float* __restrict__ origins, const float* __restri
             q = (qq >= 0) ? qq : 0;
             if (mine) packed_voxel = P.sp_items[entry];
         } else {
-            const unsigned e = mine ? P.list[i] : 0u;
+            int sh = 0;
+#pragma unroll
+            for (int k = 0; k < kListShards - 1; ++k) sh += (i >= seg_end[k]) ? 1 : 0;
+            int seg0 = 0;  // seg_end[sh - 1]
+#pragma unroll
+            for (int k = 0; k < kListShards - 1; ++k) seg0 = (sh == k + 1) ? seg_end[k] : seg0;
+            const unsigned e = mine ? P.list[(size_t)sh * P.list_cap + (i - seg0)] : 0u;
             q = (long long)(e & ((1u << kListRayBits) - 1u));
             entry = (long long)(e >> kListRayBits) * Q + q;
             mine = mine && (P.n_items[q] >= 0);  // < 0: ray handed back to the one-kernel path
