@@ -392,18 +392,11 @@ int run_forward(const Launch& L, const asurf_rays* rays, float* rgb_out, int M, 
             for (int k = 0; k < 3; ++k) nbmax = std::max(nbmax, ((L.g.size[k] - 2) >> 3) + 1);
             int lpr_log2 = 0;
             while ((1 << lpr_log2) < nbmax) ++lpr_log2;
-            int sweep_threads = kSweepThreads;
-            if (const char* e = getenv("ASURF_SWEEP_THREADS")) {  // measurement
-                const int n = atoi(e);
-                if (n == 64 || n == 128 || n == 256 || n == 512) sweep_threads = n;
-            }
-            int sweep_lanes = kSweepLanes;
-            if (const char* e = getenv("ASURF_SWEEP_LANES")) {  // measurement
-                const int n = atoi(e);
-                if (n == 128 || n == 256 || n == 512 || n == 1024) sweep_lanes = n;
-            }
-            const int rpb = std::max(1, std::min(sweep_lanes >> lpr_log2, kSweepMaxRays));
-            sweep_threads = std::min(sweep_threads, std::max(64, rpb << lpr_log2));
+            // rays per block from the (ray, brick layer) pairs a block takes; threads from the measured optimum (the
+            // pairs are strided over them): 256 threads x 16 rays at 256^3 -- with 512 the phases that occupy one
+            // wave leave seven waiting (0.50 ms against 0.35), with 128 a block takes too many rounds (0.39)
+            const int rpb = std::max(1, std::min(kSweepLanes >> lpr_log2, kSweepMaxRays));
+            const int sweep_threads = std::min(kSweepThreads, std::max(64, rpb << lpr_log2));
             const int K = kSweepKeys / rpb;
             const int task_cap = (rpb << lpr_log2) * kSweepTasksPerLane2 / 2;
             const size_t lds = (size_t)rpb * sizeof(SweepRay) + (size_t)task_cap * 8 + (size_t)kSweepKeys * 4;

@@ -46,9 +46,10 @@ constexpr int kSweepKeys = 2048;    // entries of all rays of a block kept in LD
 constexpr int kSweepMaxRays = 32;   // rays per block
 constexpr unsigned kSweepCutBit = 1u << 30;   // key flag: the reference's backward pass stops before this voxel
 constexpr unsigned kSweepDropped = 0xffffffffu;  // key of an entry the exact test rejected
-// tasks per (ray, brick layer) pair a block has room for: 2 x 2 bricks at most unless a footprint straddles a third
-// brick; a block that runs out hands its rays back
-constexpr int kSweepTasksPerLane2 = 5;  // x 1/2  // 2 x 2 bricks per layer, rarely 3 x 3; beyond: handed back
+// tasks per (ray, brick layer) pair a block has room for, x 1/2: a pair touches 2 x 2 bricks at most unless its
+// footprint straddles a third one, and rarely are all of them occupied; a block that runs out takes its rays in
+// four passes (9 / 4 <= 5 / 2)
+constexpr int kSweepTasksPerLane2 = 5;
 
 struct SweepRay {  // 144 bytes
     float o[3], tmin;           // the ray in grid coordinates (setup_ray), as the reference's walk sees it
@@ -174,12 +175,17 @@ k_sweep(KGrid g, KOpt o, const float* __restrict__ origins, const float* __restr
         s_cnt[tid] = 0;
     }
     __syncthreads();
-    if (o.debug & 32) return;  // timing probes (results invalid)
 
+    // Phases 1 and 2 run once over all rays of the block; if the task list would not hold them (scenes where
+    // most bricks hold a flagged voxel) they run again in four passes over a quarter of the rays each, which
+    // fits whatever the scene: (pairs per block / 4) x 9 bricks <= task_cap.
+    int passes = 1;
+    for (int pass = 0; pass < passes; ++pass) {
+    const int r_lo = (pass * rpb) / passes, r_hi = ((pass + 1) * rpb) / passes;
     // ---- phase 1: (ray, brick layer) -> tasks ----
     for (int lt = tid; lt < (rpb << lpr_log2); lt += nthreads) {
         const int rl = lt >> lpr_log2, A = lt & ((1 << lpr_log2) - 1);
-        {
+        if (rl >= r_lo && rl < r_hi) {
             const SweepRay R = s_ray[rl];
             if (R.state == 1 && A < R.na) {
                 float L = (A == 0) ? -1e30f : (float)(8 * A) - kEps;
@@ -211,7 +217,14 @@ k_sweep(KGrid g, KOpt o, const float* __restrict__ origins, const float* __restr
         }
     }
     __syncthreads();
-    if (o.debug & 64) return;
+    if (passes == 1 && rpb >= 2 && s_ntask > task_cap) {  // (block-uniform) start over, a quarter of the rays at a time
+        __syncthreads();
+        if (tid == 0) s_ntask = 0;
+        __syncthreads();
+        passes = min(4, rpb);
+        pass = -1;
+        continue;
+    }
 
     // ---- phase 2: lane = task.  The brick's 8 words (one 64-byte line); the ray's (b, c) position at the 9 slab
     // planes, each shared by two slabs; per slab the rectangle mask of the cells between two planes ----
@@ -267,7 +280,11 @@ k_sweep(KGrid g, KOpt o, const float* __restrict__ origins, const float* __restr
         }
     }
     __syncthreads();
-    if (o.debug & 128) return;
+    if (pass + 1 < passes) {
+        if (tid == 0) s_ntask = 0;
+        __syncthreads();
+    }
+    }  // passes
 
     // ---- phase 3: exact membership, lane = entry.  s_eend: inclusive prefix of the rays' FOUND counts ----
     if (tid < 64) {
@@ -330,7 +347,6 @@ k_sweep(KGrid g, KOpt o, const float* __restrict__ origins, const float* __restr
         s_key[rl * K + slot] = key;
     }
     __syncthreads();
-    if (o.debug & 256) return;
 
     // ---- phase 4: per ray, counts and allocations ----
     if (tid < rpb) {
@@ -375,8 +391,6 @@ k_sweep(KGrid g, KOpt o, const float* __restrict__ origins, const float* __restr
         const int cells = __shfl(ci, 63);
         if (tid == 0) {
             const int shard = blockIdx.x % kListShards;
-            if (o.debug & 1024) s_lbase = 0;  // timing probe
-            else
             s_lbase = shard * P.list_cap +
                       (cells > 0 ? atomicAdd(&P.counters[kCtrListShard0 + shard * kCtrShardStride], cells) : 0);
         }

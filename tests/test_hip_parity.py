@@ -310,10 +310,49 @@ def test_cubic_root_grad_kernel(hip, oracle):
     assert (np.abs(g - go) / scale).max() < 1e-3
 
 
+def test_sweep_dense_scene_and_long_rays(hip, monkeypatch):
+    """k_sweep where its LDS budgets are exceeded: a scene in which nearly every brick holds a work voxel (the
+    task list overflows: the block falls back to four passes) and rays that run inside the shell for most of
+    their length (more entries than a ray's key buffer holds: handed to the one-kernel path).  Reference: the
+    per-voxel walk."""
+    from alphasurf_amd import synth
+    rs = np.random.RandomState(3)
+    reso = 64
+    sc = synth.make_sparse_scene(reso, 4, seed=9, band=40.0, dilate=1)   # everything active
+    n = sc["density"].shape[0]
+    # a surface field that changes sign between most neighbouring vertices: a work voxel almost everywhere
+    sc["surface"] = (rs.rand(n, 1).astype(np.float32) - 0.5)
+    sc["density"] = (0.5 + 0.1 * rs.randn(n, 1)).astype(np.float32)
+    o1, d1 = synth.random_rays(3000, 21)
+    # rays along grid diagonals and almost along an axis: long runs through occupied voxels
+    o2 = np.tile(np.array([[-1.4, -1.4, -1.4]], np.float32), (200, 1)) + 0.01 * rs.randn(200, 3).astype(np.float32)
+    d2 = np.ones((200, 3), np.float32) + 0.02 * rs.randn(200, 3).astype(np.float32)
+    o3 = np.stack([np.full(200, -1.5), rs.uniform(-0.6, 0.6, 200), rs.uniform(-0.6, 0.6, 200)], 1).astype(np.float32)
+    d3 = np.stack([np.ones(200), 0.01 * rs.randn(200), 0.01 * rs.randn(200)], 1).astype(np.float32)
+    o = np.concatenate([o1, o2, o3])
+    d = np.concatenate([d1, d2, d3])
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    gt = rs.rand(o.shape[0], 3).astype(np.float32)
+    opts = dict(OPTION_SETS["syn_yaml"], step_size=0.5)
+    fused = dict(lambda_l2=1.0, lambda_l_entropy=1e-3)
+    monkeypatch.setenv("ASURF_DEBUG", "8")
+    monkeypatch.setenv("ASURF_WALK_SEG", "1")
+    rgb_ref, g_ref = hip.render_fused(sc, o, d, opts, gt, fused)
+    monkeypatch.delenv("ASURF_DEBUG")
+    monkeypatch.delenv("ASURF_WALK_SEG")
+    rgb, g = hip.render_fused(sc, o, d, opts, gt, fused)
+    # (the rays handed to the one-kernel path sum their colours in another order than k_comp: an ulp)
+    assert np.abs(rgb - rgb_ref).max() <= 5e-7, np.abs(rgb - rgb_ref).max()
+    assert (g["mask"] == g_ref["mask"]).all()
+    for k in ("sh", "density", "surface"):
+        grad_close(g[k], g_ref[k], 1e-5, f"dense scene grad_{k}")
+
+
 def test_brick_skipping_is_exact(hip, monkeypatch):
-    """k_walk jumps over empty 8^3 bricks; the work-voxel lists must be those of the per-voxel
-    walk.  RGB is a deterministic function of that list, so it must match bit for bit -- on
-    random rays and on rays built to graze voxel planes, brick corners and lattice points."""
+    """k_sweep finds a ray's work voxels in closed form and k_walk jumps over empty 8^3 bricks; their
+    work-voxel lists must be those of the per-voxel walk.  RGB is a deterministic function of that list,
+    so it must match bit for bit -- on random rays and on rays built to graze voxel planes, brick corners
+    and lattice points."""
     from alphasurf_amd import synth
     rs = np.random.RandomState(11)
     for reso, seed in ((48, 5), (96, 6), (130, 7)):
@@ -361,12 +400,16 @@ def test_brick_skipping_is_exact(hip, monkeypatch):
             rgb_ref, g_ref = hip.render_fused(scene, o, d, op, gt, fused)
             monkeypatch.delenv("ASURF_DEBUG")
             monkeypatch.delenv("ASURF_WALK_SEG")
-            # ... against the hierarchical walk with the ray on 1, 2, 4 and 8 lanes (k_walk_seg: every lane but
-            # the first enters its segment at a landing point in the middle of the ray)
-            for seg in ("1", "2", "4", "8"):
-                monkeypatch.setenv("ASURF_WALK_SEG", seg)
+            # ... against the closed-form sweep (the default), and the hierarchical walk with the ray on 1, 2, 4 and
+            # 8 lanes (k_walk_seg: every lane but the first enters its segment at a landing point in the middle of
+            # the ray)
+            for seg in ("sweep", "1", "2", "4", "8"):
+                if seg != "sweep":
+                    monkeypatch.setenv("ASURF_WALK", "step")
+                    monkeypatch.setenv("ASURF_WALK_SEG", seg)
                 rgb, g = hip.render_fused(scene, o, d, op, gt, fused)
-                monkeypatch.delenv("ASURF_WALK_SEG")
+                monkeypatch.delenv("ASURF_WALK", raising=False)
+                monkeypatch.delenv("ASURF_WALK_SEG", raising=False)
                 assert np.array_equal(rgb, rgb_ref), f"reso {reso} {extra} seg {seg}: {np.abs(rgb - rgb_ref).max()}"
                 assert (g["mask"] == g_ref["mask"]).all()
                 for k in ("sh", "density", "surface"):
