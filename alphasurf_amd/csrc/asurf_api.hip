@@ -323,7 +323,8 @@ int prepare(const asurf_grid* grid, const asurf_rays* rays, const asurf_render_o
     L.ray_grid = dim3((unsigned)((rays->n_rays + kBlock - 1) / kBlock));
     L.sweep = !cuvol && !masks_only && want_sweep(use_live, L.o);
     prof_begin(L.stream);
-    hipLaunchKernelGGL(k_build_masks, dim3((unsigned)L.ML.coarse_words), dim3(512), 0, L.stream, L.g,
+    const int nzg = (L.ML.nb[2] + 7) / 8;  // groups of 8 bricks along z
+    hipLaunchKernelGGL(k_build_masks, dim3((unsigned)((size_t)L.ML.nb[0] * L.ML.nb[1] * nzg)), dim3(512), 0, L.stream, L.g,
                        opt->sigma_thresh, cuvol ? 2 : (need_surf ? 1 : 0),  // 2: cuvol cells (asurf_cuvol.h)
                        reinterpret_cast<unsigned long long*>(L.ws + L.ML.off_fine_work),
                        reinterpret_cast<unsigned long long*>(L.ws + L.ML.off_fine_live),
@@ -331,7 +332,7 @@ int prepare(const asurf_grid* grid, const asurf_rays* rays, const asurf_render_o
                        reinterpret_cast<unsigned int*>(L.ws + L.ML.off_coarse_live),
                        L.sweep ? reinterpret_cast<unsigned long long*>(L.ws + L.ML.off_fine_y) : nullptr,
                        L.sweep ? reinterpret_cast<unsigned long long*>(L.ws + L.ML.off_fine_z) : nullptr,
-                       use_live ? 1 : 0);
+                       use_live ? 1 : 0, nzg);
     prof_after("k_build_masks", 0, L.stream);
     return launch_error("k_build_masks");
 }
@@ -423,12 +424,9 @@ int run_forward(const Launch& L, const asurf_rays* rays, float* rgb_out, int M, 
             hipLaunchKernelGGL((k_walk<false>), L.ray_grid, dim3(kBlock), 0, L.stream, L.g, L.o,
                                rays->origins, rays->dirs, Q, P, record ? 1 : 0);
         prof_after(L.sweep ? "k_sweep" : "k_walk", 1, L.stream);
-        hipLaunchKernelGGL((k_geom<false>), dim3(kListBlocks), dim3(kBlock), 0, L.stream, L.g,
-                           L.o, rays->origins, rays->dirs, Q, P);
-        prof_after("k_geom", 1, L.stream);
-        hipLaunchKernelGGL((k_geom<true>), dim3(256), dim3(kBlock), 0, L.stream, L.g, L.o, rays->origins,
+        hipLaunchKernelGGL(k_geom, dim3(kListBlocks), dim3(kBlock), 0, L.stream, L.g, L.o, rays->origins,
                            rays->dirs, Q, P);
-        prof_after("k_geom_spill", 1, L.stream);
+        prof_after("k_geom", 1, L.stream);
         if (cache)
             hipLaunchKernelGGL((k_comp<B, true>), L.ray_grid, dim3(kBlock), 0, L.stream, L.g, L.o,
                                rays->dirs, Q, P, rgb_out, M, ca, cw, ct, cn, rv, rm, rn, kRecDepth, rf);

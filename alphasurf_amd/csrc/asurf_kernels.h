@@ -28,34 +28,48 @@ namespace asurf {
 // ------------------------------------------------------------------------------------
 // Occupancy pyramid
 // ------------------------------------------------------------------------------------
-// grid: nb[0]*nb[1]*nwz blocks of 512 threads; block = one (bx,by) brick column segment of
-// up to 32 bricks along z; thread = one voxel of the current brick.
+// grid: nb[0] * nb[1] * ceil(nb[2] / 8) blocks of 512 threads; block = 8 bricks in a row along z.  Wave w is the
+// row y = 8 by + w of the bricks, its 64 lanes are 64 consecutive z (one 256-byte request per wave and link
+// plane), and the block walks the 8 x-slabs: 8 iterations, no barrier between them.  A ballot is then a run of
+// 64 z for one (x, y); byte j of it belongs to brick j of the row.  The brick words are put together from
+// those bytes: word x (bit 8 y + z) across the waves in LDS, word y (bit 8 z + x) inside the wave over the
+// iterations, word z (bit 8 x + y) per lane over the iterations and across the waves in LDS at the end.
+// (The first version gave a thread one voxel of ONE brick and walked 32 bricks with two barriers each: a chain of
+// 32 dependent round trips of 32-byte pieces, 0.07 ms at 256^3.)  The coarse plane is written as bytes: a
+// block's 8 bricks are one byte of its little-endian 32-bit words.
+__device__ __forceinline__ unsigned long long spread_bits_to_bytes(unsigned b) {  // bit i of a byte -> bit 8 i
+    const unsigned long long x = ((unsigned long long)b * 0x0101010101010101ull) & 0x8040201008040201ull;
+    const unsigned long long lo7 = 0x7f7f7f7f7f7f7f7full;
+    return ((((x & lo7) + lo7) | x) >> 7) & 0x0101010101010101ull;
+}
+
 __global__ void __launch_bounds__(512)
 k_build_masks(KGrid g, float sigma_thresh, int need_surf, unsigned long long* fine_work,
               unsigned long long* fine_live, unsigned int* coarse_work,
               unsigned int* coarse_live, unsigned long long* fine_y, unsigned long long* fine_z,
-              int orient_live) {
+              int orient_live, int nzg) {
     const int t = threadIdx.x;
-    const int lx = t >> 6, ly = (t >> 3) & 7, lz = t & 7;
-    const int wz = blockIdx.x % g.nwz;
-    const int bxy = blockIdx.x / g.nwz;
+    const int ly = t >> 6, l = t & 63;
+    const int zg = blockIdx.x % nzg;
+    const int bxy = blockIdx.x / nzg;
     const int by = bxy % g.nb[1];
     const int bx = bxy / g.nb[1];
-    __shared__ unsigned s_work[8], s_live[8];
-    __shared__ unsigned char s_flag[512];  // the plane the sweep tests, one byte per voxel of the brick
-    unsigned word_work = 0, word_live = 0;
-    for (int bi = 0; bi < 32; ++bi) {
-        const int bz = wz * 32 + bi;
-        if (bz >= g.nb[2]) break;
-        const int x = bx * 8 + lx, y = by * 8 + ly, z = bz * 8 + lz;
+    __shared__ unsigned long long s_xw[64], s_xl[64], s_z[64];  // [x-slab][brick], [x-slab][brick], [brick][lz]
+    if (t < 64) s_xw[t] = s_xl[t] = s_z[t] = 0ull;
+    __syncthreads();
+    const int y = by * 8 + ly, z = zg * 64 + l;
+    const bool inside_yz = y + 1 < g.size[1] && z + 1 < g.size[2];
+    unsigned long long acc_y = 0ull, acc_z = 0ull;
+    for (int lx = 0; lx < 8; ++lx) {
+        const int x = bx * 8 + lx;
         bool live = false, work = false;
-        const bool inside = x + 1 < g.size[0] && y + 1 < g.size[1] && z + 1 < g.size[2];
+        const bool inside = inside_yz && x + 1 < g.size[0];
         const int32_t* p = g.links + ((size_t)x * g.offx + (size_t)y * g.offy + z);
         const int32_t l0 = inside ? p[0] : -1;
-        // most of a sparse grid is empty space: when no cell of the slab has its own vertex (and the surf_trav
+        // most of a sparse grid is empty space: when no cell of the run has its own vertex (and the surf_trav
         // planes need all eight), the other seven loads are skipped for the whole wave
-        const bool slab_dead = need_surf != 2 && __ballot(l0 >= 0) == 0ull;
-        if (inside && !slab_dead) {
+        const bool run_dead = need_surf != 2 && __ballot(l0 >= 0) == 0ull;
+        if (inside && !run_dead) {
             const int32_t l1 = p[1], l2 = p[g.offy], l3 = p[g.offy + 1];
             const int32_t l4 = p[g.offx], l5 = p[g.offx + 1], l6 = p[g.offx + g.offy],
                           l7 = p[g.offx + g.offy + 1];
@@ -80,9 +94,9 @@ k_build_masks(KGrid g, float sigma_thresh, int need_surf, unsigned long long* fi
                         float smin = g.surface[lk[0]], smax = smin;
 #pragma unroll
                         for (int i = 1; i < 8; ++i) {
-                            const float s = g.surface[lk[i]];
-                            smin = fminf(smin, s);
-                            smax = fmaxf(smax, s);
+                            const float sv = g.surface[lk[i]];
+                            smin = fminf(smin, sv);
+                            smax = fmaxf(smax, sv);
                         }
                         work = false;
                         for (int li = 0; li < g.level_set_num; ++li) {
@@ -94,41 +108,42 @@ k_build_masks(KGrid g, float sigma_thresh, int need_surf, unsigned long long* fi
             }
         }
         const unsigned long long bw = __ballot(work), bl = __ballot(live);
-        const size_t brick = ((size_t)bx * g.nb[1] + by) * g.nb[2] + bz;
-        if ((t & 63) == 0) {
-            fine_work[brick * 8 + lx] = bw;
-            fine_live[brick * 8 + lx] = bl;
-            s_work[lx] = bw != 0;
-            s_live[lx] = bl != 0;
+        if ((bw | bl) == 0ull) continue;  // (wave-uniform)
+        if (l < 8) {  // lane j: brick j of the row
+            const unsigned byte_w = (unsigned)(bw >> (8 * l)) & 0xffu, byte_l = (unsigned)(bl >> (8 * l)) & 0xffu;
+            if (byte_w) atomicOr(&s_xw[lx * 8 + l], (unsigned long long)byte_w << (8 * ly));
+            if (byte_l) atomicOr(&s_xl[lx * 8 + l], (unsigned long long)byte_l << (8 * ly));
+            acc_y |= spread_bits_to_bytes(orient_live ? byte_l : byte_w) << lx;
         }
-        if (fine_y) s_flag[t] = (orient_live ? live : work) ? 1 : 0;
-        __syncthreads();
-        if (fine_y) {
-            // the same 512 bits cut along y and along z: wave w gathers the voxels whose y (z) index is w,
-            // lane = 8 * (next axis) + (axis after that), cyclically (y: z, x; z: x, y)
-            const int w = t >> 6, l = t & 63;
-            const unsigned long long by_ = __ballot(s_flag[((l & 7) << 6) | (w << 3) | (l >> 3)] != 0);
-            const unsigned long long bz_ = __ballot(s_flag[((l >> 3) << 6) | ((l & 7) << 3) | w] != 0);
-            if (l == 0) {
-                fine_y[brick * 8 + w] = by_;
-                fine_z[brick * 8 + w] = bz_;
-            }
+        if (orient_live ? live : work) acc_z |= 1ull << (lx * 8 + ly);
+    }
+    if (fine_y && acc_z) atomicOr(&s_z[l], acc_z);
+    __syncthreads();
+    const size_t brick0 = ((size_t)bx * g.nb[1] + by) * g.nb[2] + (size_t)zg * 8;
+    const int nbr = min(8, g.nb[2] - zg * 8);  // bricks of the row that exist
+    if (fine_y && l < nbr) fine_y[(brick0 + l) * 8 + ly] = acc_y;
+    if (t < 64) {
+        const int lx = t >> 3, j = t & 7;
+        if (j < nbr) {
+            fine_work[(brick0 + j) * 8 + lx] = s_xw[t];
+            fine_live[(brick0 + j) * 8 + lx] = s_xl[t];
         }
-        if (t == 0) {
-            unsigned aw = 0, al = 0;
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                aw |= s_work[i];
-                al |= s_live[i];
-            }
-            word_work |= aw << bi;
-            word_live |= al << bi;
-        }
-        __syncthreads();
+        const int j2 = t >> 3, lz = t & 7;
+        if (fine_y && j2 < nbr) fine_z[(brick0 + j2) * 8 + lz] = s_z[t];
     }
     if (t == 0) {
-        coarse_work[blockIdx.x] = word_work;
-        coarse_live[blockIdx.x] = word_live;
+        unsigned cw = 0, cl = 0;
+        for (int j = 0; j < 8; ++j) {
+            unsigned long long aw = 0ull, al = 0ull;
+            for (int lx = 0; lx < 8; ++lx) {
+                aw |= s_xw[lx * 8 + j];
+                al |= s_xl[lx * 8 + j];
+            }
+            cw |= (aw != 0ull ? 1u : 0u) << j;
+            cl |= (al != 0ull ? 1u : 0u) << j;
+        }
+        reinterpret_cast<unsigned char*>(coarse_work)[(size_t)bxy * g.nwz * 4 + zg] = (unsigned char)cw;
+        reinterpret_cast<unsigned char*>(coarse_live)[(size_t)bxy * g.nwz * 4 + zg] = (unsigned char)cl;
     }
 }
 
@@ -917,6 +932,8 @@ k_forward(KGrid g, KOpt o, const float* __restrict__ origins, const float* __res
     int rec_cnt = 0;
     bool rec_over = false;
     int n_pushed = 0, n_drained = 0, rec_cut = 0x7fffffff;
+    // (as the pipeline's fallback this kernel usually finds an empty list: leave before anything is staged)
+    if (ray_list != nullptr && (long long)blockIdx.x * kBlock >= (long long)*n_list) return;
     if constexpr (CLDS) {
         for (int i = tid; i < g.coarse_words; i += kBlock) s_coarse[i] = g.coarse[i];
         __syncthreads();
@@ -1169,6 +1186,14 @@ k_backward(KGrid g, KOpt o, KLoss L, KGrads G, const float* __restrict__ origins
     __shared__ float s_sph[kBlock * kSphPad];
     __shared__ LaneRec s_rec[kBlock];
     const int tid = threadIdx.x;
+    const long long q = (long long)blockIdx.x * kBlock + tid;
+    bool valid = q < Q;
+    if (valid) {
+        if constexpr (REC) valid = rec_n[q] >= 0;
+        else if (ray_filter != nullptr) valid = ray_filter[q] < 0;
+    }
+    // (as the replay's fallback this kernel usually finds no ray to walk: leave before anything is staged)
+    if (ray_filter != nullptr && !__syncthreads_or(valid ? 1 : 0)) return;
     if constexpr (CLDS && !REC) {
         for (int i = tid; i < g.coarse_words; i += kBlock) s_coarse[i] = g.coarse[i];
         __syncthreads();
@@ -1176,12 +1201,6 @@ k_backward(KGrid g, KOpt o, KLoss L, KGrads G, const float* __restrict__ origins
     const float* sph_wave = s_sph + (tid & ~63) * kSphPad;
     const LaneRec* rec_wave = s_rec + (tid & ~63);
 
-    const long long q = (long long)blockIdx.x * kBlock + tid;
-    bool valid = q < Q;
-    if (valid) {
-        if constexpr (REC) valid = rec_n[q] >= 0;
-        else if (ray_filter != nullptr) valid = ray_filter[q] < 0;
-    }
     Ray r;
     r.tmin = 1.f;
     r.tmax = 0.f;

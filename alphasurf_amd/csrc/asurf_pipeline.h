@@ -409,31 +409,25 @@ k_walk_seg(KGrid g, KOpt o, const float* __restrict__ origins, const float* __re
 }
 
 // ------------------------------------------------------------------------------------
-// One work voxel per lane, taken from a dense list: SPILL = false the list of table cells written
-// by k_walk, SPILL = true the spill list.  kListBlocks blocks stride over it.
+// One work voxel per lane, taken from a dense list: the table cells written by k_sweep / k_walk, then the
+// spill list.  kListBlocks blocks stride over it.
 #ifndef ASURF_GEOM_WAVES
 #define ASURF_GEOM_WAVES 3
 #endif
-template <bool SPILL>
 __global__ void __launch_bounds__(kBlock, ASURF_GEOM_WAVES)
 k_geom(KGrid g, KOpt o, const float* __restrict__ origins, const float* __restrict__ dirs,
        long long Q, PipeBuf P) {
     const int lane = threadIdx.x & 63;
     // the table cells come as kListShards segments: their lengths' running sums (wave-uniform) turn a position in the
-    // concatenation into (segment, offset)
+    // concatenation into (segment, offset); the spill list follows them (a launch of its own cost 13 us, empty or not)
     int seg_end[kListShards];
-    int n_list;
-    if constexpr (SPILL) {
-        n_list = min(P.counters[1], P.sp_cap);
-    } else {
-        int acc = 0;
+    int n_cells = 0;
 #pragma unroll
-        for (int sh = 0; sh < kListShards; ++sh) {
-            acc += min(P.counters[kCtrListShard0 + sh * kCtrShardStride], P.list_cap);
-            seg_end[sh] = acc;
-        }
-        n_list = acc;
+    for (int sh = 0; sh < kListShards; ++sh) {
+        n_cells += min(P.counters[kCtrListShard0 + sh * kCtrShardStride], P.list_cap);
+        seg_end[sh] = n_cells;
     }
+    const int n_list = n_cells + min(P.counters[1], P.sp_cap);
     const unsigned wave_id = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
     const int stride = (int)gridDim.x * kBlock;
     unsigned turn = 0;
@@ -443,9 +437,10 @@ k_geom(KGrid g, KOpt o, const float* __restrict__ origins, const float* __restri
         long long entry = 0;
         int packed_voxel = 0;
         bool mine = i < n_list;
-        if constexpr (SPILL) {
-            entry = i;
-            const int qq = mine ? P.sp_ray[i] : -1;
+        const bool SPILL = i >= n_cells;
+        if (SPILL) {
+            entry = i - n_cells;
+            const int qq = mine ? P.sp_ray[entry] : -1;
             mine = (qq >= 0) && (P.n_items[qq] >= 0);
             q = (qq >= 0) ? qq : 0;
             if (mine) packed_voxel = P.sp_items[entry];
@@ -541,7 +536,7 @@ k_geom(KGrid g, KOpt o, const float* __restrict__ origins, const float* __restri
         // one pool allocation per wave: exclusive prefix of the lanes' counts + a single atomic
         int total;
         const int pre = wave_excl_scan(nc, &total);
-        const int shard = (int)((wave_id + turn * 61u + (SPILL ? 101u : 0u)) % kPoolShards);
+        const int shard = (int)((wave_id + turn * 61u) % kPoolShards);
         int base0 = 0;
         if (total > 0) {
             if (lane == 0) base0 = atomicAdd(&P.counters[2 + shard], total);
@@ -560,7 +555,7 @@ k_geom(KGrid g, KOpt o, const float* __restrict__ origins, const float* __restri
             if (nc > 2) P.pool[at + 2] = c2;
             packed = (at << 2) | nc;
         }
-        if constexpr (SPILL) P.sp_citem[entry] = packed;
+        if (SPILL) P.sp_citem[entry] = packed;
         else P.citem[entry] = packed;
     }
 }

@@ -63,7 +63,6 @@ def algorithmic_bytes_per_kernel(n_rays, v_t, v_a, s, D, stat_loss, M):
         "k_sweep": float(24 * n_rays + 32 * v_t),               # ray + 8 links per visited voxel: the search for the
         "k_walk": float(24 * n_rays + 32 * v_t),                # work voxels (k_sweep, or k_walk with ASURF_WALK=step)
         "k_geom": float(64 * v_a),                              # 8 density + 8 surface values
-        "k_geom_spill": 0.0,
         "k_comp": float(12 * n_rays + s * 32 * (1 + D)),        # rgb + corner density/SH rows
         "k_forward_fallback": 0.0,
         "k_bwd_seq": float(24 * n_rays + cache),                # colour cache + rgb_gt + sample cache
