@@ -60,12 +60,23 @@ k_build_masks(KGrid g, float sigma_thresh, int need_surf, unsigned long long* fi
     const int y = by * 8 + ly, z = zg * 64 + l;
     const bool inside_yz = y + 1 < g.size[1] && z + 1 < g.size[2];
     unsigned long long acc_y = 0ull, acc_z = 0ull;
+    // The kernel streams `links` and is as fast as the bytes it keeps in flight (one 256-byte request per wave
+    // would be 2 MB on the whole chip: 1 TB/s at the 2 us such a request takes): all eight slabs' first links
+    // are asked for before the first one is looked at.
+    int32_t l0s[8];
+#pragma unroll
+    for (int lx = 0; lx < 8; ++lx) {
+        const int x = bx * 8 + lx;
+        l0s[lx] = (inside_yz && x + 1 < g.size[0])
+                      ? g.links[(size_t)x * g.offx + (size_t)y * g.offy + z] : -1;
+    }
+#pragma unroll
     for (int lx = 0; lx < 8; ++lx) {
         const int x = bx * 8 + lx;
         bool live = false, work = false;
         const bool inside = inside_yz && x + 1 < g.size[0];
         const int32_t* p = g.links + ((size_t)x * g.offx + (size_t)y * g.offy + z);
-        const int32_t l0 = inside ? p[0] : -1;
+        const int32_t l0 = l0s[lx];
         // most of a sparse grid is empty space: when no cell of the run has its own vertex (and the surf_trav
         // planes need all eight), the other seven loads are skipped for the whole wave
         const bool run_dead = need_surf != 2 && __ballot(l0 >= 0) == 0ull;
