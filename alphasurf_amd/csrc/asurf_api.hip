@@ -48,6 +48,7 @@ struct MaskLayout {
     size_t off_cache_a, off_cache_w, off_cache_t, off_cache_n;
     size_t off_rec_v, off_rec_m, off_rec_n, off_rec_neff, off_rec_sws, off_rec_f;
     size_t off_p_items, off_p_citem, off_p_nitems, off_p_cut, off_p_flagged, off_p_counters, off_p_pool;
+    size_t off_p_cand;  // cand_mask [Q]
     size_t off_p_spbase, off_p_spill, off_p_list, off_rec_list;
     int pool_shard_cap, sp_cap, list_cap;
     size_t total;
@@ -131,6 +132,8 @@ MaskLayout layout_for(const int32_t size[3], int64_t n_rays, int32_t M) {
     off = align_up(off + nr * 4, 256);
     L.off_p_spbase = off;
     off = align_up(off + nr * 4, 256);
+    L.off_p_cand = off;
+    off = align_up(off + nr * 8, 256);
     L.sp_cap = (int)(4 * nr) + 256;  // spilled work voxels (beyond kPipeC1 per ray), all rays together
     L.off_p_spill = off;             // sp_items | sp_citem | sp_ray
     off = align_up(off + (size_t)L.sp_cap * 3 * 4, 256);
@@ -381,6 +384,7 @@ int run_forward(const Launch& L, const asurf_rays* rays, float* rgb_out, int M, 
         P.sp_ray = P.sp_citem + L.ML.sp_cap;
         P.sp_cap = L.ML.sp_cap;
         P.pool = reinterpret_cast<CandRec*>(L.ws + L.ML.off_p_pool);
+        P.cand_mask = reinterpret_cast<unsigned long long*>(L.ws + L.ML.off_p_cand);
         P.shard_cap = L.ML.pool_shard_cap;
         P.C1 = kPipeC1;
         P.list = reinterpret_cast<unsigned*>(L.ws + L.ML.off_p_list);

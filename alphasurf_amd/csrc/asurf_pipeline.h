@@ -50,6 +50,7 @@ __device__ __forceinline__ void cand_put(CandRec& dst, const CandRec& src, bool 
 // atomics of k_geom do not serialise on one address.
 // work voxels per ray the table keeps (lane-coalesced planes); the rest of a longer ray goes to the spill list
 constexpr int kPipeC1 = 32;
+static_assert(kPipeC1 <= 32, "PipeBuf::cand_mask: one bit per table slot");
 constexpr int kPoolShards = 256;
 constexpr int kCtrList = 2 + kPoolShards;   // [kCtrList + 1]: entries in the backward's list
 // The dense list of table cells is cut into shards too (producer block b appends to shard b % kListShards, one
@@ -81,6 +82,9 @@ struct PipeBuf {
                      // segments of list_cap cells
     int list_cap;
     CandRec* pool;
+    // per ray: which of its work voxels yielded a candidate (bit s: the s-th one, table slots first, then the spill
+    // slice; bit 63: one beyond the 63rd did) -- k_geom ORs the bits in, k_comp visits those only
+    unsigned long long* cand_mask;
     int shard_cap;   // records per pool shard
     int sp_cap;
     int C1;
@@ -184,6 +188,7 @@ k_walk(KGrid g, KOpt o, const float* __restrict__ origins, const float* __restri
     if (valid) {
         P.n_items[q] = cnt;
         P.cut[q] = cutv;
+        P.cand_mask[q] = 0ull;
     }
     // dense list of this wave's table cells, slot-major so that neighbouring list entries are
     // neighbouring rays at the same depth (k_geom works one entry per lane)
@@ -386,6 +391,7 @@ k_walk_seg(KGrid g, KOpt o, const float* __restrict__ origins, const float* __re
     if (valid && seg == 0) {
         P.n_items[q] = cnt;
         P.cut[q] = cutv;
+        P.cand_mask[q] = 0ull;
     }
     // dense list of this wave's table cells (as k_walk)
     {
@@ -438,12 +444,16 @@ k_geom(KGrid g, KOpt o, const float* __restrict__ origins, const float* __restri
         int packed_voxel = 0;
         bool mine = i < n_list;
         const bool SPILL = i >= n_cells;
+        int slot = 0;  // ordinal of the voxel among the ray's work voxels
         if (SPILL) {
             entry = i - n_cells;
             const int qq = mine ? P.sp_ray[entry] : -1;
             mine = (qq >= 0) && (P.n_items[qq] >= 0);
             q = (qq >= 0) ? qq : 0;
-            if (mine) packed_voxel = P.sp_items[entry];
+            if (mine) {
+                packed_voxel = P.sp_items[entry];
+                slot = P.C1 + (int)(entry - P.sp_base[q]);
+            }
         } else {
             int sh = 0;
 #pragma unroll
@@ -453,7 +463,8 @@ k_geom(KGrid g, KOpt o, const float* __restrict__ origins, const float* __restri
             for (int k = 0; k < kListShards - 1; ++k) seg0 = (sh == k + 1) ? seg_end[k] : seg0;
             const unsigned e = mine ? P.list[(size_t)sh * P.list_cap + (i - seg0)] : 0u;
             q = (long long)(e & ((1u << kListRayBits) - 1u));
-            entry = (long long)(e >> kListRayBits) * Q + q;
+            slot = (int)(e >> kListRayBits);
+            entry = (long long)slot * Q + q;
             mine = mine && (P.n_items[q] >= 0);  // < 0: ray handed back to the one-kernel path
             if (mine) packed_voxel = P.items[entry];
         }
@@ -554,6 +565,8 @@ k_geom(KGrid g, KOpt o, const float* __restrict__ origins, const float* __restri
             if (nc > 1) P.pool[at + 1] = c1;
             if (nc > 2) P.pool[at + 2] = c2;
             packed = (at << 2) | nc;
+            // tell k_comp that this slot matters (one in nine of a ray's work voxels does)
+            atomicOr(&P.cand_mask[q], 1ull << min(slot, 63));
         }
         if (SPILL) P.sp_citem[entry] = packed;
         else P.citem[entry] = packed;
@@ -590,25 +603,37 @@ k_comp(KGrid g, KOpt o, const float* __restrict__ dirs, long long Q, PipeBuf P,
     float log_transmit = 0.f;
     int sample_i = 0, intersect_i = -1, rec_cnt = 0;
     bool rec_over = false;
-    int n_left = valid ? n : 0;  // becomes 0 when stop_thresh ends the ray
-
-    // the per-voxel candidate words of four consecutive slots are fetched together (independent
-    // loads): the loop is otherwise one dependent memory round trip per slot
-    int ci4[4] = {0, 0, 0, 0}, pv4[4] = {0, 0, 0, 0};
-    for (int s = 0; __any(s < n_left); ++s) {
-        const bool have = s < n_left;
-        if ((s & 3) == 0) {
+    // Where a ray's candidates are.  One work voxel in nine yields any, so a ray does not walk its slots: k_geom
+    // left it a bit per slot that matters, and it visits those in order.  Only a ray with a candidate beyond its
+    // 63rd work voxel scans all its slots (`scan`).  Either way the words of the next four stops are fetched together
+    // (independent loads): the loop is otherwise one dependent memory round trip per stop.
+    const unsigned long long cmask = valid ? P.cand_mask[q] : 0ull;
+    const bool scan = (cmask >> 63) != 0ull;
+    unsigned long long todo = cmask;   // slots still to visit (!scan)
+    int n_left = valid ? (scan ? n : __popcll(todo)) : 0;  // stops this ray still makes; 0 when stop_thresh ends it
+    int ci4[4] = {0, 0, 0, 0}, pv4[4] = {0, 0, 0, 0}, s4[4] = {0, 0, 0, 0};
+    for (int it = 0; __any(it < n_left); ++it) {
+        const bool have = it < n_left;
+        if ((it & 3) == 0) {
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                const int su = s + u;
+                int su = it + u;
+                bool on = su < n_left;
+                if (!scan) {
+                    on = todo != 0ull;
+                    su = on ? __ffsll((long long)todo) - 1 : 0;
+                    todo &= todo - 1ull;
+                }
+                s4[u] = su;
                 ci4[u] = pv4[u] = 0;
-                if (su < n_left) {
+                if (on) {
                     ci4[u] = (su < P.C1) ? P.citem[(size_t)su * Q + q] : P.sp_citem[spb + su - P.C1];
                     pv4[u] = (su < P.C1) ? P.items[(size_t)su * Q + q] : P.sp_items[spb + su - P.C1];
                 }
             }
         }
-        const int sel = s & 3;
+        const int sel = it & 3;
+        const int s = sel == 0 ? s4[0] : sel == 1 ? s4[1] : sel == 2 ? s4[2] : s4[3];
         int ci = sel == 0 ? ci4[0] : sel == 1 ? ci4[1] : sel == 2 ? ci4[2] : ci4[3];
         const int pv = sel == 0 ? pv4[0] : sel == 1 ? pv4[1] : sel == 2 ? pv4[2] : pv4[3];
         if (!have) ci = 0;

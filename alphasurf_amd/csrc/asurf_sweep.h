@@ -369,6 +369,7 @@ k_sweep(KGrid g, KOpt o, const float* __restrict__ origins, const float* __restr
             P.n_items[q] = handback ? -1 : n;
             P.cut[q] = 0x7fffffff;
             P.sp_base[q] = spb;
+            P.cand_mask[q] = 0ull;
         }
         s_n[tid] = n;
         s_spb[tid] = spb;
