@@ -400,7 +400,8 @@ int run_forward(const Launch& L, const asurf_rays* rays, float* rgb_out, int M, 
             // rays per block from the (ray, brick layer) pairs a block takes; threads from the measured optimum (the
             // pairs are strided over them): 256 threads x 16 rays at 256^3 -- with 512 the phases that occupy one
             // wave leave seven waiting (0.50 ms against 0.35), with 128 a block takes too many rounds (0.39)
-            const int rpb = std::max(1, std::min(kSweepLanes >> lpr_log2, kSweepMaxRays));
+            // (at least 8 rays per block: its fixed costs -- barriers, set-up, allocation -- are per block)
+            const int rpb = std::max(8, std::min(kSweepLanes >> lpr_log2, kSweepMaxRays));
             const int sweep_threads = std::min(kSweepThreads, std::max(64, rpb << lpr_log2));
             const int K = kSweepKeys / rpb;
             const int task_cap = (rpb << lpr_log2) * kSweepTasksPerLane2 / 2;

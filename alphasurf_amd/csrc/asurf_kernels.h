@@ -488,7 +488,7 @@ __device__ __forceinline__ bool walk_visits(const Ray& r, const int* n0, const i
     float tc[3], tf[3];
 #pragma unroll
     for (int a = 0; a < 3; ++a) {  // 0 / 0 on an axis the ray does not move along: a crossing that never comes
-        tc[a] = (tc_in[a] != tc_in[a]) ? -INFINITY : tc_in[a];
+        tc[a] = (tc_in[a] != tc_in[a]) ? INFINITY : tc_in[a];  // (only read for an axis on which v is off the start)
         tf[a] = (tf_in[a] != tf_in[a]) ? INFINITY : tf_in[a];
     }
 #pragma unroll

@@ -1930,6 +1930,22 @@ int64_t oracle_trace_voxel_lists(const oracle_grid* grid, const oracle_rays* ray
     return total;
 }
 
+int oracle_setup_rays(const oracle_grid* grid, const oracle_rays* rays, const oracle_render_options* opt,
+                      float* out) {
+    if (check_common(grid, rays, opt)) return -1;
+    for (int64_t q = 0; q < rays->n_rays; ++q) {
+        Ray r;
+        setup_ray(*grid, *opt, rays->origins + 3 * q, rays->dirs + 3 * q, r);
+        for (int k = 0; k < 3; ++k) {
+            out[8 * q + k] = r.origin[k];
+            out[8 * q + 3 + k] = r.dir[k];
+        }
+        out[8 * q + 6] = r.tmin;
+        out[8 * q + 7] = r.tmax;
+    }
+    return 0;
+}
+
 int oracle_test_cubic_root_grad(const double* fs, const int32_t* st_ids, float* grad_fs,
                                 float* st, int64_t n, int32_t use_vieta) {
     if (!use_vieta) {  // test_cuda.cu:32-106: Vieta roots, gradient through the f/g/h chain

@@ -178,6 +178,11 @@ int64_t oracle_trace_voxel_lists(const oracle_grid* grid, const oracle_rays* ray
                                  const oracle_render_options* opt, int32_t* voxel_ls,
                                  int64_t cap, int32_t* vox_start_i, int32_t* vox_num);
 
+/* The rays as the kernels' prologue leaves them (surf_trav.cu:3163-3171): out[8 q .. 8 q + 7] = origin[3] and
+ * unit direction[3] in grid coordinates, tmin, tmax. */
+int oracle_setup_rays(const oracle_grid* grid, const oracle_rays* rays, const oracle_render_options* opt,
+                      float* out);
+
 /* SH basis at unit directions (render_util.cuh:405-436; svox2/utils.py:119-166) */
 void oracle_eval_sh(int32_t basis_dim, const float* dirs, int64_t n, float* out);
 

@@ -35,6 +35,15 @@ class Rays(C.Structure):
     _fields_ = [("origins", c_f), ("dirs", c_f), ("masks", c_u8), ("n_rays", C.c_int64)]
 
 
+def setup_rays(sc, origins, dirs, opts=None):
+    """float32 [Q, 8]: origin, unit direction (grid coordinates), tmin, tmax as the kernels' prologue computes them."""
+    r = _rays(origins, dirs)
+    g, o = _grid(sc), make_opts(opts)
+    out = np.zeros((r.n_rays, 8), np.float32)
+    _check(lib().oracle_setup_rays(C.byref(g), C.byref(r), C.byref(o), _f(out)), "oracle_setup_rays")
+    return out
+
+
 class RayVox(C.Structure):
     _fields_ = [("voxel_ls", c_i), ("vox_start_i", c_i), ("vox_num", c_i), ("n_vox", C.c_int64)]
 
@@ -282,6 +291,15 @@ def trace_voxel_lists(sc, origins, dirs, opts=None):
     lib().oracle_trace_voxel_lists(C.byref(g), C.byref(r), C.byref(o), _i(vox), C.c_int64(total),
                                    _i(start), _i(num))
     return vox[:total], start, num
+
+
+def setup_rays(sc, origins, dirs, opts=None):
+    """float32 [Q, 8]: origin, unit direction (grid coordinates), tmin, tmax as the kernels' prologue computes them."""
+    r = _rays(origins, dirs)
+    g, o = _grid(sc), make_opts(opts)
+    out = np.zeros((r.n_rays, 8), np.float32)
+    _check(lib().oracle_setup_rays(C.byref(g), C.byref(r), C.byref(o), _f(out)), "oracle_setup_rays")
+    return out
 
 
 class RayVox(C.Structure):
