@@ -827,11 +827,12 @@ int asurf_volume_render_surf_trav_fused(const asurf_grid* grid, const asurf_rays
 static int optim_launch(bool rms_mode, float* data, float* rms, float* grad, int64_t n_rows,
                         int32_t n_cols, const uint8_t* mask, const int64_t* indices,
                         int64_t n_indices, float beta, float lr, float epsilon, float minval,
-                        float lr_last, void* stream) {
+                        float lr_last, void* stream, const int* n_idx_dev = nullptr) {
     if (!data || !grad || (rms_mode && !rms)) return fail(ASURF_E_INVALID, "optim step: NULL tensor");
     if (n_rows < 0 || n_cols <= 0 || n_indices < 0) return fail(ASURF_E_INVALID, "optim step: bad shape");
     if (lr_last < 0.f) lr_last = lr;  // optim_kernel.cu:169
     const int mode = mask ? 1 : (indices ? 2 : 0);
+    if (n_idx_dev) n_indices = std::min<int64_t>(n_rows, 1 << 18);  // launch shape only: the kernels stride to the count
     if (mode == 2 && n_indices == 0) return 0;  // empty index list: nothing to do
     const long long total = (mode == 2 ? n_indices : n_rows) * (long long)n_cols;
     if (total == 0) return 0;
@@ -845,11 +846,11 @@ static int optim_launch(bool rms_mode, float* data, float* rms, float* grad, int
         if (rms_mode)
             hipLaunchKernelGGL((k_optim_rows<true>), dim3((unsigned)blocks), dim3(256), 0,
                                static_cast<hipStream_t>(stream), data, rms, grad, (long long)n_rows, n_cols, cp_shift,
-                               mode, mask, idx, (long long)n_indices, beta, lr, epsilon, minval, lr_last);
+                               mode, mask, idx, (long long)n_indices, beta, lr, epsilon, minval, lr_last, n_idx_dev);
         else
             hipLaunchKernelGGL((k_optim_rows<false>), dim3((unsigned)blocks), dim3(256), 0,
                                static_cast<hipStream_t>(stream), data, rms, grad, (long long)n_rows, n_cols, cp_shift,
-                               mode, mask, idx, (long long)n_indices, beta, lr, epsilon, minval, lr_last);
+                               mode, mask, idx, (long long)n_indices, beta, lr, epsilon, minval, lr_last, n_idx_dev);
         return launch_error("k_optim_rows");
     }
     long long blocks = (total + 255) / 256;
@@ -857,11 +858,11 @@ static int optim_launch(bool rms_mode, float* data, float* rms, float* grad, int
     if (rms_mode)
         hipLaunchKernelGGL((k_optim_step<true>), dim3((unsigned)blocks), dim3(256), 0,
                            static_cast<hipStream_t>(stream), data, rms, grad, (long long)n_rows, n_cols,
-                           mode, mask, idx, (long long)n_indices, beta, lr, epsilon, minval, lr_last);
+                           mode, mask, idx, (long long)n_indices, beta, lr, epsilon, minval, lr_last, n_idx_dev);
     else
         hipLaunchKernelGGL((k_optim_step<false>), dim3((unsigned)blocks), dim3(256), 0,
                            static_cast<hipStream_t>(stream), data, rms, grad, (long long)n_rows, n_cols,
-                           mode, mask, idx, (long long)n_indices, beta, lr, epsilon, minval, lr_last);
+                           mode, mask, idx, (long long)n_indices, beta, lr, epsilon, minval, lr_last, n_idx_dev);
     return launch_error("k_optim_step");
 }
 
@@ -876,6 +877,40 @@ int asurf_sgd_step(float* data, float* grad, int64_t n_rows, int32_t n_cols, con
                    const int64_t* indices, int64_t n_indices, float lr, float lr_last, void* stream) {
     return optim_launch(false, data, nullptr, grad, n_rows, n_cols, mask, indices, n_indices, 0.f, lr,
                         0.f, 0.f, lr_last, stream);
+}
+
+size_t asurf_optim_scratch_bytes(int64_t n_rows) { return (size_t)(n_rows > 0 ? n_rows : 0) * 8 + 256; }
+
+// mask -> row list on the device, then the index-list step over it (its length stays on the device)
+static int optim_masked(bool rms_mode, float* data, float* rms, float* grad, int64_t n_rows, int32_t n_cols,
+                        const uint8_t* mask, void* scratch, size_t scratch_bytes, float beta, float lr, float epsilon,
+                        float minval, float lr_last, void* stream) {
+    if (!mask) return fail(ASURF_E_INVALID, "optim step: mask is NULL");
+    if (n_rows <= 0) return 0;
+    if (!scratch || scratch_bytes < asurf_optim_scratch_bytes(n_rows))
+        return fail(ASURF_E_WORKSPACE, "optim step: scratch of %zu bytes needed", asurf_optim_scratch_bytes(n_rows));
+    int* count = static_cast<int*>(scratch);
+    long long* rows = reinterpret_cast<long long*>(static_cast<char*>(scratch) + 256);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (hipMemsetAsync(count, 0, sizeof(int), s) != hipSuccess) return fail(ASURF_E_LAUNCH, "hipMemsetAsync failed");
+    hipLaunchKernelGGL(k_compact_rows, dim3((unsigned)((n_rows + kCompactRowsPerBlock - 1) / kCompactRowsPerBlock)),
+                       dim3(256), 0, s, mask, (long long)n_rows, rows, count);
+    if (int e = launch_error("k_compact_rows")) return e;
+    return optim_launch(rms_mode, data, rms, grad, n_rows, n_cols, nullptr, reinterpret_cast<const int64_t*>(rows), 0,
+                        beta, lr, epsilon, minval, lr_last, stream, count);
+}
+
+int asurf_rmsprop_step_masked(float* data, float* rms, float* grad, int64_t n_rows, int32_t n_cols,
+                              const uint8_t* mask, void* scratch, size_t scratch_bytes, float beta, float lr,
+                              float epsilon, float minval, float lr_last, void* stream) {
+    return optim_masked(true, data, rms, grad, n_rows, n_cols, mask, scratch, scratch_bytes, beta, lr, epsilon,
+                        minval, lr_last, stream);
+}
+
+int asurf_sgd_step_masked(float* data, float* grad, int64_t n_rows, int32_t n_cols, const uint8_t* mask,
+                          void* scratch, size_t scratch_bytes, float lr, float lr_last, void* stream) {
+    return optim_masked(false, data, nullptr, grad, n_rows, n_cols, mask, scratch, scratch_bytes, 0.f, lr, 0.f, 0.f,
+                        lr_last, stream);
 }
 
 int asurf_profile_enable(int on) {

@@ -31,11 +31,52 @@ __device__ __forceinline__ void optim_once(float* __restrict__ data, float* __re
     grad[off] = 0.f;
 }
 
+// Row mask -> list of the rows it names, count left ON THE DEVICE (the steps below read it there): the reference
+// decides between mask and index list on the host (`torch.count_nonzero(...).item()`, svox2.py:6326-6332), a device ->
+// host round trip per optimizer step that stalls the launch queue of a whole training iteration.  Block = 4096 rows:
+// per-thread counts, one scan, one atomic per block; the order of the list is irrelevant to its readers.
+constexpr int kCompactRowsPerBlock = 4096;
+__global__ void __launch_bounds__(256)
+k_compact_rows(const uint8_t* __restrict__ mask, long long n_rows, long long* __restrict__ indices,
+               int* __restrict__ count) {
+    __shared__ int s_wave[4], s_base;
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+    const long long row0 = (long long)blockIdx.x * kCompactRowsPerBlock;
+    unsigned flags = 0;
+#pragma unroll
+    for (int j = 0; j < kCompactRowsPerBlock / 256; ++j) {
+        const long long row = row0 + t + 256 * j;
+        if (row < n_rows && mask[row]) flags |= 1u << j;
+    }
+    const int c = __popc(flags);
+    int incl = c;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int v = __shfl_up(incl, d);
+        if (lane >= d) incl += v;
+    }
+    if (lane == 63) s_wave[w] = incl;
+    __syncthreads();
+    if (t == 0) {
+        const int total = s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
+        s_base = total > 0 ? atomicAdd(count, total) : 0;
+    }
+    __syncthreads();
+    int at = s_base + incl - c;
+    for (int k = 0; k < w; ++k) at += s_wave[k];
+#pragma unroll
+    for (int j = 0; j < kCompactRowsPerBlock / 256; ++j)
+        if (flags & (1u << j)) indices[at++] = row0 + t + 256 * j;
+}
+
+// n_idx_dev != nullptr: the length of `indices` is read from the device (k_compact_rows' count)
 template <bool RMS>
 __global__ void __launch_bounds__(256)
 k_optim_rows(float* __restrict__ data, float* __restrict__ rms, float* __restrict__ grad, long long n_rows, int n_cols,
              int cp_shift, int mode, const uint8_t* __restrict__ mask, const long long* __restrict__ indices,
-             long long n_idx, float beta, float lr, float epsilon, float minval, float lr_last) {
+             long long n_idx, float beta, float lr, float epsilon, float minval, float lr_last,
+             const int* __restrict__ n_idx_dev) {
+    if (n_idx_dev != nullptr) n_idx = *n_idx_dev;
     const long long groups = mode == 2 ? n_idx : n_rows;
     const long long stride = ((long long)gridDim.x * blockDim.x) >> cp_shift;
     const int chnl = (int)(threadIdx.x & ((1u << cp_shift) - 1u));
@@ -56,7 +97,8 @@ __global__ void __launch_bounds__(256)
 k_optim_step(float* __restrict__ data, float* __restrict__ rms, float* __restrict__ grad,
              long long n_rows, int n_cols, int mode, const uint8_t* __restrict__ mask,
              const long long* __restrict__ indices, long long n_idx, float beta, float lr,
-             float epsilon, float minval, float lr_last) {
+             float epsilon, float minval, float lr_last, const int* __restrict__ n_idx_dev) {
+    if (n_idx_dev != nullptr) n_idx = *n_idx_dev;
     const long long total = (mode == 2 ? n_idx : n_rows) * n_cols;
     const long long stride = (long long)gridDim.x * blockDim.x;
     for (long long tid = (long long)blockIdx.x * blockDim.x + threadIdx.x; tid < total; tid += stride) {

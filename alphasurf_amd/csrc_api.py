@@ -450,15 +450,39 @@ def _indexer_args(indexer, n_rows):
     return C.c_void_p(0), _ptr(indexer), indexer.shape[0], False
 
 
+_optim_scratch = {}
+
+
+def _optim_scratch_for(device, n_rows):
+    """Scratch of the masked optimizer steps (row list + its length), per (device, stream) like the workspace."""
+    nbytes = int(_L.lib().asurf_optim_scratch_bytes(n_rows))
+    key = (device.type, device.index, torch.cuda.current_stream(device).cuda_stream)
+    with _ws_lock:
+        buf = _optim_scratch.get(key)
+        if buf is None or buf.numel() < nbytes:
+            buf = torch.empty(nbytes, dtype=torch.uint8, device=device)
+            _optim_scratch[key] = buf
+    return buf, nbytes
+
+
 def rmsprop_step(data, rms, grad, indexer, beta, lr, epsilon, minval, lr_last):
     """void rmsprop_step(data, rms, grad, indexer, beta, lr, epsilon, minval, lr_last)
-    (optim_kernel.cu:154-216): in-place RMSProp on [rows, cols] tensors; zeroes the gradient."""
+    (optim_kernel.cu:154-216): in-place RMSProp on [rows, cols] tensors; zeroes the gradient.
+    A bool row mask takes asurf_rmsprop_step_masked: same rows, same arithmetic, the mask turned into a row list
+    on the device (the reference's caller makes that choice on the host, with a device -> host round trip)."""
     for t, name in ((data, "data"), (rms, "rms"), (grad, "grad")):
         _check_input(t, name, torch.float32)
     if data.dim() != 2 or rms.shape != data.shape or grad.shape != data.shape:
         raise RuntimeError("data, rms and grad must be 2-D tensors of the same shape")
     mask, idx, n_idx, empty = _indexer_args(indexer, data.shape[0])
     if empty:
+        return
+    if torch.is_tensor(indexer) and indexer.dim() == 1 and indexer.dtype == torch.bool:
+        with torch.cuda.device(data.device):
+            scratch, nbytes = _optim_scratch_for(data.device, data.shape[0])
+            _L.check(_L.lib().asurf_rmsprop_step_masked(
+                _ptr(data), _ptr(rms), _ptr(grad), data.shape[0], data.shape[1], mask, _ptr(scratch), nbytes,
+                float(beta), float(lr), float(epsilon), float(minval), float(lr_last), _stream(data.device)))
         return
     with torch.cuda.device(data.device):
         _L.check(_L.lib().asurf_rmsprop_step(_ptr(data), _ptr(rms), _ptr(grad), data.shape[0], data.shape[1],
@@ -474,6 +498,13 @@ def sgd_step(data, grad, indexer, lr, lr_last):
         raise RuntimeError("data and grad must be 2-D tensors of the same shape")
     mask, idx, n_idx, empty = _indexer_args(indexer, data.shape[0])
     if empty:
+        return
+    if torch.is_tensor(indexer) and indexer.dim() == 1 and indexer.dtype == torch.bool:
+        with torch.cuda.device(data.device):
+            scratch, nbytes = _optim_scratch_for(data.device, data.shape[0])
+            _L.check(_L.lib().asurf_sgd_step_masked(
+                _ptr(data), _ptr(grad), data.shape[0], data.shape[1], mask, _ptr(scratch), nbytes,
+                float(lr), float(lr_last), _stream(data.device)))
         return
     with torch.cuda.device(data.device):
         _L.check(_L.lib().asurf_sgd_step(_ptr(data), _ptr(grad), data.shape[0], data.shape[1], mask, idx,

@@ -1207,23 +1207,15 @@ class SparseGrid(nn.Module):
 
     # ---- optimizers (:5972-6140 -> optim_kernel.cu:14-265) ----
     def _maybe_convert_sparse_grad_indexer(self, sh=False, bg=False):
-        """Mask -> index list when under 1/8 of the rows were touched (:6314-6333)."""
+        """The row selector of an optimizer step (:6314-6333).  The reference turns the mask into an index list on
+        the host when under 1/8 of the rows were touched -- `torch.count_nonzero(mask).item()`, a device -> host
+        round trip in every optimizer step that stalls the launch queue of the whole iteration.  Here the mask
+        itself goes to `_C.rmsprop_step` / `sgd_step`, which build the row list on the device
+        (asurf_rmsprop_step_masked): the same rows are updated, nothing waits."""
         indexer = self.sparse_sh_grad_indexer if sh else self.sparse_grad_indexer
         if indexer is None:
             return torch.empty((), device=self.density_data.device)
-        if indexer.dtype != torch.bool:
-            return indexer
-        # the count is a device -> host round trip; the density and the surface step of an iteration ask about the
-        # same mask, so the answer is kept while the mask is untouched
-        key = (indexer.data_ptr(), indexer._version, self.__dict__.get("_mask_gen", 0))
-        cached = self.__dict__.get("_indexer_cache_sh" if sh else "_indexer_cache")
-        if cached is not None and cached[0] == key and cached[1] is indexer:
-            return cached[2]
-        out = indexer
-        if torch.count_nonzero(indexer).item() < indexer.size(0) // 8:
-            out = torch.nonzero(indexer.flatten(), as_tuple=False).flatten()
-        self.__dict__["_indexer_cache_sh" if sh else "_indexer_cache"] = (key, indexer, out)
-        return out
+        return indexer
 
     def _optim_step(self, name, rms_name, indexer, lr, beta, epsilon, optim):
         p = getattr(self, name)

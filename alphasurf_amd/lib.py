@@ -92,7 +92,8 @@ EXPORTS = [
     "asurf_volume_render_surface_backward", "asurf_volume_render_surface_fused",
     "asurf_test_cubic_root_grad", "asurf_profile_enable", "asurf_profile_read",
     "asurf_profile_read_spans",
-    "asurf_rmsprop_step", "asurf_sgd_step", "asurf_ray_voxel_count", "asurf_ray_voxel_fill",
+    "asurf_rmsprop_step", "asurf_sgd_step", "asurf_optim_scratch_bytes", "asurf_rmsprop_step_masked",
+    "asurf_sgd_step_masked", "asurf_ray_voxel_count", "asurf_ray_voxel_fill",
     "asurf_tv", "asurf_tv_grad_sparse", "asurf_surf_tv_grad_sparse", "asurf_surface_normal_grad_sparse",
     "asurf_alpha_surf_sparsify_grad_sparse", "asurf_surface_eikonal_grad_sparse",
     "asurf_render_eval_surf_trav", "asurf_dilate", "asurf_accel_dist_prop_tmp_bytes", "asurf_accel_dist_prop",
@@ -135,6 +136,11 @@ def lib():
         fl = C.c_float
         L.asurf_rmsprop_step.argtypes = [vp, vp, vp, C.c_int64, C.c_int32, vp, vp, C.c_int64, fl, fl, fl, fl, fl, vp]
         L.asurf_sgd_step.argtypes = [vp, vp, C.c_int64, C.c_int32, vp, vp, C.c_int64, fl, fl, vp]
+        L.asurf_optim_scratch_bytes.restype = C.c_size_t
+        L.asurf_optim_scratch_bytes.argtypes = [C.c_int64]
+        L.asurf_rmsprop_step_masked.argtypes = [vp, vp, vp, C.c_int64, C.c_int32, vp, vp, C.c_size_t,
+                                                fl, fl, fl, fl, fl, vp]
+        L.asurf_sgd_step_masked.argtypes = [vp, vp, C.c_int64, C.c_int32, vp, vp, C.c_size_t, fl, fl, vp]
         L.asurf_ray_voxel_count.argtypes = [vp, vp, vp, C.c_int32, vp, vp]
         L.asurf_ray_voxel_fill.argtypes = [vp, vp, vp, C.c_int32, vp, vp, vp]
         i32, i64 = C.c_int32, C.c_int64

@@ -250,6 +250,18 @@ int asurf_rmsprop_step(float* data, float* rms, float* grad, int64_t n_rows, int
 int asurf_sgd_step(float* data, float* grad, int64_t n_rows, int32_t n_cols, const uint8_t* mask,
                    const int64_t* indices, int64_t n_indices, float lr, float lr_last, void* stream);
 
+/* The same steps for a bool row mask, without the reference's host-side choice between mask and index list
+ * (svox2.py:6314-6333: `torch.count_nonzero(mask).item()`, a device -> host round trip per step): the mask is
+ * compacted into a row list on the device and the index-list kernel strides over it, its length read on the
+ * device.  Same rows, same arithmetic as asurf_rmsprop_step / asurf_sgd_step with `mask`.  `scratch`: device
+ * memory of asurf_optim_scratch_bytes(n_rows) bytes, contents irrelevant before and after the call. */
+size_t asurf_optim_scratch_bytes(int64_t n_rows);
+int asurf_rmsprop_step_masked(float* data, float* rms, float* grad, int64_t n_rows, int32_t n_cols,
+                              const uint8_t* mask, void* scratch, size_t scratch_bytes, float beta, float lr,
+                              float epsilon, float minval, float lr_last, void* stream);
+int asurf_sgd_step_masked(float* data, float* grad, int64_t n_rows, int32_t n_cols, const uint8_t* mask,
+                          void* scratch, size_t scratch_bytes, float lr, float lr_last, void* stream);
+
 /* Evaluation renders: traversal + cubic core without colour, density
  * gate, window or fake samples.  `workspace` as for the training calls (asurf_workspace_bytes with
  * l_dist_max_sample = 0).  mode / param / outputs:

@@ -167,19 +167,20 @@ def _rmsprop_ref(data, rms, grad, rows, beta, lr, eps, minval, lr_last):
     return data, rms, grad
 
 
-@pytest.mark.parametrize("kind", ["all", "mask", "index", "empty_index"])
-def test_optimizer_steps(env, kind):
+@pytest.mark.parametrize("c", [27, 1])
+@pytest.mark.parametrize("kind", ["all", "mask", "mask_none", "mask_all", "index", "empty_index"])
+def test_optimizer_steps(env, kind, c):
     torch, svox2 = env
     import svox2.csrc as _C
     rs = np.random.RandomState(3)
-    n, c = 5003, 27
+    n = 13003  # (several blocks of the mask -> row-list pass)
     data = rs.randn(n, c).astype(np.float32)
     rms = (rs.rand(n, c).astype(np.float32)) * (rs.rand(n, c) > 0.3)
     grad = rs.randn(n, c).astype(np.float32) * 1e-2
     if kind == "all":
         indexer, rows = torch.empty((), device="cuda"), np.arange(n)
-    elif kind == "mask":
-        m = rs.rand(n) < 0.3
+    elif kind.startswith("mask"):
+        m = rs.rand(n) < {"mask": 0.3, "mask_none": -1.0, "mask_all": 2.0}[kind]
         indexer, rows = torch.from_numpy(m).cuda(), np.nonzero(m)[0]
     elif kind == "index":
         rows = np.sort(rs.choice(n, 400, replace=False))
