@@ -250,16 +250,20 @@ def main():
         dom_ms, dom_bytes = spans[dom_name], shares.get(dom_name, 0.0)
         achieved = dom_bytes / (dom_ms * 1e-3) / 1e9
         peak = 8000.0
-        traffic = None
+        # real HBM traffic per launch from the PMC counters (profiles/traffic.json, collected with rocprofv3 --pmc in
+        # separate passes): next to the model's bytes it shows what the kernels actually move
+        traffic, traffic_call = None, None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tpath):
             try:
                 tj = json.load(open(tpath))
                 traffic = tj.get(dom_name, {}).get("hbm_bytes_per_launch")
+                traffic_call = sum(tj[k]["hbm_bytes_per_launch"] for k in spans if k in tj)
             except Exception:
-                traffic = None
+                traffic, traffic_call = None, None
         roofline = dict(bound="hbm", kernel=dom_name, achieved=round(achieved, 1), peak=peak, unit="GB/s",
                         frac=round(achieved / peak, 4), traffic=traffic,
+                        traffic_GBps=(round(traffic / (dom_ms * 1e-3) / 1e9, 1) if traffic else None),
                         algorithmic_bytes_per_launch=dom_bytes, avg_launch_ms=round(dom_ms, 4),
                         per_kernel_ms={k: round(v, 4) for k, v in spans.items()},
                         per_kernel_algorithmic_GBps={k: round(shares.get(k, 0.0) / (v * 1e-3) / 1e9, 1)
@@ -268,7 +272,12 @@ def main():
                                        backward=round(t_bwd, 4)),
                         whole_call=dict(algorithmic_bytes=b_f + b_b,
                                         achieved=round((b_f + b_b) / ((t_mask + t_fwd + t_bwd) * 1e-3) / 1e9, 1),
-                                        frac=round((b_f + b_b) / ((t_mask + t_fwd + t_bwd) * 1e-3) / 1e9 / peak, 4)))
+                                        frac=round((b_f + b_b) / ((t_mask + t_fwd + t_bwd) * 1e-3) / 1e9 / peak, 4),
+                                        traffic=traffic_call,
+                                        traffic_GBps=(round(traffic_call / ((t_mask + t_fwd + t_bwd) * 1e-3) / 1e9, 1)
+                                                      if traffic_call else None),
+                                        traffic_frac=(round(traffic_call / ((t_mask + t_fwd + t_bwd) * 1e-3) / 1e9 / peak, 4)
+                                                      if traffic_call else None)))
 
         cpu = None
         if not args.no_cpu_baseline:
