@@ -340,6 +340,15 @@ int prepare(const asurf_grid* grid, const asurf_rays* rays, const asurf_render_o
     return launch_error("k_build_masks");
 }
 
+// Blocks of the kernels that stride over a dense list whose length only the device knows: enough for the list a
+// batch of n_rays can produce to be spread over the chip (a ray rarely holds more than 16 work voxels, the table
+// keeps 32), but no more than kListBlocks -- 2048 blocks that find an empty list still cost their dispatch, which
+// is most of these kernels' time at the training script's batch size.
+unsigned list_blocks(long long n_rays, int per_ray) {
+    const long long want = (n_rays * per_ray + kBlock - 1) / kBlock;
+    return (unsigned)std::min<long long>(std::max<long long>(want, 64), kListBlocks);
+}
+
 // The three-kernel forward is used unless the call needs what only the one-kernel path keeps:
 // exact V_t/V_a/S counters (a ray stopped by stop_thresh must not be walked further),
 // stop_thresh > 1 (the reference then stops at the first voxel that passes the gates even if
@@ -429,7 +438,7 @@ int run_forward(const Launch& L, const asurf_rays* rays, float* rgb_out, int M, 
             hipLaunchKernelGGL((k_walk<false>), L.ray_grid, dim3(kBlock), 0, L.stream, L.g, L.o,
                                rays->origins, rays->dirs, Q, P, record ? 1 : 0);
         prof_after(L.sweep ? "k_sweep" : "k_walk", 1, L.stream);
-        hipLaunchKernelGGL(k_geom, dim3(kListBlocks), dim3(kBlock), 0, L.stream, L.g, L.o, rays->origins,
+        hipLaunchKernelGGL(k_geom, dim3(list_blocks(Q, 16)), dim3(kBlock), 0, L.stream, L.g, L.o, rays->origins,
                            rays->dirs, Q, P);
         prof_after("k_geom", 1, L.stream);
         if (cache)
@@ -531,10 +540,10 @@ int run_backward(const Launch& L, const asurf_rays* rays, const KLoss& loss, con
         hipLaunchKernelGGL(k_bwd_seq, L.ray_grid, dim3(kBlock), 0, L.stream, L.o, loss, L.g.trunc_a, Q,
                            grad_in, color_cache, M, ca, cw, ct, cn, S);
         prof_after("k_bwd_seq", 2, L.stream);
-        hipLaunchKernelGGL((k_bwd_sh<B>), dim3(kListBlocks), dim3(kBlock), 0, L.stream, L.g, G,
+        hipLaunchKernelGGL((k_bwd_sh<B>), dim3(list_blocks(Q, 8)), dim3(kBlock), 0, L.stream, L.g, G,
                            L.o.no_surf_grad_from_sh ? 0 : 1, rays->dirs, Q, S);
         prof_after("k_bwd_sh", 2, L.stream);
-        hipLaunchKernelGGL(k_bwd_geo, dim3(kListBlocks), dim3(kBlock), 0, L.stream, L.g, L.o, loss, G, rays->origins,
+        hipLaunchKernelGGL(k_bwd_geo, dim3(list_blocks(Q, 2)), dim3(kBlock), 0, L.stream, L.g, L.o, loss, G, rays->origins,
                            rays->dirs, Q, S);
         prof_after("k_bwd_geo", 2, L.stream);
     } else if (mode == 1) {

@@ -290,9 +290,12 @@ k_bwd_sh(KGrid g, KGrads G, int want_dpos, const float* __restrict__ dirs, long 
     const int ch = e / B;
     const int k = e - ch * B;
     const bool on = cs < C::CPR;
-  // one dense chunk of 64 list entries per wave and turn (see k_bwd_geo)
-  for (int base = wave_id * 64; base < n_list; base += (int)gridDim.x * kBlock) {
-    const bool mine = base + lane < n_list;
+  // one dense chunk of list entries per wave and turn (see k_bwd_geo).  A wave works its chunk off two samples at a
+  // time, a dependent round trip each: a short list is cut into shorter chunks (8 entries at the training script's
+  // batch size: 0.049 -> 0.02 ms), a long one into chunks of 64, whose runs of one voxel merge more atomics.
+  const int chunk = n_list >= (1 << 18) ? 64 : n_list >= (1 << 17) ? 32 : n_list >= (1 << 16) ? 16 : 8;
+  for (int base = wave_id * chunk; base < n_list; base += (int)gridDim.x * (kBlock / 64) * chunk) {
+    const bool mine = lane < chunk && base + lane < n_list;
     const unsigned cell = mine ? S.list[base + lane] : 0u;
     const long long q = (long long)(cell & ((1u << kListRayBits) - 1u));
     const int r = (int)(cell >> kListRayBits);
