@@ -304,6 +304,10 @@ class _SampleGridAutogradFunction(autograd.Function):
                 grad_sh if ctx.needs_input_grad[1] else None, None, None, None)
 
 
+# rays per call of the whole-image renders (the caller's batch_size is a lower bound)
+_IMAGE_RAYS = 1 << 20
+
+
 class SparseGrid(nn.Module):
     """Sparse voxel grid with a per-vertex surface scalar (:560-990).  Only what the surf_trav
     hot path needs is built: SH basis, SDF/UDF surface types, no MSI background."""
@@ -611,8 +615,11 @@ class SparseGrid(nn.Module):
         if debug_pixels is not None:
             ids = debug_pixels[:, 0] + debug_pixels[:, 1] * camera.width
             return self.volume_render(rays[ids], **kw)["rgb"]
-        parts = [self.volume_render(rays[s:s + batch_size], **kw)["rgb"]
-                 for s in range(0, camera.height * camera.width, batch_size)]
+        # `batch_size` is the reference's guard for its [Q, 64] sample buffers; rays are independent, and every call
+        # pays for the occupancy pyramid of the whole grid once: the batches are merged up to _IMAGE_RAYS rays
+        step = max(int(batch_size), _IMAGE_RAYS)
+        parts = [self.volume_render(rays[s:s + step], **kw)["rgb"]
+                 for s in range(0, camera.height * camera.width, step)]
         return torch.cat(parts, dim=0).view(camera.height, camera.width, -1)
 
     # ---- point sampling and resampling (:1040-1113, 3963-4180 -> svox2_kernel.cu) ----
@@ -941,6 +948,7 @@ class SparseGrid(nn.Module):
         return _C.volume_render_alpha_surf_trav(self._to_cpp(), rays._to_cpp(), self.opt._to_cpp(), thresh)
 
     def _image_batches(self, camera: Camera, batch_size: int, fn):
+        batch_size = max(int(batch_size), _IMAGE_RAYS)  # (see volume_render_image)
         rays = camera.gen_rays()
         return torch.cat([fn(rays[s:s + batch_size]) for s in range(0, camera.height * camera.width, batch_size)],
                          dim=0)
@@ -976,6 +984,7 @@ class SparseGrid(nn.Module):
         self._eval_backend(kwargs)
         rays = camera.gen_rays()
         all_pts, all_alpha = [], []
+        batch_size = max(int(batch_size), _IMAGE_RAYS)  # (see volume_render_image)
         for s in range(0, camera.height * camera.width, batch_size):
             rb = rays[s:s + batch_size]
             depths, alphas = _C.extract_pts_surf_trav(self._to_cpp(), rb._to_cpp(), self.opt._to_cpp(), max_sample,
