@@ -412,9 +412,12 @@ int run_forward(const Launch& L, const asurf_rays* rays, float* rgb_out, int M, 
             // (at least 8 rays per block: its fixed costs -- barriers, set-up, allocation -- are per block)
             const int rpb = std::max(8, std::min(kSweepLanes >> lpr_log2, kSweepMaxRays));
             const int sweep_threads = std::min(kSweepThreads, std::max(64, rpb << lpr_log2));
-            const int K = kSweepKeys / rpb;
+            // at least 128 keys per ray: a ray that finds more is handed to the one-kernel path, whose latency
+            // (that of one wave walking a whole ray) is then the call's
+            const int keys = std::max(kSweepKeys, rpb * 128);
+            const int K = keys / rpb;
             const int task_cap = (rpb << lpr_log2) * kSweepTasksPerLane2 / 2;
-            const size_t lds = (size_t)rpb * sizeof(SweepRay) + (size_t)task_cap * 8 + (size_t)kSweepKeys * 4;
+            const size_t lds = (size_t)rpb * sizeof(SweepRay) + (size_t)task_cap * 8 + (size_t)keys * 4;
             const dim3 sgrid((unsigned)((Q + rpb - 1) / rpb));
             hipLaunchKernelGGL(k_sweep, sgrid, dim3(sweep_threads), lds, L.stream, L.g, L.o, rays->origins,
                                rays->dirs, Q, P, lpr_log2, rpb, K, record ? 1 : 0, task_cap);

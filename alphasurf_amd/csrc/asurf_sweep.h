@@ -42,7 +42,7 @@ namespace asurf {
 constexpr int kSweepLanes = 512;    // (ray, brick layer) pairs per block: rays per block = kSweepLanes / LPR
 constexpr int kSweepThreads = 256;  // threads per block (the pairs are strided over them)
 constexpr int kSweepMaxThreads = 512;
-constexpr int kSweepKeys = 2048;    // entries of all rays of a block kept in LDS (K = kSweepKeys / rays per block)
+constexpr int kSweepKeys = 2048;    // entries of all rays of a block kept in LDS, at least (K = keys / rays per block)
 constexpr int kSweepMaxRays = 32;   // rays per block
 constexpr unsigned kSweepCutBit = 1u << 30;   // key flag: the reference's backward pass stops before this voxel
 constexpr unsigned kSweepDropped = 0xffffffffu;  // key of an entry the exact test rejected
