@@ -348,6 +348,42 @@ def test_sweep_dense_scene_and_long_rays(hip, monkeypatch):
         grad_close(g[k], g_ref[k], 1e-5, f"dense scene grad_{k}")
 
 
+def test_sweep_small_and_odd_grids(hip, monkeypatch):
+    """k_sweep and k_build_masks on grids whose edges are not multiples of the brick edge, down to 2 vertices per
+    axis (one voxel), against the per-voxel walk."""
+    from alphasurf_amd import synth
+    rs = np.random.RandomState(17)
+    base = synth.make_sparse_scene(24, 4, seed=2, band=30.0, dilate=0)   # every vertex active
+    n = base["density"].shape[0]
+    base["surface"] = (rs.rand(n, 1).astype(np.float32) - 0.5)           # a level set in most voxels
+    o, d = synth.random_rays(3000, 8)
+    o2 = (rs.rand(1500, 3).astype(np.float32) - 0.5) * 1.6               # origins inside the box too
+    d2 = rs.randn(1500, 3).astype(np.float32)
+    o = np.concatenate([o, o2])
+    d = np.concatenate([d, d2 / np.linalg.norm(d2, axis=1, keepdims=True)]).astype(np.float32)
+    gt = rs.rand(o.shape[0], 3).astype(np.float32)
+    opts = dict(OPTION_SETS["syn_yaml"], step_size=0.5)
+    fused = dict(lambda_l2=1.0)
+    for shape in ((2, 2, 2), (2, 9, 3), (8, 8, 8), (9, 9, 9), (17, 5, 24), (16, 23, 10), (24, 24, 24)):
+        links = base["links"][: shape[0], : shape[1], : shape[2]]
+        # re-number the rows of the crop (raster order), keep the values of the vertices that remain
+        keep = links.reshape(-1)
+        sc = dict(base, links=np.arange(keep.size, dtype=np.int32).reshape(shape),
+                  density=base["density"][keep], surface=base["surface"][keep], sh=base["sh"][keep],
+                  offset=(0.5 * np.array(shape)).astype(np.float32), scaling=(0.5 * np.array(shape)).astype(np.float32))
+        monkeypatch.setenv("ASURF_DEBUG", "8")
+        monkeypatch.setenv("ASURF_WALK_SEG", "1")
+        rgb_ref, g_ref = hip.render_fused(sc, o, d, opts, gt, fused)
+        monkeypatch.delenv("ASURF_DEBUG")
+        monkeypatch.delenv("ASURF_WALK_SEG")
+        rgb, g = hip.render_fused(sc, o, d, opts, gt, fused)
+        assert np.abs(rgb - rgb_ref).max() <= 5e-7, (shape, np.abs(rgb - rgb_ref).max())
+        assert (g["mask"] == g_ref["mask"]).all(), shape
+        for k in ("sh", "density", "surface"):
+            grad_close(g[k], g_ref[k], 1e-5, f"shape {shape} grad_{k}")
+        assert np.abs(rgb - 1.0).max() > 1e-3 or shape == (2, 2, 2)  # (something was hit)
+
+
 def test_brick_skipping_is_exact(hip, monkeypatch):
     """k_sweep finds a ray's work voxels in closed form and k_walk jumps over empty 8^3 bricks; their
     work-voxel lists must be those of the per-voxel walk.  RGB is a deterministic function of that list,
