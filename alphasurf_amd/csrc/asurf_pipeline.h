@@ -1,5 +1,8 @@
 // asurf_pipeline.h -- the forward pass as three dense kernels (gfx950, wave64).
 //
+//   k_sweep (asurf_sweep.h): the work voxels of every ray, found slab-parallel in closed form, into the tables
+//            described under k_walk; the default.  k_walk / k_walk_seg below find them by stepping: they serve
+//            the calls that test the `live` plane, ASURF_WALK=step, and the tests' per-voxel reference.
 //   k_walk : one ray per lane, nothing but the hierarchical DDA (walk_hier: empty 8^3 bricks are
 //            left in one step) + occupancy-bit tests (few registers, many waves per SIMD).  The
 //            first C1 work voxels of a ray go to a lane-coalesced table [C1][Q]; a ray with more
@@ -8,15 +11,15 @@
 //            also appended to a dense list (slot-major within a wave).
 //            Batches that do not fill the chip several times over use k_walk_seg: S lanes per ray, each
 //            walking one t-segment (the walk is a serial chain; see the kernel).
-//   k_geom : one WORK VOXEL per lane, a fixed grid of kListBlocks blocks striding over the dense
-//            list (and, in a second launch, over the spill list): every lane is busy no matter how
+//   k_geom : one WORK VOXEL per lane, a fixed grid of blocks striding over the dense
+//            list, then over the spill list: every lane is busy no matter how
 //            the work voxels are spread over rays, and no block is dispatched only to exit.
 //            Gathers the 8 corners, forms and solves the cubic (f64), validates the roots and
 //            leaves up to 3 sample candidates per voxel in a sharded pool.
 //   k_comp : one ray per lane again, for what is inherently sequential along a ray: the
 //            sigma gate, truncation window, compositing, the sample cache of the fused losses
-//            and the records the replaying backward kernel consumes.  Shading stays
-//            wave-cooperative (coop_shade_fwd).
+//            and the records the replaying backward kernel consumes.  It visits only the slots
+//            k_geom marked (cand_mask).  Shading stays wave-cooperative (pair_shade_fwd).
 //
 // A ray is handed back to the one-kernel path (k_forward with a compacted ray list) only
 // when a voxel yields more than 3 candidates or a pool runs out; results are identical.
