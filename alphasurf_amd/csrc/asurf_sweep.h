@@ -32,8 +32,9 @@
 //   phase 4  per ray: counts, spill slice, the block's cells of the dense list (one atomic per block)
 //   phase 5  lane = entry: rank among the ray's surviving keys = its slot; table / spill slice / dense list
 //            written as k_walk does
-// Rays that are not regular (non-finite origin or direction) or that collect more than
-// K = kSweepKeys / (rays per block) entries are handed to the one-kernel path (P.flagged), as k_walk does for rays it cannot place.
+// Rays that are not regular (non-finite origin or direction) or that collect more entries than their share K of the
+// block's key buffer (at least 128) are handed to the one-kernel path (P.flagged), as k_walk does for rays it
+// cannot place.
 #pragma once
 #include "asurf_pipeline.h"
 
@@ -65,7 +66,7 @@ struct SweepRay {  // 144 bytes
     int bs_a, bs_b, bs_c, pad;        // brick strides of the fine planes
 };
 
-static_assert(kPipeC1 <= 64, "phase 3b holds one table slot per lane of a wave");
+static_assert(kPipeC1 <= 64, "phase 4 holds one table slot per lane of a wave");
 __device__ __forceinline__ int sweep_clampi(int v, int lo, int hi) { return min(max(v, lo), hi); }
 
 // LDS is what limits the number of resident blocks (every phase waits on memory or on a barrier, so the
@@ -74,13 +75,13 @@ __device__ __forceinline__ int sweep_clampi(int v, int lo, int hi) { return min(
 __global__ void __launch_bounds__(kSweepMaxThreads)
 k_sweep(KGrid g, KOpt o, const float* __restrict__ origins, const float* __restrict__ dirs, long long Q,
         PipeBuf P, int lpr_log2, int rpb, int K, int want_cut, int task_cap) {
-    extern __shared__ uint4 s_dyn4[];   // [rpb rays] [task_cap tasks] [kSweepKeys keys]
+    extern __shared__ uint4 s_dyn4[];   // [rpb rays] [task_cap tasks] [rpb * K keys]
     SweepRay* s_ray = reinterpret_cast<SweepRay*>(s_dyn4);
     uint2* s_tasks = reinterpret_cast<uint2*>(s_ray + rpb);  // x: ray | layer | brick b | brick c, y: brick index
     unsigned* s_key = reinterpret_cast<unsigned*>(s_tasks + task_cap);
     __shared__ int s_cnt[kSweepMaxRays];      // entries found per ray
     __shared__ int s_n[kSweepMaxRays];        // entries placed per ray (0 when handed back)
-    __shared__ int s_eend[kSweepMaxRays];     // inclusive prefix of s_n
+    __shared__ int s_eend[kSweepMaxRays];     // inclusive prefix of the rays' found counts (entries in s_key)
     __shared__ int s_slot0[64];               // first list cell of each table slot, within the block's segment
     __shared__ int s_spb[kSweepMaxRays];      // spill base of the ray
     __shared__ int s_ntask, s_lbase;
