@@ -264,6 +264,10 @@ def main():
         roofline = dict(bound="hbm", kernel=dom_name, achieved=round(achieved, 1), peak=peak, unit="GB/s",
                         frac=round(achieved / peak, 4), traffic=traffic,
                         traffic_GBps=(round(traffic / (dom_ms * 1e-3) / 1e9, 1) if traffic else None),
+                        note="achieved = bytes of SURVEY.md 8(d)'s compulsory-traffic model of the REFERENCE algorithm "
+                             "(8 link loads per traversed voxel, a second traversal in the backward pass) / time; "
+                             "the kernels find the work voxels by bit tests and replay samples, so they move far "
+                             "fewer real bytes (traffic, traffic_GBps) and frac exceeds 1",
                         algorithmic_bytes_per_launch=dom_bytes, avg_launch_ms=round(dom_ms, 4),
                         per_kernel_ms={k: round(v, 4) for k, v in spans.items()},
                         per_kernel_algorithmic_GBps={k: round(shares.get(k, 0.0) / (v * 1e-3) / 1e9, 1)
