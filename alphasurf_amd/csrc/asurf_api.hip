@@ -843,8 +843,8 @@ static int optim_launch(bool rms_mode, float* data, float* rms, float* grad, int
     if (!data || !grad || (rms_mode && !rms)) return fail(ASURF_E_INVALID, "optim step: NULL tensor");
     if (n_rows < 0 || n_cols <= 0 || n_indices < 0) return fail(ASURF_E_INVALID, "optim step: bad shape");
     if (lr_last < 0.f) lr_last = lr;  // optim_kernel.cu:169
-    const int mode = mask ? 1 : (indices ? 2 : 0);
-    if (n_idx_dev) n_indices = std::min<int64_t>(n_rows, 1 << 18);  // launch shape only: the kernels stride to the count
+    const int mode = n_idx_dev ? 2 : (mask ? 1 : (indices ? 2 : 0));
+    if (n_idx_dev) n_indices = n_rows;  // launch shape only (the kernels stride to what they find on the device)
     if (mode == 2 && n_indices == 0) return 0;  // empty index list: nothing to do
     const long long total = (mode == 2 ? n_indices : n_rows) * (long long)n_cols;
     if (total == 0) return 0;
@@ -908,7 +908,8 @@ static int optim_masked(bool rms_mode, float* data, float* rms, float* grad, int
     hipLaunchKernelGGL(k_compact_rows, dim3((unsigned)((n_rows + kCompactRowsPerBlock - 1) / kCompactRowsPerBlock)),
                        dim3(256), 0, s, mask, (long long)n_rows, rows, count);
     if (int e = launch_error("k_compact_rows")) return e;
-    return optim_launch(rms_mode, data, rms, grad, n_rows, n_cols, nullptr, reinterpret_cast<const int64_t*>(rows), 0,
+    // (the step kernel reads the count: a list that names a quarter of the rows or more is not walked, the mask is)
+    return optim_launch(rms_mode, data, rms, grad, n_rows, n_cols, mask, reinterpret_cast<const int64_t*>(rows), 0,
                         beta, lr, epsilon, minval, lr_last, stream, count);
 }
 

@@ -76,7 +76,10 @@ k_optim_rows(float* __restrict__ data, float* __restrict__ rms, float* __restric
              int cp_shift, int mode, const uint8_t* __restrict__ mask, const long long* __restrict__ indices,
              long long n_idx, float beta, float lr, float epsilon, float minval, float lr_last,
              const int* __restrict__ n_idx_dev) {
-    if (n_idx_dev != nullptr) n_idx = *n_idx_dev;
+    if (n_idx_dev != nullptr) {  // the list is k_compact_rows': walk it if it is short, else the mask it came from
+        n_idx = *n_idx_dev;
+        mode = (mask != nullptr && 4 * n_idx >= n_rows) ? 1 : 2;
+    }
     const long long groups = mode == 2 ? n_idx : n_rows;
     const long long stride = ((long long)gridDim.x * blockDim.x) >> cp_shift;
     const int chnl = (int)(threadIdx.x & ((1u << cp_shift) - 1u));
@@ -98,7 +101,10 @@ k_optim_step(float* __restrict__ data, float* __restrict__ rms, float* __restric
              long long n_rows, int n_cols, int mode, const uint8_t* __restrict__ mask,
              const long long* __restrict__ indices, long long n_idx, float beta, float lr,
              float epsilon, float minval, float lr_last, const int* __restrict__ n_idx_dev) {
-    if (n_idx_dev != nullptr) n_idx = *n_idx_dev;
+    if (n_idx_dev != nullptr) {
+        n_idx = *n_idx_dev;
+        mode = (mask != nullptr && 4 * n_idx >= n_rows) ? 1 : 2;
+    }
     const long long total = (mode == 2 ? n_idx : n_rows) * n_cols;
     const long long stride = (long long)gridDim.x * blockDim.x;
     for (long long tid = (long long)blockIdx.x * blockDim.x + threadIdx.x; tid < total; tid += stride) {

@@ -168,7 +168,7 @@ def _rmsprop_ref(data, rms, grad, rows, beta, lr, eps, minval, lr_last):
 
 
 @pytest.mark.parametrize("c", [27, 1])
-@pytest.mark.parametrize("kind", ["all", "mask", "mask_none", "mask_all", "index", "empty_index"])
+@pytest.mark.parametrize("kind", ["all", "mask", "mask_sparse", "mask_none", "mask_all", "index", "empty_index"])
 def test_optimizer_steps(env, kind, c):
     torch, svox2 = env
     import svox2.csrc as _C
@@ -180,7 +180,8 @@ def test_optimizer_steps(env, kind, c):
     if kind == "all":
         indexer, rows = torch.empty((), device="cuda"), np.arange(n)
     elif kind.startswith("mask"):
-        m = rs.rand(n) < {"mask": 0.3, "mask_none": -1.0, "mask_all": 2.0}[kind]
+        # (a mask that names under a quarter of the rows is walked as a list built on the device, a fuller one as it is)
+        m = rs.rand(n) < {"mask": 0.3, "mask_sparse": 0.05, "mask_none": -1.0, "mask_all": 2.0}[kind]
         indexer, rows = torch.from_numpy(m).cuda(), np.nonzero(m)[0]
     elif kind == "index":
         rows = np.sort(rs.choice(n, 400, replace=False))
