@@ -578,7 +578,6 @@ class SparseGrid(nn.Module):
             holder.grad_surface_out = grad["surface_data"]
         holder.grad_sh_out = grad["sh_data"]
         holder.mask_out = self.sparse_grad_indexer
-        self._masks_written()
         if backend == "cuvol":  # :3625-3634
             _C.volume_render_cuvol_fused(self._to_cpp(), rays._to_cpp(), self.opt._to_cpp(randomize=randomize),
                                          rgb_gt, beta_loss, sparsity_loss, rgb_out, holder)
@@ -999,20 +998,12 @@ class SparseGrid(nn.Module):
         """:6295-6299"""
         if self.sparse_grad_indexer is None:
             return torch.empty((0,), dtype=torch.bool, device=self.density_data.device)
-        self._masks_written()  # the caller hands it to a kernel, which writes through the raw pointer
         return self.sparse_grad_indexer
 
     def _get_sparse_sh_grad_indexer(self):
         if self.sparse_sh_grad_indexer is None:
             return torch.empty((0,), dtype=torch.bool, device=self.density_data.device)
-        self._masks_written()
         return self.sparse_sh_grad_indexer
-
-    def _masks_written(self):
-        """The HIP kernels set mask bytes through raw pointers, which torch's `_version` does not see: every
-        method that hands a mask to a kernel bumps this generation, and the mask -> index-list cache of
-        `_maybe_convert_sparse_grad_indexer` is keyed on it."""
-        self.__dict__["_mask_gen"] = self.__dict__.get("_mask_gen", 0) + 1
 
     def _get_h(self):
         """:3228-3232"""
