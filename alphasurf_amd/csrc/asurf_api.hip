@@ -362,25 +362,11 @@ bool use_pipeline(const asurf_grid* grid, const asurf_rays* rays, const asurf_re
            grid->size[0] <= 1024 && grid->size[1] <= 1024 && grid->size[2] <= 1024;
 }
 
-// The one-kernel forward.  `pipeline` = the three-kernel pipeline runs first and this kernel
-// only renders the rays it handed back (k_forward's ray_filter).
-template <int B>
-int run_forward(const Launch& L, const asurf_rays* rays, float* rgb_out, int M, bool cache,
-                bool record, uint64_t* counters, bool pipeline) {
-    float* ca = reinterpret_cast<float*>(L.ws + L.ML.off_cache_a);
-    float* cw = reinterpret_cast<float*>(L.ws + L.ML.off_cache_w);
-    float* ct = reinterpret_cast<float*>(L.ws + L.ML.off_cache_t);
-    int* cn = reinterpret_cast<int*>(L.ws + L.ML.off_cache_n);
-    int* rv = record ? reinterpret_cast<int*>(L.ws + L.ML.off_rec_v) : nullptr;
-    int* rm = record ? reinterpret_cast<int*>(L.ws + L.ML.off_rec_m) : nullptr;
-    int* rn = record ? reinterpret_cast<int*>(L.ws + L.ML.off_rec_n) : nullptr;
-    float* rf = record ? reinterpret_cast<float*>(L.ws + L.ML.off_rec_f) : nullptr;
-    auto* cnt = reinterpret_cast<unsigned long long*>(counters);
+// The first two stages of the forward pipeline: the work voxels of every ray (k_sweep, or the stepping walk) and
+// their sample candidates (k_geom), left in the per-ray tables and the candidate pool that `P` names.
+int find_candidates(const Launch& L, const asurf_rays* rays, bool record, PipeBuf& P) {
     const long long Q = rays->n_rays;
-    const int* ray_list = nullptr;
-    const int* n_list = nullptr;
-    if (pipeline) {
-        PipeBuf P;
+    {
         P.items = reinterpret_cast<int*>(L.ws + L.ML.off_p_items);
         P.citem = reinterpret_cast<int*>(L.ws + L.ML.off_p_citem);
         P.n_items = reinterpret_cast<int*>(L.ws + L.ML.off_p_nitems);
@@ -444,6 +430,30 @@ int run_forward(const Launch& L, const asurf_rays* rays, float* rgb_out, int M, 
         hipLaunchKernelGGL(k_geom, dim3(list_blocks(Q, 16)), dim3(kBlock), 0, L.stream, L.g, L.o, rays->origins,
                            rays->dirs, Q, P);
         prof_after("k_geom", 1, L.stream);
+    }
+    return launch_error("forward pipeline");
+}
+
+// The one-kernel forward.  `pipeline` = the three-kernel pipeline runs first and this kernel
+// only renders the rays it handed back (k_forward's ray_filter).
+template <int B>
+int run_forward(const Launch& L, const asurf_rays* rays, float* rgb_out, int M, bool cache,
+                bool record, uint64_t* counters, bool pipeline) {
+    float* ca = reinterpret_cast<float*>(L.ws + L.ML.off_cache_a);
+    float* cw = reinterpret_cast<float*>(L.ws + L.ML.off_cache_w);
+    float* ct = reinterpret_cast<float*>(L.ws + L.ML.off_cache_t);
+    int* cn = reinterpret_cast<int*>(L.ws + L.ML.off_cache_n);
+    int* rv = record ? reinterpret_cast<int*>(L.ws + L.ML.off_rec_v) : nullptr;
+    int* rm = record ? reinterpret_cast<int*>(L.ws + L.ML.off_rec_m) : nullptr;
+    int* rn = record ? reinterpret_cast<int*>(L.ws + L.ML.off_rec_n) : nullptr;
+    float* rf = record ? reinterpret_cast<float*>(L.ws + L.ML.off_rec_f) : nullptr;
+    auto* cnt = reinterpret_cast<unsigned long long*>(counters);
+    const long long Q = rays->n_rays;
+    const int* ray_list = nullptr;
+    const int* n_list = nullptr;
+    if (pipeline) {
+        PipeBuf P;
+        if (int e = find_candidates(L, rays, record, P)) return e;
         if (cache)
             hipLaunchKernelGGL((k_comp<B, true>), L.ray_grid, dim3(kBlock), 0, L.stream, L.g, L.o,
                                rays->dirs, Q, P, rgb_out, M, ca, cw, ct, cn, rv, rm, rn, kRecDepth, rf);
@@ -644,13 +654,27 @@ int leg_bwd(dim3 gd, hipStream_t s, const KGrid& g, const KOpt& o, const KGrads&
 }
 
 template <int MODE>
-int launch_eval(const Launch& L, const asurf_rays* rays, float param, int max_sample, float* out0, float* out1) {
+int launch_eval(const Launch& L, const asurf_rays* rays, float param, int max_sample, float* out0, float* out1,
+                bool pipeline) {
+    const long long Q = rays->n_rays;
+    const int* ray_list = nullptr;
+    const int* n_list = nullptr;
+    if (pipeline) {
+        PipeBuf P;
+        if (int e = find_candidates(L, rays, false, P)) return e;
+        hipLaunchKernelGGL((k_eval_comp<MODE>), L.ray_grid, dim3(kBlock), 0, L.stream, L.g, L.o, rays->dirs, Q, P, param,
+                           max_sample, out0, out1);
+        prof_after("k_eval_comp", 1, L.stream);
+        ray_list = P.flagged;
+        n_list = P.counters;
+    }
     if (L.coarse_in_lds)
         hipLaunchKernelGGL((k_eval<MODE, true>), L.ray_grid, dim3(kBlock), L.dyn_lds, L.stream, L.g, L.o,
-                           rays->origins, rays->dirs, (long long)rays->n_rays, param, max_sample, out0, out1);
+                           rays->origins, rays->dirs, Q, param, max_sample, out0, out1, ray_list, n_list);
     else
         hipLaunchKernelGGL((k_eval<MODE, false>), L.ray_grid, dim3(kBlock), 0, L.stream, L.g, L.o,
-                           rays->origins, rays->dirs, (long long)rays->n_rays, param, max_sample, out0, out1);
+                           rays->origins, rays->dirs, Q, param, max_sample, out0, out1, ray_list, n_list);
+    prof_after(pipeline ? "k_eval_fallback" : "k_eval", 1, L.stream);
     return launch_error("k_eval");
 }
 
@@ -1219,20 +1243,27 @@ int asurf_render_eval_surf_trav(const asurf_grid* grid, const asurf_rays* rays,
     asurf_render_options eo = *opt;
     eo.sigma_thresh = -INFINITY;
     eo.surf_fake_sample = 0;
+    eo.only_outward_intersect = 0;  // (these renders take every crossing, surf_trav.cu:564-1705)
+    // through k_sweep + k_geom when the caller's workspace holds the per-ray tables (asurf_workspace_bytes with the
+    // call's ray count); with a pyramid-only workspace, or where the one-kernel form is needed, the stepping walk
+    const char* ev = getenv("ASURF_EVAL");
+    const bool pipe = !(ev && strcmp(ev, "walk") == 0) && check_grid(grid) == 0 && check_rays(rays) == 0 &&
+                      rays->n_rays > 0 && workspace_bytes >= layout_for(grid->size, rays->n_rays, 0).total &&
+                      use_pipeline(grid, rays, &eo, nullptr);
     Launch L;
-    if (int e = prepare(grid, rays, &eo, 0, workspace, workspace_bytes, stream, L, true)) return e;
+    if (int e = prepare(grid, rays, &eo, 0, workspace, workspace_bytes, stream, L, !pipe)) return e;
     if (grid->size[0] > 1024 || grid->size[1] > 1024 || grid->size[2] > 1024)
         return fail(ASURF_E_INVALID, "render_eval: grid sizes above 1024 are not supported");
     if (rays->n_rays == 0) return 0;
     if (!out0 || (mode == 5 && (!out1 || max_sample < 1)))
         return fail(ASURF_E_INVALID, "render_eval: output tensor missing / max_sample < 1");
     switch (mode) {
-        case 0: return launch_eval<EVAL_EXPECTED>(L, rays, param, max_sample, out0, out1);
-        case 1: return launch_eval<EVAL_MODE_DEPTH>(L, rays, param, max_sample, out0, out1);
-        case 2: return launch_eval<EVAL_FIRST_DEPTH>(L, rays, param, max_sample, out0, out1);
-        case 3: return launch_eval<EVAL_FIRST_ALPHA>(L, rays, param, max_sample, out0, out1);
-        case 4: return launch_eval<EVAL_NORMAL>(L, rays, param, max_sample, out0, out1);
-        default: return launch_eval<EVAL_EXTRACT>(L, rays, param, max_sample, out0, out1);
+        case 0: return launch_eval<EVAL_EXPECTED>(L, rays, param, max_sample, out0, out1, pipe);
+        case 1: return launch_eval<EVAL_MODE_DEPTH>(L, rays, param, max_sample, out0, out1, pipe);
+        case 2: return launch_eval<EVAL_FIRST_DEPTH>(L, rays, param, max_sample, out0, out1, pipe);
+        case 3: return launch_eval<EVAL_FIRST_ALPHA>(L, rays, param, max_sample, out0, out1, pipe);
+        case 4: return launch_eval<EVAL_NORMAL>(L, rays, param, max_sample, out0, out1, pipe);
+        default: return launch_eval<EVAL_EXTRACT>(L, rays, param, max_sample, out0, out1, pipe);
     }
 }
 

@@ -2,8 +2,13 @@
 // without colour, density gate, truncation window or fake samples.  surf_trav.cu:564-1705, kernels
 // :3457-3580.  One ray per lane; the walk is the hierarchical exact DDA of the training path over
 // the per-call occupancy pyramid (links present + a level set inside the voxel's value range).
+//
+// Two forms.  k_eval_comp (the default) runs behind the training path's k_sweep + k_geom: the candidates of every ray
+// are in the pool, in order, and a lane per ray folds them into the requested quantity.  k_eval is the one-kernel
+// form -- the stepping walk with the cubic solved in the loop -- for the rays the pipeline hands back, for
+// stop_thresh > 1 (the render then ends at the first work voxel, sample or not) and for ASURF_EVAL=walk.
 #pragma once
-#include "asurf_kernels.h"
+#include "asurf_pipeline.h"
 
 namespace asurf {
 
@@ -19,14 +24,21 @@ enum EvalMode {
 template <int MODE, bool CLDS>
 __global__ void __launch_bounds__(kBlock)
 k_eval(KGrid g, KOpt o, const float* __restrict__ origins, const float* __restrict__ dirs, long long Q,
-       float param, int max_sample, float* __restrict__ out0, float* __restrict__ out1) {
+       float param, int max_sample, float* __restrict__ out0, float* __restrict__ out1,
+       const int* __restrict__ ray_list, const int* __restrict__ n_list) {
     extern __shared__ unsigned int s_coarse[];
     const int tid = threadIdx.x;
+    // ray_list: only the rays the pipeline handed back (usually none: leave before anything is staged)
+    if (ray_list != nullptr && (long long)blockIdx.x * kBlock >= (long long)*n_list) return;
     if constexpr (CLDS) {
         for (int i = tid; i < g.coarse_words; i += kBlock) s_coarse[i] = g.coarse[i];
         __syncthreads();
     }
-    const long long q = (long long)blockIdx.x * kBlock + tid;
+    long long q = (long long)blockIdx.x * kBlock + tid;
+    if (ray_list != nullptr) {
+        if (q >= (long long)*n_list) return;
+        q = ray_list[q];
+    }
     if (q >= Q) return;
     Ray r;
 #pragma unroll
@@ -115,6 +127,107 @@ k_eval(KGrid g, KOpt o, const float* __restrict__ origins, const float* __restri
         }
         if constexpr (MODE == EVAL_EXPECTED || MODE == EVAL_MODE_DEPTH) {
             if (expf(log_transmit) < o.stop_thresh) break;  // once per visited voxel, :786-789
+        }
+    }
+    if constexpr (MODE == EVAL_EXPECTED) my0[0] = outv;
+    else if constexpr (MODE == EVAL_MODE_DEPTH) my0[0] = (weight_acc > param) ? outv : 0.f;
+    else if constexpr (MODE == EVAL_FIRST_DEPTH || MODE == EVAL_FIRST_ALPHA) my0[0] = res[0];
+    else if constexpr (MODE == EVAL_NORMAL) {
+        my0[0] = res[0];
+        my0[1] = res[1];
+        my0[2] = res[2];
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// The same quantities from the candidates k_geom left (surf_trav.cu:564-1705): one ray per lane, its candidates in
+// order (k_comp's way through the slots: cand_mask).  `ts` of a candidate is t_close + st rounded to float; the
+// reference forms the depth from the double sum (a relative 1e-7 apart).
+template <int MODE>
+__global__ void __launch_bounds__(kBlock)
+k_eval_comp(KGrid g, KOpt o, const float* __restrict__ dirs, long long Q, PipeBuf P, float param, int max_sample,
+            float* __restrict__ out0, float* __restrict__ out1) {
+    const long long q = (long long)blockIdx.x * kBlock + threadIdx.x;
+    if (q >= Q) return;
+    const int n = P.n_items[q];
+    if (n < 0) return;  // handed back: k_eval renders this ray
+    const float ds0 = dirs[3 * q] * g.scaling[0], ds1 = dirs[3 * q + 1] * g.scaling[1], ds2 = dirs[3 * q + 2] * g.scaling[2];
+    const float world_step = (1.f / sqrtf(ds0 * ds0 + ds1 * ds1 + ds2 * ds2)) * o.step_size;
+    constexpr int NOUT = (MODE == EVAL_NORMAL) ? 3 : 1;
+    float* my0 = out0 + (size_t)q * (MODE == EVAL_EXTRACT ? max_sample : NOUT);
+    float* my1 = (MODE == EVAL_EXTRACT) ? out1 + (size_t)q * max_sample : nullptr;
+    float outv = 0.f, weight_acc = 0.f, max_weight = -1.f, log_transmit = 0.f;
+    float res[3] = {0.f, 0.f, 0.f};
+    int sample_id = 0;
+    bool done = false;
+    const unsigned long long cmask = P.cand_mask[q];
+    const bool scan = (cmask >> 63) != 0ull;
+    unsigned long long todo = cmask;
+    const int spb = (n > P.C1) ? P.sp_base[q] : 0;
+    int s_scan = 0;
+    while (!done) {
+        int s;
+        if (scan) {
+            if (s_scan >= n) break;
+            s = s_scan++;
+        } else {
+            if (todo == 0ull) break;
+            s = __ffsll((long long)todo) - 1;
+            todo &= todo - 1ull;
+        }
+        const int ci = (s < P.C1) ? P.citem[(size_t)s * Q + q] : P.sp_citem[spb + s - P.C1];
+        const int nc = ci & 3, base = ci >> 2;
+        for (int c = 0; c < nc && !done; ++c) {
+            const CandRec cr = P.pool[base + c];
+            const float alpha = alpha_act(cr.raw, o.alpha_activation_type);
+            const double depth = (double)cr.ts / (double)o.step_size * (double)world_step;
+            if constexpr (MODE == EVAL_EXPECTED || MODE == EVAL_MODE_DEPTH) {
+                const float pcnt = -1 * logf(1 - alpha);
+                const float weight = expf(log_transmit) * (1.f - expf(-pcnt));
+                log_transmit -= pcnt;
+                if constexpr (MODE == EVAL_EXPECTED) {
+                    outv = (float)((double)outv + (double)weight * depth);
+                } else {
+                    weight_acc += weight;
+                    if (weight > max_weight) {
+                        max_weight = weight;
+                        outv = (float)depth;
+                    }
+                }
+            } else if constexpr (MODE == EVAL_FIRST_DEPTH) {
+                if (alpha > param) {
+                    res[0] = (float)depth;
+                    done = true;
+                }
+            } else if constexpr (MODE == EVAL_FIRST_ALPHA) {
+                if (alpha > param) {
+                    res[0] = alpha;
+                    done = true;
+                }
+            } else if constexpr (MODE == EVAL_NORMAL) {
+                if (alpha > 0) {
+                    const int pv = (s < P.C1) ? P.items[(size_t)s * Q + q] : P.sp_items[spb + s - P.C1];
+                    const int32_t* p = g.links + ((size_t)(pv >> 20) * g.offx + (size_t)((pv >> 10) & 1023) * g.offy +
+                                                  (pv & 1023));
+                    const int lk[8] = {p[0], p[1], p[g.offy], p[g.offy + 1], p[g.offx], p[g.offx + 1],
+                                       p[g.offx + g.offy], p[g.offx + g.offy + 1]};
+                    float surf[8];
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) surf[i] = g.surface[lk[i]];
+                    const float pos[3] = {cr.px, cr.py, cr.pz};
+                    field_grad(surf, pos, res);
+                    done = true;
+                }
+            } else {
+                if (alpha > param) {
+                    my0[sample_id] = (float)depth;
+                    my1[sample_id] = alpha;
+                    if (++sample_id >= max_sample) done = true;
+                }
+            }
+        }
+        if constexpr (MODE == EVAL_EXPECTED || MODE == EVAL_MODE_DEPTH) {
+            if (nc > 0 && expf(log_transmit) < o.stop_thresh) break;  // once per visited voxel, :786-789
         }
     }
     if constexpr (MODE == EVAL_EXPECTED) my0[0] = outv;

@@ -696,7 +696,7 @@ def _render_eval(grid, rays, opt, mode, param, max_sample=1):
         else:
             out0 = torch.empty((q,), dtype=torch.float32, device=dev)
             out1 = None
-        nb = _L.workspace_bytes(grid.links.shape, 0, 0)
+        nb = _L.workspace_bytes(grid.links.shape, q, 0)  # (with the per-ray tables: the render runs behind k_sweep)
         ws = _workspace(dev, nb)
         _L.check(_L.lib().asurf_render_eval_surf_trav(
             C.byref(g), C.byref(r), C.byref(o), int(mode), float(param), int(max_sample), _ptr(out0),

@@ -83,3 +83,17 @@ def test_grid_methods(hip):
     assert pts2.shape[0] == al.shape[0] and (al > 0.2).all()
     # the points lie on the initial sphere-like surface, inside the unit cube
     assert pts2.abs().max() <= 1.0 + 1e-3
+
+
+def test_both_forms_agree(hip, monkeypatch):
+    """The render behind k_sweep + k_geom and the stepping form (ASURF_EVAL=walk) on the same rays; three level sets
+    make some voxels hold more than three crossings, which hands those rays to the stepping form inside the first."""
+    sc, o, d = sparse_case(7, level_set=(-0.3, 0.0, 0.4))
+    for what, param, ms in (("expected", 0.0, 1), ("mode", 0.2, 1), ("sigma_thresh", 0.3, 1), ("alpha", 0.3, 1),
+                            ("normal", 0.0, 1), ("extract_pts", 0.05, 6)):
+        monkeypatch.delenv("ASURF_EVAL", raising=False)
+        a = hip.render_eval(sc, o, d, OPTION_SETS["syn_yaml"], what, param, ms)
+        monkeypatch.setenv("ASURF_EVAL", "walk")
+        b = hip.render_eval(sc, o, d, OPTION_SETS["syn_yaml"], what, param, ms)
+        for x, y in zip(a if isinstance(a, tuple) else (a,), b if isinstance(b, tuple) else (b,)):
+            np.testing.assert_allclose(x, y, rtol=2e-6, atol=2e-6, err_msg=what)
