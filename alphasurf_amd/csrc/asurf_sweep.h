@@ -176,6 +176,10 @@ k_sweep(KGrid g, KOpt o, const float* __restrict__ origins, const float* __restr
         s_cnt[tid] = 0;
     }
     __syncthreads();
+    if (((o.debug >> 8) & 7) == 1) {  // TEMP phase timing
+        if (tid < rpb && q0 + tid < Q) { P.n_items[q0 + tid] = 0; P.cut[q0 + tid] = 0x7fffffff; P.sp_base[q0 + tid] = 0; P.cand_mask[q0 + tid] = 0ull; }
+        return;
+    }
 
     // Phases 1 and 2 run once over all rays of the block; if the task list would not hold them (scenes where
     // most bricks hold a flagged voxel) they run again in four passes over a quarter of the rays each, which
@@ -227,6 +231,10 @@ k_sweep(KGrid g, KOpt o, const float* __restrict__ origins, const float* __restr
         continue;
     }
 
+    if (((o.debug >> 8) & 7) == 2) {  // TEMP phase timing
+        if (tid < rpb && q0 + tid < Q) { P.n_items[q0 + tid] = 0; P.cut[q0 + tid] = 0x7fffffff; P.sp_base[q0 + tid] = 0; P.cand_mask[q0 + tid] = 0ull; }
+        return;
+    }
     // ---- phase 2: lane = task.  The brick's 8 words (one 64-byte line); the ray's (b, c) position at the 9 slab
     // planes, each shared by two slabs; per slab the rectangle mask of the cells between two planes ----
     const int ntask = min(s_ntask, task_cap);
@@ -287,6 +295,10 @@ k_sweep(KGrid g, KOpt o, const float* __restrict__ origins, const float* __restr
     }
     }  // passes
 
+    if (((o.debug >> 8) & 7) == 3) {  // TEMP phase timing
+        if (tid < rpb && q0 + tid < Q) { P.n_items[q0 + tid] = 0; P.cut[q0 + tid] = 0x7fffffff; P.sp_base[q0 + tid] = 0; P.cand_mask[q0 + tid] = 0ull; }
+        return;
+    }
     // ---- phase 3: exact membership, lane = entry.  s_eend: inclusive prefix of the rays' FOUND counts ----
     if (tid < 64) {
         const int found = (tid < rpb) ? min(s_cnt[tid], K) : 0;
@@ -349,6 +361,10 @@ k_sweep(KGrid g, KOpt o, const float* __restrict__ origins, const float* __restr
     }
     __syncthreads();
 
+    if (((o.debug >> 8) & 7) == 4) {  // TEMP phase timing
+        if (tid < rpb && q0 + tid < Q) { P.n_items[q0 + tid] = 0; P.cut[q0 + tid] = 0x7fffffff; P.sp_base[q0 + tid] = 0; P.cand_mask[q0 + tid] = 0ull; }
+        return;
+    }
     // ---- phase 4: per ray, counts and allocations ----
     if (tid < rpb) {
         const long long q = q0 + tid;
@@ -399,6 +415,10 @@ k_sweep(KGrid g, KOpt o, const float* __restrict__ origins, const float* __restr
     }
     __syncthreads();
 
+    if (((o.debug >> 8) & 7) == 5) {  // TEMP phase timing
+        if (tid < rpb && q0 + tid < Q) { P.n_items[q0 + tid] = 0; P.cut[q0 + tid] = 0x7fffffff; P.sp_base[q0 + tid] = 0; P.cand_mask[q0 + tid] = 0ull; }
+        return;
+    }
     // ---- phase 5: per surviving entry, its rank among the ray's keys is its slot ----
     for (int t = tid; t < n_found; t += nthreads) {
         int rl = 0;
