@@ -9,6 +9,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <mutex>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -239,6 +240,14 @@ KOpt make_kopt(const asurf_render_options* o) {
     k.trunc_vol_weight_min = o->trunc_vol_weight_min;
     const char* dbg = getenv("ASURF_DEBUG");
     k.debug = dbg ? atoi(dbg) : 0;
+#ifdef ASURF_TIMELINE
+    static std::once_flag tl_once;  // ASURF_TIMELINE=<kernel id>: that kernel's waves leave their times (asurf_device.h)
+    std::call_once(tl_once, [] {
+        const char* tl = getenv("ASURF_TIMELINE");
+        const int id = tl ? atoi(tl) : 0;
+        if (id > 0) (void)hipMemcpyToSymbol(HIP_SYMBOL(g_tl_kernel), &id, sizeof(int));
+    });
+#endif
     return k;
 }
 
@@ -343,7 +352,9 @@ int prepare(const asurf_grid* grid, const asurf_rays* rays, const asurf_render_o
 // Blocks of the kernels that stride over a dense list whose length only the device knows: enough for the list a
 // batch of n_rays can produce to be spread over the chip (a ray rarely holds more than 16 work voxels, the table
 // keeps 32), but no more than kListBlocks -- 2048 blocks that find an empty list still cost their dispatch, which
-// is most of these kernels' time at the training script's batch size.
+// is most of these kernels' time at the training script's batch size.  (Grids of exactly the blocks the device keeps
+// resident -- every wave starts at once and strides the same number of turns -- change nothing: these kernels run at
+// the rate of their memory requests, not of their wave slots; variants/timeline.py.)
 unsigned list_blocks(long long n_rays, int per_ray) {
     const long long want = (n_rays * per_ray + kBlock - 1) / kBlock;
     return (unsigned)std::min<long long>(std::max<long long>(want, 64), kListBlocks);
@@ -966,6 +977,19 @@ int asurf_profile_read(float* ms, int n) {
         ms[g_span_group[i]] += t;
     }
     return 0;
+}
+
+int asurf_debug_read_timeline(void* dst, int max_recs) {
+    if (!dst || max_recs < 1) return fail(ASURF_E_INVALID, "asurf_debug_read_timeline: NULL buffer"), -1;
+#ifdef ASURF_TIMELINE
+    const int n = std::min(max_recs, kTimelineCap);
+    if (hipDeviceSynchronize() != hipSuccess ||
+        hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_timeline), (size_t)n * sizeof(TimelineRec)) != hipSuccess)
+        return fail(ASURF_E_LAUNCH, "asurf_debug_read_timeline: copy failed"), -1;
+    return n;
+#else
+    return fail(ASURF_E_INVALID, "asurf_debug_read_timeline: the library was built without TIMELINE=1"), -1;
+#endif
 }
 
 int asurf_profile_read_spans(char* names, size_t names_cap, float* ms, int max_spans) {

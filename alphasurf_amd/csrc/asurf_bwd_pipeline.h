@@ -268,6 +268,7 @@ k_bwd_seq(KOpt o, KLoss L, float trunc_a, long long Q, const float* __restrict__
 template <int B>
 __global__ void __launch_bounds__(kBlock)
 k_bwd_sh(KGrid g, KGrads G, int want_dpos, const float* __restrict__ dirs, long long Q, SampleRec S) {
+    const TlScope tl(6);
     using C = Coop<B>;
     constexpr int SP = B | 1;  // odd LDS row stride of the per-sample SH basis
     __shared__ float s_sph[kBlock * SP];
@@ -442,6 +443,7 @@ k_bwd_sh(KGrid g, KGrads G, int want_dpos, const float* __restrict__ dirs, long 
         S.gz[idx] = go.z;
     }
   }
+  tl.end();
 }
 
 __device__ __forceinline__ void acc8(float* dst, const float* w) {
@@ -453,6 +455,9 @@ __device__ __forceinline__ void acc8(float* dst, const float* w) {
 __global__ void __launch_bounds__(kBlock)
 k_bwd_geo(KGrid g, KOpt o, KLoss L, KGrads G, const float* __restrict__ origins,
           const float* __restrict__ dirs, long long Q, SampleRec S) {
+    const TlScope tl(7);
+  __shared__ float s_head_d[kBlock / 64][64][9], s_head_s[kBlock / 64][64][9];  // per wave: the heads' rows (see the scatter)
+  __shared__ int s_head_l[kBlock / 64][64][9];
   const int n_list = *S.n_list;
   const int lane = threadIdx.x & 63;
   const int wave_id = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
@@ -662,21 +667,43 @@ k_bwd_geo(KGrid g, KOpt o, KLoss L, KGrads G, const float* __restrict__ origins,
                 const bool on_prev_face = bp != 0 && ((c ^ bp) & bp) == hip;
                 give[c] = next_shared && !on_prev_face;
             }
+            // The scatter.  An atomic costs one request per 64-byte line an INSTRUCTION touches, whatever the number of
+            // lanes in the line (variants/micro/atomics.hip: 21 G lines/s on the whole chip, scattered floats or rows
+            // alike), and the rows of a voxel's two corners along z are neighbours in memory wherever the links were
+            // numbered in grid order.  So the heads do not issue their eight corners one after the other: they
+            // leave them in LDS, and the wave writes them out eight heads at a time, lane = (head, corner).
+            const int hr = __popcll(H & ((1ull << lane) - 1ull));
+            float* hd = s_head_d[threadIdx.x >> 6][hr];
+            float* hs = s_head_s[threadIdx.x >> 6][hr];
+            int* hl = s_head_l[threadIdx.x >> 6][hr];
 #pragma unroll
             for (int c = 0; c < 8; ++c) {
-                if (!give[c]) {
-                    if (G.grad_density != nullptr) atomicAdd(&G.grad_density[lk8[c]], od[c]);
-                    if (G.grad_surface != nullptr) atomicAdd(&G.grad_surface[lk8[c]], os[c]);
-                    if (G.mask != nullptr) G.mask[lk8[c]] = 1;
+                hd[c] = od[c];
+                hs[c] = os[c];
+                hl[c] = give[c] ? -1 : lk8[c];
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        const int n_heads = __popcll(H);
+        for (int h0 = 0; h0 < n_heads; h0 += 8) {
+            const int hh = h0 + (lane >> 3), c = lane & 7;
+            if (hh < n_heads) {
+                const int lk = s_head_l[threadIdx.x >> 6][hh][c];
+                if (lk >= 0) {
+                    if (G.grad_density != nullptr) atomicAdd(&G.grad_density[lk], s_head_d[threadIdx.x >> 6][hh][c]);
+                    if (G.grad_surface != nullptr) atomicAdd(&G.grad_surface[lk], s_head_s[threadIdx.x >> 6][hh][c]);
+                    if (G.mask != nullptr) G.mask[lk] = 1;
                 }
             }
         }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // (the next turn writes the table again)
     }
     if (G.grad_fake_sample_std != nullptr) {
         const float tot = wave_sum(gstd_acc);
         if (lane == 0 && tot != 0.f) atomicAdd(G.grad_fake_sample_std, tot);
     }
   }
+  tl.end();
 }
 
 }  // namespace asurf

@@ -84,6 +84,46 @@ struct KLoss {  // already scaled by the launcher (surf_trav.cu:3896-3915)
     float norm_l2, norm_l1;  // 2/(3Q), 1/(3Q) with the (global) ray count
 };
 
+// Wave timeline (diagnostics; compiled in with `make TIMELINE=1` only -- the two timestamps a wave carries cost
+// k_geom 64 bytes of scratch per lane and 0.06 ms).  With ASURF_TIMELINE=<kernel id> the waves of ONE kernel leave
+// their start and end on the 100 MHz wall clock and where they ran; asurf_debug_read_timeline() copies the table out
+// (variants/timeline.py).  ids: 1 k_build_masks, 2 k_sweep, 3 k_geom, 6 k_bwd_sh, 7 k_bwd_geo.
+constexpr int kTimelineCap = 1 << 18;
+struct TimelineRec {
+    unsigned long long t0, t1;
+    unsigned hw_id, xcc_id;
+};
+#ifdef ASURF_TIMELINE
+__device__ int g_tl_kernel = 0;
+__device__ TimelineRec g_timeline[kTimelineCap];
+struct TlScope {
+    unsigned long long t0;
+    bool on;
+    __device__ __forceinline__ explicit TlScope(int kernel_id) {
+        on = (g_tl_kernel == kernel_id);
+        t0 = on ? wall_clock64() : 0ull;
+    }
+    __device__ __forceinline__ void end() const {
+        if (on && (threadIdx.x & 63) == 0) {
+            const unsigned w = blockIdx.x * ((blockDim.x + 63u) >> 6) + (threadIdx.x >> 6);
+            if (w < (unsigned)kTimelineCap) {
+                TimelineRec rec;
+                rec.t0 = t0;
+                rec.t1 = wall_clock64();
+                rec.hw_id = __builtin_amdgcn_s_getreg((31 << 11) | 4);    // HW_REG_HW_ID
+                rec.xcc_id = __builtin_amdgcn_s_getreg((31 << 11) | 20);  // HW_REG_XCC_ID
+                g_timeline[w] = rec;
+            }
+        }
+    }
+};
+#else
+struct TlScope {
+    __device__ __forceinline__ explicit TlScope(int) {}
+    __device__ __forceinline__ void end() const {}
+};
+#endif
+
 __device__ __forceinline__ float lerpf(float a, float b, float w) { return fmaf(w, b - a, a); }
 __device__ __forceinline__ float sqrf(float x) { return x * x; }
 __device__ __forceinline__ double sqrd(double x) { return x * x; }

@@ -48,6 +48,7 @@ k_build_masks(KGrid g, float sigma_thresh, int need_surf, unsigned long long* fi
               unsigned long long* fine_live, unsigned int* coarse_work,
               unsigned int* coarse_live, unsigned long long* fine_y, unsigned long long* fine_z,
               int orient_live, int nzg) {
+    const TlScope tl(1);
     const int t = threadIdx.x;
     const int ly = t >> 6, l = t & 63;
     const int zg = blockIdx.x % nzg;
@@ -156,6 +157,7 @@ k_build_masks(KGrid g, float sigma_thresh, int need_surf, unsigned long long* fi
         reinterpret_cast<unsigned char*>(coarse_work)[(size_t)bxy * g.nwz * 4 + zg] = (unsigned char)cw;
         reinterpret_cast<unsigned char*>(coarse_live)[(size_t)bxy * g.nwz * 4 + zg] = (unsigned char)cl;
     }
+    tl.end();
 }
 
 // ------------------------------------------------------------------------------------

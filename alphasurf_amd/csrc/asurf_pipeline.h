@@ -426,6 +426,7 @@ k_walk_seg(KGrid g, KOpt o, const float* __restrict__ origins, const float* __re
 __global__ void __launch_bounds__(kBlock, ASURF_GEOM_WAVES)
 k_geom(KGrid g, KOpt o, const float* __restrict__ origins, const float* __restrict__ dirs,
        long long Q, PipeBuf P) {
+    const TlScope tl(3);
     const int lane = threadIdx.x & 63;
     // the table cells come as kListShards segments: their lengths' running sums (wave-uniform) turn a position in the
     // concatenation into (segment, offset); the spill list follows them (a launch of its own cost 13 us, empty or not)
@@ -574,6 +575,7 @@ k_geom(KGrid g, KOpt o, const float* __restrict__ origins, const float* __restri
         if (SPILL) P.sp_citem[entry] = packed;
         else P.citem[entry] = packed;
     }
+    tl.end();
 }
 
 // ------------------------------------------------------------------------------------

@@ -85,6 +85,7 @@ k_sweep(KGrid g, KOpt o, const float* __restrict__ origins, const float* __restr
     __shared__ int s_slot0[64];               // first list cell of each table slot, within the block's segment
     __shared__ int s_spb[kSweepMaxRays];      // spill base of the ray
     __shared__ int s_ntask, s_lbase;
+    const TlScope tl(2);
     const int tid = threadIdx.x;
     const int nthreads = blockDim.x;
     const long long q0 = (long long)blockIdx.x * rpb;
@@ -176,7 +177,7 @@ k_sweep(KGrid g, KOpt o, const float* __restrict__ origins, const float* __restr
         s_cnt[tid] = 0;
     }
     __syncthreads();
-    if (((o.debug >> 8) & 7) == 1) {  // TEMP phase timing
+    if (((o.debug >> 8) & 7) == 1) {  // diagnostics: ASURF_DEBUG = 256 * n leaves after phase n - 1 (phase timing; nothing is found)
         if (tid < rpb && q0 + tid < Q) { P.n_items[q0 + tid] = 0; P.cut[q0 + tid] = 0x7fffffff; P.sp_base[q0 + tid] = 0; P.cand_mask[q0 + tid] = 0ull; }
         return;
     }
@@ -231,7 +232,7 @@ k_sweep(KGrid g, KOpt o, const float* __restrict__ origins, const float* __restr
         continue;
     }
 
-    if (((o.debug >> 8) & 7) == 2) {  // TEMP phase timing
+    if (((o.debug >> 8) & 7) == 2) {  // diagnostics: ASURF_DEBUG = 256 * n leaves after phase n - 1 (phase timing; nothing is found)
         if (tid < rpb && q0 + tid < Q) { P.n_items[q0 + tid] = 0; P.cut[q0 + tid] = 0x7fffffff; P.sp_base[q0 + tid] = 0; P.cand_mask[q0 + tid] = 0ull; }
         return;
     }
@@ -295,7 +296,7 @@ k_sweep(KGrid g, KOpt o, const float* __restrict__ origins, const float* __restr
     }
     }  // passes
 
-    if (((o.debug >> 8) & 7) == 3) {  // TEMP phase timing
+    if (((o.debug >> 8) & 7) == 3) {  // diagnostics: ASURF_DEBUG = 256 * n leaves after phase n - 1 (phase timing; nothing is found)
         if (tid < rpb && q0 + tid < Q) { P.n_items[q0 + tid] = 0; P.cut[q0 + tid] = 0x7fffffff; P.sp_base[q0 + tid] = 0; P.cand_mask[q0 + tid] = 0ull; }
         return;
     }
@@ -361,7 +362,7 @@ k_sweep(KGrid g, KOpt o, const float* __restrict__ origins, const float* __restr
     }
     __syncthreads();
 
-    if (((o.debug >> 8) & 7) == 4) {  // TEMP phase timing
+    if (((o.debug >> 8) & 7) == 4) {  // diagnostics: ASURF_DEBUG = 256 * n leaves after phase n - 1 (phase timing; nothing is found)
         if (tid < rpb && q0 + tid < Q) { P.n_items[q0 + tid] = 0; P.cut[q0 + tid] = 0x7fffffff; P.sp_base[q0 + tid] = 0; P.cand_mask[q0 + tid] = 0ull; }
         return;
     }
@@ -415,7 +416,7 @@ k_sweep(KGrid g, KOpt o, const float* __restrict__ origins, const float* __restr
     }
     __syncthreads();
 
-    if (((o.debug >> 8) & 7) == 5) {  // TEMP phase timing
+    if (((o.debug >> 8) & 7) == 5) {  // diagnostics: ASURF_DEBUG = 256 * n leaves after phase n - 1 (phase timing; nothing is found)
         if (tid < rpb && q0 + tid < Q) { P.n_items[q0 + tid] = 0; P.cut[q0 + tid] = 0x7fffffff; P.sp_base[q0 + tid] = 0; P.cand_mask[q0 + tid] = 0ull; }
         return;
     }
@@ -453,6 +454,7 @@ k_sweep(KGrid g, KOpt o, const float* __restrict__ origins, const float* __restr
             P.sp_ray[at] = (int)q;
         }
     }
+    tl.end();
 }
 
 }  // namespace asurf

@@ -90,7 +90,7 @@ EXPORTS = [
     "asurf_volume_render_surf_trav", "asurf_volume_render_surf_trav_backward",
     "asurf_volume_render_surf_trav_fused", "asurf_volume_render_surface",
     "asurf_volume_render_surface_backward", "asurf_volume_render_surface_fused",
-    "asurf_test_cubic_root_grad", "asurf_profile_enable", "asurf_profile_read",
+    "asurf_test_cubic_root_grad", "asurf_profile_enable", "asurf_profile_read", "asurf_debug_read_timeline",
     "asurf_profile_read_spans",
     "asurf_rmsprop_step", "asurf_sgd_step", "asurf_optim_scratch_bytes", "asurf_rmsprop_step_masked",
     "asurf_sgd_step_masked", "asurf_ray_voxel_count", "asurf_ray_voxel_fill",

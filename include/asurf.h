@@ -428,6 +428,12 @@ int asurf_profile_enable(int on);
 int asurf_profile_read(float* ms, int n);
 int asurf_profile_read_spans(char* names, size_t names_cap, float* ms, int max_spans);
 
+/* Diagnostics: with ASURF_TIMELINE=<kernel id> in the environment (1 k_build_masks, 2 k_sweep, 3 k_geom, 6 k_bwd_sh,
+ * 7 k_bwd_geo) every wave of that kernel records {start, end} on the 100 MHz wall clock and {HW_ID, XCC_ID};
+ * this copies the first max_recs records (24 bytes each: u64 t0, u64 t1, u32 hw_id, u32 xcc_id; index = wave number
+ * in launch order) of the LAST launch to host memory after a device synchronize.  Returns the record count or -1. */
+int asurf_debug_read_timeline(void* dst, int max_recs);
+
 #ifdef __cplusplus
 }
 #endif
