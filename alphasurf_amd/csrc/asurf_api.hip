@@ -51,7 +51,7 @@ struct MaskLayout {
     size_t off_p_items, off_p_citem, off_p_nitems, off_p_cut, off_p_flagged, off_p_counters, off_p_pool;
     size_t off_p_cand;  // cand_mask [Q]
     size_t off_p_spbase, off_p_spill, off_p_list, off_rec_list;
-    int pool_shard_cap, sp_cap, list_cap;
+    int pool_shard_cap, sp_cap, list_cap, band_rays;
     size_t total;
 };
 
@@ -138,11 +138,14 @@ MaskLayout layout_for(const int32_t size[3], int64_t n_rays, int32_t M) {
     L.sp_cap = (int)(4 * nr) + 256;  // spilled work voxels (beyond kPipeC1 per ray), all rays together
     L.off_p_spill = off;             // sp_items | sp_citem | sp_ray
     off = align_up(off + (size_t)L.sp_cap * 3 * 4, 256);
-    L.off_p_list = off;      // dense list of occupied table cells (k_walk / k_sweep -> k_geom), kListShards segments:
-                             // producer block b fills segment b % kListShards, so a segment holds the cells of at most
-                             // nr / kListShards + 2 * (rays per producer block <= 256) rays
-    L.list_cap = kPipeC1 * (int)((nr + kListShards - 1) / kListShards + 512);
-    off = align_up(off + (size_t)L.list_cap * kListShards * 4, 256);
+    L.off_p_list = off;      // dense list of occupied table cells (k_walk / k_sweep -> k_geom), kListSegs segments: the
+                             // producer blocks of the bands of group g (list_segment, asurf_pipeline.h) cover at most
+                             // nr / kListGroups + band_rays rays, a kListShards-th of them per segment (a band is a whole
+                             // number of rounds of 16 producer blocks)
+    L.band_rays = kBandRaysMax;
+    while (L.band_rays > kBandRaysMin && (long long)L.band_rays * 64 > nr) L.band_rays >>= 1;
+    L.list_cap = kPipeC1 * (int)(((nr + kListGroups - 1) / kListGroups + L.band_rays) / kListShards + 256);
+    off = align_up(off + (size_t)L.list_cap * kListSegs * 4, 256);
     L.off_rec_list = off;    // dense list of visited records (k_bwd_seq -> k_bwd_geo)
     off = align_up(off + rplane, 256);
     L.off_p_counters = off;  // n_flagged, spill cursor, kPoolShards pool cursors, 2 list lengths
@@ -357,7 +360,7 @@ int prepare(const asurf_grid* grid, const asurf_rays* rays, const asurf_render_o
 // the rate of their memory requests, not of their wave slots; variants/timeline.py.)
 unsigned list_blocks(long long n_rays, int per_ray) {
     const long long want = (n_rays * per_ray + kBlock - 1) / kBlock;
-    return (unsigned)std::min<long long>(std::max<long long>(want, 64), kListBlocks);
+    return (unsigned)std::min<long long>((std::max<long long>(want, 64) + 7) & ~7ll, kListBlocks);  // (k_geom: 8 groups)
 }
 
 // The three-kernel forward is used unless the call needs what only the one-kernel path keeps:
@@ -395,6 +398,7 @@ int find_candidates(const Launch& L, const asurf_rays* rays, bool record, PipeBu
         P.C1 = kPipeC1;
         P.list = reinterpret_cast<unsigned*>(L.ws + L.ML.off_p_list);
         P.list_cap = L.ML.list_cap;
+        P.band_rays = L.ML.band_rays;
         if (hipMemsetAsync(P.counters, 0, kCtrTotal * sizeof(int), L.stream) != hipSuccess)
             return fail(ASURF_E_LAUNCH, "hipMemsetAsync failed");
         const int seg = walk_segments(Q);
@@ -480,7 +484,7 @@ int run_forward(const Launch& L, const asurf_rays* rays, float* rgb_out, int M, 
                 long long pool = 0;
                 for (int i = 0; i < kPoolShards; ++i) pool += h[2 + i];
                 fprintf(stderr, "[asurf] rays %lld: handed back %d, spilled voxels %d, table cells %d, candidates %lld\n",
-                        Q, h[0], h[1], [&] { int t = 0; for (int i = 0; i < kListShards; ++i) t += h[kCtrListShard0 + i * kCtrShardStride]; return t; }(), pool);
+                        Q, h[0], h[1], [&] { int t = 0; for (int i = 0; i < kListSegs; ++i) t += h[kCtrListShard0 + i * kCtrShardStride]; return t; }(), pool);
             }
         }
         ray_list = P.flagged;

@@ -617,6 +617,68 @@ __device__ __forceinline__ bool root_position(const Ray& r, const Vox& v, double
     return !((pos[0] < 0) | (pos[0] > 1) | (pos[1] < 0) | (pos[1] > 1) | (pos[2] < 0) | (pos[2] > 1));
 }
 
+// Conservative test in front of the cubic solver (k_geom's light stage): false only when NO root of any in-range
+// level set's cubic can pass `st > 0 && root_position()`.
+//   * where a sample can be: root_position() wants pos_k = fmaf(st, d_k, new_origin_k) - voxel_k in [0, 1] on every
+//     axis; in st that is an interval per axis, here widened by 5e-4 voxel for the float roundings of pos (a few ulp
+//     of a coordinate <= 1024: 1.2e-4), cut at st = 0.
+//   * the cubic over that interval [a, a + h] in Bernstein form: its values lie between the smallest and the largest
+//     coefficient, so coefficients of one sign (by a margin of 1e-6 of their scale) mean no root.
+//   * the solver's roots are those of the polynomial up to its own rounding, which is far below the margins unless
+//     the cubic term is so small against the quadratic one that the Vieta form cancels (|f2 / f3| large against the
+//     interval): those voxels, and the solver's degenerate branches (|f3| < 1e-10), are never rejected through
+//     the cubic -- the latter are tested as the quadratic / linear equation the solver then solves.
+__device__ __forceinline__ bool voxel_may_hold_root(const KGrid& g, const Ray& r, const Vox& v) {
+    const int vv[3] = {v.vx, v.vy, v.vz};
+    float a = 0.f, b = INFINITY;
+    const float tol = 5e-4f;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const float lo = (float)vv[k] - v.new_origin[k] - tol, hi = (float)vv[k] - v.new_origin[k] + (1.f + tol);
+        if (fabsf(r.d[k]) > 1e-20f) {
+            const float inv = 1.f / r.d[k];
+            const float t0 = lo * inv, t1 = hi * inv;
+            a = fmaxf(a, fminf(t0, t1));
+            b = fminf(b, fmaxf(t0, t1));
+        } else if (lo > 0.f || hi < 0.f) {
+            return false;  // the position never moves along k and is outside
+        }
+    }
+    if (!(a <= b)) return false;
+    if (!(b < 1e30f)) return true;
+    // (one more ulp-scale widening of the interval itself: the divisions above)
+    const double da = (double)a - 1e-6 * (double)(b - a) - 1e-30, dh = ((double)b - da) * (1.0 + 1e-6) + 1e-30;
+    bool maybe = false;
+    for (int li = 0; li < g.level_set_num; ++li) {
+        const float lvf = g.level_set[li];
+        if (lvf < v.smin || lvf > v.smax) continue;
+        const double f0 = v.fs[0] - (double)lvf, f1 = v.fs[1], f2 = v.fs[2], f3 = v.fs[3];
+        double c0, c1, c2, c3;
+        if (fabs(f3) < 1e-10) {  // the solver drops the cubic term (and the quadratic one below 1e-10)
+            const double q2 = (fabs(f2) < 1e-10) ? 0.0 : f2;
+            c0 = (q2 * da + f1) * da + f0;
+            c1 = dh * (2.0 * q2 * da + f1);
+            c2 = dh * dh * q2;
+            c3 = 0.0;
+        } else {
+            // Vieta: st = m * cos(..) - b / 3 with b = f2 / f3; trusted while |b| stays within 1e9 interval lengths
+            if (fabs(f2) > 1e9 * dh * fabs(f3)) {
+                maybe = true;
+                continue;
+            }
+            c0 = ((f3 * da + f2) * da + f1) * da + f0;
+            c1 = dh * ((3.0 * f3 * da + 2.0 * f2) * da + f1);
+            c2 = dh * dh * (3.0 * f3 * da + f2);
+            c3 = dh * dh * dh * f3;
+        }
+        const double b0 = c0, b1 = c0 + c1 * (1.0 / 3.0), b2 = c0 + (2.0 * c1 + c2) * (1.0 / 3.0), b3 = c0 + c1 + c2 + c3;
+        const double margin = 1e-6 * (fabs(c0) + fabs(c1) + fabs(c2) + fabs(c3)) + 1e-300;
+        const double mn = fmin(fmin(b0, b1), fmin(b2, b3)), mx = fmax(fmax(b0, b1), fmax(b2, b3));
+        if (!(mn > margin || mx < -margin)) maybe = true;
+    }
+    return maybe;
+}
+
 // fake-sample geometry (surf_trav.cu:437-490)
 __device__ __forceinline__ void fake_position(const Ray& r, const Vox& v, float* pos) {
     const float tm = (v.t_far + v.t_close) / 2.f;

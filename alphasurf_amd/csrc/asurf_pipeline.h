@@ -62,7 +62,19 @@ constexpr int kCtrList = 2 + kPoolShards;   // [kCtrList + 1]: entries in the ba
 constexpr int kListShards = 16;
 constexpr int kCtrShardStride = 16;
 constexpr int kCtrListShard0 = kCtrList + 2;
-constexpr int kCtrTotal = kCtrListShard0 + kListShards * kCtrShardStride;
+// ... and into kListGroups groups of shards by WHERE the rays are: rays come in image order, a band of band_rays
+// consecutive rays (8192: ten rows of an 800-pixel image) sees one slab of the scene, and band n belongs to group n % 8.
+// k_geom's blocks on XCD x (block b runs on XCD b % 8 -- variants/timeline.py reads it back from XCC_ID) take group
+// x: the links and values of a slab are then fetched into ONE of the eight L2s instead of all of them.  Interleaved
+// bands keep the groups level (one contiguous eighth of the image per XCD leaves the XCDs of the background idle);
+// a small batch is cut into shorter bands (PipeBuf::band_rays, at least 64 bands where the batch allows).
+#ifndef ASURF_LIST_GROUPS
+#define ASURF_LIST_GROUPS 8
+#endif
+constexpr int kListGroups = ASURF_LIST_GROUPS;
+constexpr int kListSegs = kListGroups * kListShards;
+constexpr int kBandRaysMax = 8192, kBandRaysMin = 256;  // powers of two; every producer block lies within a band
+constexpr int kCtrTotal = kCtrListShard0 + kListSegs * kCtrShardStride;
 constexpr int kListRayBits = 27;  // rays per call < 2^27 for the list-driven kernels
 // The kernels that work through a dense list are launched with a fixed number of blocks and
 // stride over it: the list length is only known on the device, and tens of thousands of
@@ -84,6 +96,7 @@ struct PipeBuf {
     unsigned* list;  // dense list of the occupied (slot, ray) cells of `items`: slot << 27 | ray; kListShards
                      // segments of list_cap cells
     int list_cap;
+    int band_rays;   // rays per band (list_segment)
     CandRec* pool;
     // per ray: which of its work voxels yielded a candidate (bit s: the s-th one, table slots first, then the spill
     // slice; bit 63: one beyond the 63rd did) -- k_geom ORs the bits in, k_comp visits those only
@@ -92,6 +105,15 @@ struct PipeBuf {
     int sp_cap;
     int C1;
 };
+
+// Segment the producer block (rays_per_block consecutive rays, a power of two <= kBandRaysMin) appends to: group =
+// its band's, shard = the block's place in the band + the band's place in the group, so that the blocks of a group
+// go round its shards whatever the number of blocks per band.
+__device__ __forceinline__ int list_segment(const PipeBuf& P, int rays_per_block) {
+    const unsigned nbb = (unsigned)(P.band_rays / rays_per_block);
+    const unsigned band = blockIdx.x / nbb, in_band = blockIdx.x - band * nbb;
+    return (int)(band % kListGroups) * kListShards + (int)((in_band + band / kListGroups) % kListShards);
+}
 
 __device__ __forceinline__ int wave_excl_scan(int v, int* total) {
     const int lane = threadIdx.x & 63;
@@ -201,7 +223,7 @@ k_walk(KGrid g, KOpt o, const float* __restrict__ origins, const float* __restri
         wave_excl_scan(nt, &wave_total);
         if (wave_total > 0) {
             int base0 = 0;
-            const int shard = blockIdx.x % kListShards;
+            const int shard = list_segment(P, kBlock);
             if ((tid & 63) == 0)
                 base0 = shard * P.list_cap + atomicAdd(&P.counters[kCtrListShard0 + shard * kCtrShardStride], wave_total);
             base0 = __shfl(base0, 0);
@@ -403,7 +425,7 @@ k_walk_seg(KGrid g, KOpt o, const float* __restrict__ origins, const float* __re
         wave_excl_scan(nt, &wave_total);
         if (wave_total > 0) {
             int base0 = 0;
-            const int shard = blockIdx.x % kListShards;
+            const int shard = list_segment(P, (kBlock / 64) * R);
             if (lane == 0)
                 base0 = shard * P.list_cap + atomicAdd(&P.counters[kCtrListShard0 + shard * kCtrShardStride], wave_total);
             base0 = __shfl(base0, 0);
@@ -428,21 +450,43 @@ k_geom(KGrid g, KOpt o, const float* __restrict__ origins, const float* __restri
        long long Q, PipeBuf P) {
     const TlScope tl(3);
     const int lane = threadIdx.x & 63;
-    // the table cells come as kListShards segments: their lengths' running sums (wave-uniform) turn a position in the
-    // concatenation into (segment, offset); the spill list follows them (a launch of its own cost 13 us, empty or not)
+    // The table cells come as kListGroups groups of kListShards segments.  This block takes group blockIdx % 8 (its
+    // XCD's, see kListGroups) together with the other blocks of that XCD; the segments' running sums (wave-uniform)
+    // turn a position in the group's concatenation into (segment, offset).  The spill list follows: its 64-entry
+    // pieces go round the groups (a launch of its own cost 13 us, empty or not).
+    const int grp = (int)(blockIdx.x % kListGroups);
     int seg_end[kListShards];
     int n_cells = 0;
 #pragma unroll
     for (int sh = 0; sh < kListShards; ++sh) {
-        n_cells += min(P.counters[kCtrListShard0 + sh * kCtrShardStride], P.list_cap);
+        n_cells += min(P.counters[kCtrListShard0 + (grp * kListShards + sh) * kCtrShardStride], P.list_cap);
         seg_end[sh] = n_cells;
     }
-    const int n_list = n_cells + min(P.counters[1], P.sp_cap);
-    const unsigned wave_id = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
-    const int stride = (int)gridDim.x * kBlock;
+    const int n_spill = min(P.counters[1], P.sp_cap);
+    const int sp_pieces = (n_spill + 63) >> 6;
+    const int n_list = n_cells + ((sp_pieces - grp + kListGroups - 1) / kListGroups) * 64;  // (grp < kListGroups)
+    const unsigned wave_id = (blockIdx.x / kListGroups) * (kBlock / 64) + (threadIdx.x >> 6);  // within the group
+    const int stride = (int)(gridDim.x / kListGroups) * kBlock;
+    // Three work voxels in four hold no crossing (their level set is within the corner values' range, but not along
+    // this ray), and the Vieta solver (f64 acos, sincos, cbrt; both of its branches in every wave) is most of what a
+    // voxel costs.  A test in front of it is worth nothing while lanes that pass and lanes that fail share a wave
+    // (measured: 0.21 -> 0.31 ms), so the wave works in two stages: a LIGHT one over the list, 64 cells a turn --
+    // gathers, the cubic's coefficients, and a conservative "no root of the cubic where a sample could be" (Bernstein
+    // coefficients of one sign over the interval of ray parameters whose positions root_position() accepts) -- which
+    // finishes the cells that hold nothing and queues the rest in LDS, and a HEAVY one that runs the reference's
+    // solver on full waves of queued cells.  Fake samples need every voxel's geometry: with them enabled (or
+    // ASURF_DEBUG & 32) every cell is queued unseen.
+    __shared__ int s_queue[kBlock / 64][3][128];
+    int (*queue)[128] = s_queue[threadIdx.x >> 6];
+    const bool filter = !o.surf_fake_sample && !(o.debug & 32);
+    int qn = 0;  // queued cells (wave-uniform)
     unsigned turn = 0;
-    for (int base = (int)wave_id * 64; base < n_list; base += stride, ++turn) {
+    int base = (int)wave_id * 64;
+    for (;;) {
+      // ---- light stage: until a full wave is queued or the list ends ----
+      while (qn < 64 && base < n_list) {
         const int i = base + lane;
+        base += stride;
         long long q = 0;
         long long entry = 0;
         int packed_voxel = 0;
@@ -450,7 +494,9 @@ k_geom(KGrid g, KOpt o, const float* __restrict__ origins, const float* __restri
         const bool SPILL = i >= n_cells;
         int slot = 0;  // ordinal of the voxel among the ray's work voxels
         if (SPILL) {
-            entry = i - n_cells;
+            const int t = i - n_cells;
+            entry = (long long)(((t >> 6) * kListGroups + grp) << 6) + (t & 63);
+            mine = mine && entry < n_spill;
             const int qq = mine ? P.sp_ray[entry] : -1;
             mine = (qq >= 0) && (P.n_items[qq] >= 0);
             q = (qq >= 0) ? qq : 0;
@@ -465,13 +511,52 @@ k_geom(KGrid g, KOpt o, const float* __restrict__ origins, const float* __restri
             int seg0 = 0;  // seg_end[sh - 1]
 #pragma unroll
             for (int k = 0; k < kListShards - 1; ++k) seg0 = (sh == k + 1) ? seg_end[k] : seg0;
-            const unsigned e = mine ? P.list[(size_t)sh * P.list_cap + (i - seg0)] : 0u;
+            const unsigned e = mine ? P.list[(size_t)(grp * kListShards + sh) * P.list_cap + (i - seg0)] : 0u;
             q = (long long)(e & ((1u << kListRayBits) - 1u));
             slot = (int)(e >> kListRayBits);
             entry = (long long)slot * Q + q;
             mine = mine && (P.n_items[q] >= 0);  // < 0: ray handed back to the one-kernel path
             if (mine) packed_voxel = P.items[entry];
         }
+        bool maybe = mine;
+        if (filter && mine) {
+            Ray r;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                r.o[k] = origins[3 * q + k];
+                r.d[k] = dirs[3 * q + k];
+            }
+            setup_ray(g, o, r);
+            Vox v;
+            load_voxel(g, r, packed_voxel, v);
+            maybe = voxel_may_hold_root(g, r, v);
+            if (!maybe) {  // nothing here: the cell is done
+                if (SPILL) P.sp_citem[entry] = 0;
+                else P.citem[entry] = 0;
+            }
+        }
+        const unsigned long long mq = __ballot(maybe);
+        if (maybe) {
+            const int at = qn + __popcll(mq & ((1ull << lane) - 1ull));
+            queue[0][at] = (int)q;
+            queue[1][at] = slot;
+            queue[2][at] = packed_voxel;
+        }
+        qn += __popcll(mq);
+      }
+      if (qn == 0) break;  // (the list has ended)
+      // ---- heavy stage: the last min(qn, 64) queued cells, one per lane ----
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      const int take = min(qn, 64);
+      qn -= take;
+      const bool mine = lane < take;
+      const long long q = mine ? queue[0][qn + lane] : 0;
+      const int slot = mine ? queue[1][qn + lane] : 0;
+      const int packed_voxel = mine ? queue[2][qn + lane] : 0;
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // (read before the next light stage writes)
+      const bool SPILL = slot >= P.C1;
+      const long long entry = SPILL ? (long long)P.sp_base[q] + (slot - P.C1) : (long long)slot * Q + q;
+      {
         CandRec c0, c1, c2;
         c0.px = c0.py = c0.pz = c0.ts = c0.raw = c0.ext = 0.f;
         c0.meta = c0.pad = 0;
@@ -551,13 +636,13 @@ k_geom(KGrid g, KOpt o, const float* __restrict__ origins, const float* __restri
         // one pool allocation per wave: exclusive prefix of the lanes' counts + a single atomic
         int total;
         const int pre = wave_excl_scan(nc, &total);
-        const int shard = (int)((wave_id + turn * 61u) % kPoolShards);
+        const int shard = (int)((blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6) + turn * 61u) % kPoolShards);
         int base0 = 0;
         if (total > 0) {
             if (lane == 0) base0 = atomicAdd(&P.counters[2 + shard], total);
             base0 = __shfl(base0, 0);
         }
-        if (!mine) continue;
+        if (mine) {
         int packed = 0;
         const int rel = base0 + pre;
         if (overflow || (nc > 0 && rel + nc > P.shard_cap)) {
@@ -574,6 +659,9 @@ k_geom(KGrid g, KOpt o, const float* __restrict__ origins, const float* __restri
         }
         if (SPILL) P.sp_citem[entry] = packed;
         else P.citem[entry] = packed;
+        }
+      }
+      ++turn;
     }
     tl.end();
 }

@@ -409,7 +409,7 @@ k_sweep(KGrid g, KOpt o, const float* __restrict__ origins, const float* __restr
         s_slot0[tid] = ci - c;
         const int cells = __shfl(ci, 63);
         if (tid == 0) {
-            const int shard = blockIdx.x % kListShards;
+            const int shard = list_segment(P, rpb);
             s_lbase = shard * P.list_cap +
                       (cells > 0 ? atomicAdd(&P.counters[kCtrListShard0 + shard * kCtrShardStride], cells) : 0);
         }

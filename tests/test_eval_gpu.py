@@ -88,7 +88,7 @@ def test_grid_methods(hip):
 def test_both_forms_agree(hip, monkeypatch):
     """The render behind k_sweep + k_geom and the stepping form (ASURF_EVAL=walk) on the same rays; three level sets
     make some voxels hold more than three crossings, which hands those rays to the stepping form inside the first."""
-    sc, o, d = sparse_case(7, level_set=(-0.3, 0.0, 0.4))
+    sc, o, d = sparse_case(4, level_set=(-0.3, 0.0, 0.4))
     for what, param, ms in (("expected", 0.0, 1), ("mode", 0.2, 1), ("sigma_thresh", 0.3, 1), ("alpha", 0.3, 1),
                             ("normal", 0.0, 1), ("extract_pts", 0.05, 6)):
         monkeypatch.delenv("ASURF_EVAL", raising=False)

@@ -1,0 +1,47 @@
+"""k_geom's light-stage filter (voxel_may_hold_root) against the unfiltered kernel (ASURF_DEBUG=32) on many rays:
+a ray's RGB is a deterministic function of its candidates, so it must come out bit for bit.  Scenes: the 256^3 bench
+scene (one and three level sets), a 130^3 non-cubic crop; rays: random, shuffled pixel rays, rays through lattice
+points (axis-parallel components, grazing faces).  usage: geom_filter_check.py [n_random_rays]"""
+import os, sys
+import numpy as np
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests"))
+import hip_util
+from alphasurf_amd import synth
+
+n_rand = int(sys.argv[1]) if len(sys.argv) > 1 else 400000
+rs = np.random.RandomState(1)
+bad = 0
+for reso, crop, lv in ((256, None, (0.0,)), (256, None, (-0.4, 0.0, 0.3)), (130, (125, 111, 68), (0.0, 0.2))):
+    sc = synth.make_sparse_scene(reso, 4, trunc_a=5.0, level_set=lv, **dict(synth.BENCH_SCENE, seed=5 + reso))
+    if crop:
+        sc = dict(sc, links=np.ascontiguousarray(sc["links"][: crop[0], : crop[1], : crop[2]]))
+    o1, d1 = synth.random_rays(n_rand, 3)
+    cams = [synth.pinhole_rays(synth.orbit_camera(k), 200, 200) for k in range(8)]
+    o2 = np.concatenate([c[0] for c in cams]); d2 = np.concatenate([c[1] for c in cams])
+    n = 100000
+    tgt = rs.randint(0, reso, size=(n, 3)).astype(np.float64)
+    src = rs.randint(-reso, 2 * reso, size=(n, 3)).astype(np.float64)
+    src[n // 2:] += rs.rand(n - n // 2, 3)
+    keep = np.linalg.norm(tgt - src, axis=1) > 1
+    o3 = ((src[keep] - reso / 2) / (reso / 2)).astype(np.float32)
+    d3 = tgt[keep] - src[keep]
+    d3 = (d3 / np.linalg.norm(d3, axis=1, keepdims=True)).astype(np.float32)
+    o = np.concatenate([o1, o2, o3]).astype(np.float32); d = np.concatenate([d1, d2, d3]).astype(np.float32)
+    gt = rs.rand(o.shape[0], 3).astype(np.float32)
+    fused = dict(lambda_l2=1.0, lambda_l_entropy=1e-4, lambda_conv_mode_samp=1e-6)
+    for extra in ({}, dict(only_outward_intersect=False), dict(near_clip=0.4)):
+        opts = dict(synth.SYN_OPTS, **extra)
+        os.environ["ASURF_DEBUG"] = "32"
+        rgb_ref, g_ref = hip_util.render_fused(sc, o, d, opts, gt, fused)
+        del os.environ["ASURF_DEBUG"]
+        rgb, g = hip_util.render_fused(sc, o, d, opts, gt, fused)
+        dif = np.abs(rgb - rgb_ref).max(axis=1)
+        neq = int((dif > 0).sum())
+        mask_eq = bool((g["mask"] == g_ref["mask"]).all())
+        gerr = max(float(np.abs(g[k] - g_ref[k]).max() / max(np.abs(g_ref[k]).max(), 1e-20)) for k in ("sh", "density", "surface"))
+        print(f"reso {reso} crop {crop} level sets {lv} {extra}: {o.shape[0]} rays, rays with different RGB {neq} "
+              f"(max {dif.max():.1e}), masks equal {mask_eq}, max grad err {gerr:.2e}", flush=True)
+        bad += neq + (0 if mask_eq else 1) + (1 if gerr > 1e-4 else 0)
+print("FILTER CHECK", "FAILED" if bad else "OK")
+sys.exit(1 if bad else 0)
