@@ -150,7 +150,7 @@ MaskLayout layout_for(const int32_t size[3], int64_t n_rays, int32_t M) {
     off = align_up(off + rplane, 256);
     L.off_p_counters = off;  // n_flagged, spill cursor, kPoolShards pool cursors, 2 list lengths
     off = align_up(off + kCtrTotal * 4, 256);
-    L.pool_shard_cap = (int)((8 * nr + kPoolShards - 1) / kPoolShards) + 64;
+    L.pool_shard_cap = (int)((8 * nr + kPoolShards - 1) / kPoolShards) + 256;  // (a wave of k_geom may ask for 3 x 64 at once)
     L.off_p_pool = off;
     off = align_up(off + (size_t)L.pool_shard_cap * kPoolShards * sizeof(CandRec), 256);
     L.total = off;

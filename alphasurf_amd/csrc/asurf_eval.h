@@ -162,18 +162,18 @@ k_eval_comp(KGrid g, KOpt o, const float* __restrict__ dirs, long long Q, PipeBu
     bool done = false;
     const unsigned long long cmask = P.cand_mask[q];
     const bool scan = (cmask >> 63) != 0ull;
-    unsigned long long todo = cmask;
+    unsigned long long todo = cmask & ~(1ull << 63);
     const int spb = (n > P.C1) ? P.sp_base[q] : 0;
-    int s_scan = 0;
+    int s_scan = 63;  // (below slot 63 the cells hold a word only where cand_mask says so)
     while (!done) {
         int s;
-        if (scan) {
-            if (s_scan >= n) break;
-            s = s_scan++;
-        } else {
-            if (todo == 0ull) break;
+        if (todo != 0ull) {
             s = __ffsll((long long)todo) - 1;
             todo &= todo - 1ull;
+        } else if (scan && s_scan < n) {
+            s = s_scan++;
+        } else {
+            break;
         }
         const int ci = (s < P.C1) ? P.citem[(size_t)s * Q + q] : P.sp_citem[spb + s - P.C1];
         const int nc = ci & 3, base = ci >> 2;

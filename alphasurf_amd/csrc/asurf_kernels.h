@@ -618,23 +618,44 @@ __device__ __forceinline__ bool root_position(const Ray& r, const Vox& v, double
 }
 
 // Conservative test in front of the cubic solver (k_geom's light stage): false only when NO root of any in-range
-// level set's cubic can pass `st > 0 && root_position()`.
+// level set's cubic can pass `st > 0 && root_position()`.  Float arithmetic on the voxel's links and surface values
+// alone (no densities, no f64 coefficients: those are the heavy stage's), with margins that cover it:
 //   * where a sample can be: root_position() wants pos_k = fmaf(st, d_k, new_origin_k) - voxel_k in [0, 1] on every
 //     axis; in st that is an interval per axis, here widened by 5e-4 voxel for the float roundings of pos (a few ulp
-//     of a coordinate <= 1024: 1.2e-4), cut at st = 0.
+//     of a coordinate <= 1024: 1.2e-4), cut at st = 0.  Its length h satisfies h |d_k| <= 1.001.
 //   * the cubic over that interval [a, a + h] in Bernstein form: its values lie between the smallest and the largest
-//     coefficient, so coefficients of one sign (by a margin of 1e-6 of their scale) mean no root.
-//   * the solver's roots are those of the polynomial up to its own rounding, which is far below the margins unless
-//     the cubic term is so small against the quadratic one that the Vieta form cancels (|f2 / f3| large against the
-//     interval): those voxels, and the solver's degenerate branches (|f3| < 1e-10), are never rejected through
-//     the cubic -- the latter are tested as the quadratic / linear equation the solver then solves.
-__device__ __forceinline__ bool voxel_may_hold_root(const KGrid& g, const Ray& r, const Vox& v) {
-    const int vv[3] = {v.vx, v.vy, v.vz};
+//     coefficient, so coefficients of one sign mean no root.  In units of the interval every term of the
+//     coefficients is a few times max |s| at most, ~40 float operations deep: the margin, 1e-4 (max |s| + |level|),
+//     is ten times the bound of their rounding (and 3e-4 voxel of an SDF in voxel units: it hardly costs a voxel).
+//   * the solver's roots are those of the polynomial up to ITS rounding, far below these margins, except where the
+//     cubic term is so small against the quadratic one that the Vieta form cancels (root = m cos(..) - f2 / 3 f3):
+//     f3 -- the third difference of the corners times d_x d_y d_z, formed in f64 -- at or above the solver's own
+//     1e-10 switch to the quadratic formula but below 1e-9 of the quadratic term (in units of the interval).  Such
+//     voxels are passed on unseen.
+__device__ __forceinline__ bool voxel_may_hold_root(const KGrid& g, const Ray& r, int packed) {
+    const int vv[3] = {packed >> 20, (packed >> 10) & 1023, packed & 1023};
+    float t_close = 0.f;  // as load_voxel_values
+#pragma unroll
+    for (int k = 0; k < 3; ++k) t_close = fmaxf(t_close, ((float)(r.d[k] > 0.f ? vv[k] : vv[k] + 1) - r.o[k]) / r.d[k]);
+    const int32_t* p = g.links + ((size_t)vv[0] * g.offx + (size_t)vv[1] * g.offy + vv[2]);
+    const int32_t lk[8] = {p[0], p[1], p[g.offy], p[g.offy + 1], p[g.offx], p[g.offx + 1], p[g.offx + g.offy],
+                           p[g.offx + g.offy + 1]};
+    float sf[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) sf[i] = g.surface[lk[i]];
+    float smin = sf[0], smax = sf[0];
+#pragma unroll
+    for (int i = 1; i < 8; ++i) {
+        smin = fminf(smin, sf[i]);
+        smax = fmaxf(smax, sf[i]);
+    }
+    float no[3];  // the entry point inside the voxel
     float a = 0.f, b = INFINITY;
     const float tol = 5e-4f;
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
-        const float lo = (float)vv[k] - v.new_origin[k] - tol, hi = (float)vv[k] - v.new_origin[k] + (1.f + tol);
+        no[k] = fmaf(t_close, r.d[k], r.o[k]) - (float)vv[k];
+        const float lo = -no[k] - tol, hi = -no[k] + (1.f + tol);
         if (fabsf(r.d[k]) > 1e-20f) {
             const float inv = 1.f / r.d[k];
             const float t0 = lo * inv, t1 = hi * inv;
@@ -645,35 +666,44 @@ __device__ __forceinline__ bool voxel_may_hold_root(const KGrid& g, const Ray& r
         }
     }
     if (!(a <= b)) return false;
-    if (!(b < 1e30f)) return true;
-    // (one more ulp-scale widening of the interval itself: the divisions above)
-    const double da = (double)a - 1e-6 * (double)(b - a) - 1e-30, dh = ((double)b - da) * (1.0 + 1e-6) + 1e-30;
+    if (!(b < 1e30f) || !(t_close < 1e30f)) return true;
+    const float h = (b - a) * 1.0002f + 1e-30f;  // (both ends out by 1e-4 of the length: the divisions above)
+    a -= 1e-4f * (b - a);
+    // the trilinear field along the ray, multiplied out z, y, x (surface_cubic, in float)
+    float c[2][3];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const float a0 = fmaf(sf[4 * i + 1] - sf[4 * i], no[2], sf[4 * i]), b0 = r.d[2] * (sf[4 * i + 1] - sf[4 * i]);
+        const float a1 = fmaf(sf[4 * i + 3] - sf[4 * i + 2], no[2], sf[4 * i + 2]),
+                    b1 = r.d[2] * (sf[4 * i + 3] - sf[4 * i + 2]);
+        c[i][0] = fmaf(a1 - a0, no[1], a0);
+        c[i][1] = fmaf(b1 - b0, no[1], b0) + r.d[1] * (a1 - a0);
+        c[i][2] = r.d[1] * (b1 - b0);
+    }
+    const float f0 = fmaf(c[1][0] - c[0][0], no[0], c[0][0]);
+    const float f1 = fmaf(c[1][1] - c[0][1], no[0], c[0][1]) + r.d[0] * (c[1][0] - c[0][0]);
+    const float f2 = fmaf(c[1][2] - c[0][2], no[0], c[0][2]) + r.d[0] * (c[1][1] - c[0][1]);
+    const float f3 = r.d[0] * (c[1][2] - c[0][2]);
+    // in units of the interval: p(a + u h) = c0 + c1 u + c2 u^2 + c3 u^3
+    const float c1 = h * fmaf(fmaf(3.f * f3, a, 2.f * f2), a, f1);
+    const float c2 = h * h * fmaf(3.f * f3, a, f2);
+    const float c3 = h * h * h * f3;
+    const float p_a = fmaf(fmaf(fmaf(f3, a, f2), a, f1), a, f0);
+    // Vieta's cancellation zone
+    const double f3d = (double)r.d[0] * (double)r.d[1] * (double)r.d[2] *
+                       ((((double)sf[7] - (double)sf[6]) - ((double)sf[5] - (double)sf[4])) -
+                        (((double)sf[3] - (double)sf[2]) - ((double)sf[1] - (double)sf[0])));
+    const float smag = fmaxf(fabsf(smin), fabsf(smax));
+    if (fabs(f3d) >= 0.9e-10 && fabs(f3d) * (double)h * (double)h * (double)h < 1e-9 * (double)(fabsf(c2) + 1e-3f * smag))
+        return true;
     bool maybe = false;
     for (int li = 0; li < g.level_set_num; ++li) {
         const float lvf = g.level_set[li];
-        if (lvf < v.smin || lvf > v.smax) continue;
-        const double f0 = v.fs[0] - (double)lvf, f1 = v.fs[1], f2 = v.fs[2], f3 = v.fs[3];
-        double c0, c1, c2, c3;
-        if (fabs(f3) < 1e-10) {  // the solver drops the cubic term (and the quadratic one below 1e-10)
-            const double q2 = (fabs(f2) < 1e-10) ? 0.0 : f2;
-            c0 = (q2 * da + f1) * da + f0;
-            c1 = dh * (2.0 * q2 * da + f1);
-            c2 = dh * dh * q2;
-            c3 = 0.0;
-        } else {
-            // Vieta: st = m * cos(..) - b / 3 with b = f2 / f3; trusted while |b| stays within 1e9 interval lengths
-            if (fabs(f2) > 1e9 * dh * fabs(f3)) {
-                maybe = true;
-                continue;
-            }
-            c0 = ((f3 * da + f2) * da + f1) * da + f0;
-            c1 = dh * ((3.0 * f3 * da + 2.0 * f2) * da + f1);
-            c2 = dh * dh * (3.0 * f3 * da + f2);
-            c3 = dh * dh * dh * f3;
-        }
-        const double b0 = c0, b1 = c0 + c1 * (1.0 / 3.0), b2 = c0 + (2.0 * c1 + c2) * (1.0 / 3.0), b3 = c0 + c1 + c2 + c3;
-        const double margin = 1e-6 * (fabs(c0) + fabs(c1) + fabs(c2) + fabs(c3)) + 1e-300;
-        const double mn = fmin(fmin(b0, b1), fmin(b2, b3)), mx = fmax(fmax(b0, b1), fmax(b2, b3));
+        if (lvf < smin || lvf > smax) continue;
+        const float c0 = p_a - lvf;
+        const float b1 = fmaf(c1, 1.f / 3.f, c0), b2 = fmaf(2.f * c1 + c2, 1.f / 3.f, c0), b3 = c0 + c1 + c2 + c3;
+        const float margin = 1e-4f * (smag + fabsf(lvf)) + 1e-30f;
+        const float mn = fminf(fminf(c0, b1), fminf(b2, b3)), mx = fmaxf(fmaxf(c0, b1), fmaxf(b2, b3));
         if (!(mn > margin || mx < -margin)) maybe = true;
     }
     return maybe;

@@ -471,10 +471,12 @@ k_geom(KGrid g, KOpt o, const float* __restrict__ origins, const float* __restri
     // this ray), and the Vieta solver (f64 acos, sincos, cbrt; both of its branches in every wave) is most of what a
     // voxel costs.  A test in front of it is worth nothing while lanes that pass and lanes that fail share a wave
     // (measured: 0.21 -> 0.31 ms), so the wave works in two stages: a LIGHT one over the list, 64 cells a turn --
-    // gathers, the cubic's coefficients, and a conservative "no root of the cubic where a sample could be" (Bernstein
-    // coefficients of one sign over the interval of ray parameters whose positions root_position() accepts) -- which
-    // finishes the cells that hold nothing and queues the rest in LDS, and a HEAVY one that runs the reference's
-    // solver on full waves of queued cells.  Fake samples need every voxel's geometry: with them enabled (or
+    // links, surface values and a conservative "no root of the cubic where a sample could be" in float
+    // (voxel_may_hold_root: Bernstein coefficients of one sign over the interval of ray parameters whose positions
+    // root_position() accepts) -- which finishes the cells that hold nothing and queues the rest in LDS, and a HEAVY
+    // one that runs the reference's arithmetic on full waves of queued cells.  (As two kernels with the queue in
+    // memory, the light one at full occupancy: 0.091 + 0.086 ms against 0.178 in one, and 10 us more at the training
+    // script's batch size.)  Fake samples need every voxel's geometry: with them enabled (or
     // ASURF_DEBUG & 32) every cell is queued unseen.
     __shared__ int s_queue[kBlock / 64][3][128];
     int (*queue)[128] = s_queue[threadIdx.x >> 6];
@@ -515,7 +517,8 @@ k_geom(KGrid g, KOpt o, const float* __restrict__ origins, const float* __restri
             q = (long long)(e & ((1u << kListRayBits) - 1u));
             slot = (int)(e >> kListRayBits);
             entry = (long long)slot * Q + q;
-            mine = mine && (P.n_items[q] >= 0);  // < 0: ray handed back to the one-kernel path
+            // (a ray handed back to the one-kernel path in the meantime is not looked up: its cells cost their work,
+            // and what they leave behind is never read)
             if (mine) packed_voxel = P.items[entry];
         }
         bool maybe = mine;
@@ -527,13 +530,8 @@ k_geom(KGrid g, KOpt o, const float* __restrict__ origins, const float* __restri
                 r.d[k] = dirs[3 * q + k];
             }
             setup_ray(g, o, r);
-            Vox v;
-            load_voxel(g, r, packed_voxel, v);
-            maybe = voxel_may_hold_root(g, r, v);
-            if (!maybe) {  // nothing here: the cell is done
-                if (SPILL) P.sp_citem[entry] = 0;
-                else P.citem[entry] = 0;
-            }
+            maybe = voxel_may_hold_root(g, r, packed_voxel);
+            if (!maybe && slot >= 63) P.sp_citem[entry] = 0;  // nothing here (k_comp reads the cell if it scans)
         }
         const unsigned long long mq = __ballot(maybe);
         if (maybe) {
@@ -658,7 +656,7 @@ k_geom(KGrid g, KOpt o, const float* __restrict__ origins, const float* __restri
             atomicOr(&P.cand_mask[q], 1ull << min(slot, 63));
         }
         if (SPILL) P.sp_citem[entry] = packed;
-        else P.citem[entry] = packed;
+        else if (packed != 0) P.citem[entry] = packed;  // (table slots < 63: read through cand_mask only)
         }
       }
       ++turn;
@@ -698,24 +696,28 @@ k_comp(KGrid g, KOpt o, const float* __restrict__ dirs, long long Q, PipeBuf P,
     bool rec_over = false;
     // Where a ray's candidates are.  One work voxel in nine yields any, so a ray does not walk its slots: k_geom
     // left it a bit per slot that matters, and it visits those in order.  Only a ray with a candidate beyond its
-    // 63rd work voxel scans all its slots (`scan`).  Either way the words of the next four stops are fetched together
+    // 63rd work voxel scans its slots from there on (`scan`; k_geom leaves a word in every cell from slot 63 up, and
+    // below it only where a candidate is).  Either way the words of the next four stops are fetched together
     // (independent loads): the loop is otherwise one dependent memory round trip per stop.
     const unsigned long long cmask = valid ? P.cand_mask[q] : 0ull;
     const bool scan = (cmask >> 63) != 0ull;
-    unsigned long long todo = cmask;   // slots still to visit (!scan)
-    int n_left = valid ? (scan ? n : __popcll(todo)) : 0;  // stops this ray still makes; 0 when stop_thresh ends it
+    unsigned long long todo = cmask & ~(1ull << 63);   // slots below 63 still to visit
+    int s_scan = 63;                                   // next slot of the scan beyond them
+    // stops this ray still makes; 0 when stop_thresh ends it
+    int n_left = valid ? __popcll(todo) + (scan ? max(n - 63, 0) : 0) : 0;
     int ci4[4] = {0, 0, 0, 0}, pv4[4] = {0, 0, 0, 0}, s4[4] = {0, 0, 0, 0};
     for (int it = 0; __any(it < n_left); ++it) {
         const bool have = it < n_left;
         if ((it & 3) == 0) {
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                int su = it + u;
-                bool on = su < n_left;
-                if (!scan) {
-                    on = todo != 0ull;
-                    su = on ? __ffsll((long long)todo) - 1 : 0;
+                bool on = it + u < n_left;
+                int su = 0;
+                if (todo != 0ull) {
+                    su = __ffsll((long long)todo) - 1;
                     todo &= todo - 1ull;
+                } else if (on) {
+                    su = s_scan++;
                 }
                 s4[u] = su;
                 ci4[u] = pv4[u] = 0;
