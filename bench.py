@@ -37,6 +37,8 @@ def parse():
     ap.add_argument("--sort", action="store_true",
                     help="order the batch for coherence inside the timed step (asurf_ray_order), scatter rgb back")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--graph", action="store_true",
+                    help="capture one step in a HIP graph after the warm-up and replay it in the timed region")
     ap.add_argument("--cpu-rays", type=int, default=40000)
     ap.add_argument("--exchange", default="dense", choices=["dense", "sparse", "auto"],
                     help="gradient exchange for --gpus > 1 (alphasurf_amd/dist.py)")
@@ -205,9 +207,24 @@ def main():
     for _ in range(args.warmup):
         step()
     barrier()
+    timed_step = step
+    if args.graph:
+        # the call is stream-ordered (one memset + ten launches, no host synchronisation): capturable as it stands
+        assert world == 1 and not args.sort, "--graph: single GPU, unsorted rays"
+        graph = torch.cuda.CUDAGraph()
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            step()
+        torch.cuda.current_stream().wait_stream(side)
+        with torch.cuda.graph(graph):
+            step()
+        timed_step = graph.replay
+        timed_step()
+        barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        step()
+        timed_step()
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:

@@ -42,6 +42,11 @@ out = {"kernel": kid, "waves": int(m.sum()), "span_us": float(us1.max()),
 ts = np.linspace(0, us1.max(), 21)
 out["in_flight"] = [int(((us0 <= t) & (us1 > t)).sum()) for t in ts]
 out["started_by"] = [int((us0 <= t).sum()) for t in ts]
+# mean duration of the waves that started in each twentieth of the span, and the launch-order index they had
+bins = np.minimum((us0 / max(us1.max(), 1e-9) * 20).astype(int), 19)
+out["dur_by_start_bin"] = [round(float(dur[bins == b].mean()), 1) if (bins == b).any() else None for b in range(20)]
+widx0 = np.nonzero(m)[0]
+out["wave_index_by_start_bin"] = [int(np.median(widx0[bins == b])) if (bins == b).any() else None for b in range(20)]
 cu = (hw >> 8) & 15
 se = (hw >> 13) & 7
 sh = (hw >> 12) & 1
