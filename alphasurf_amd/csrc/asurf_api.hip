@@ -305,11 +305,6 @@ void prof_after(const char* name, int group, hipStream_t s) {
     g_spans = i;
 }
 
-#ifndef ASURF_MASK_THREADS
-#define ASURF_MASK_THREADS 512
-#endif
-constexpr unsigned kMaskThreads = ASURF_MASK_THREADS;  // k_build_masks: 64 x (waves per block), 8 y rows shared among them
-
 int launch_error(const char* what) {
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(ASURF_E_LAUNCH, "%s: %s", what, hipGetErrorString(e));
@@ -344,7 +339,7 @@ int prepare(const asurf_grid* grid, const asurf_rays* rays, const asurf_render_o
     L.sweep = !cuvol && !masks_only && want_sweep(use_live, L.o);
     prof_begin(L.stream);
     const int nzg = (L.ML.nb[2] + 7) / 8;  // groups of 8 bricks along z
-    hipLaunchKernelGGL(k_build_masks, dim3((unsigned)((size_t)L.ML.nb[0] * L.ML.nb[1] * nzg)), dim3(kMaskThreads), 0, L.stream, L.g,
+    hipLaunchKernelGGL(k_build_masks, dim3((unsigned)((size_t)L.ML.nb[0] * L.ML.nb[1] * nzg)), dim3(512), 0, L.stream, L.g,
                        opt->sigma_thresh, cuvol ? 2 : (need_surf ? 1 : 0),  // 2: cuvol cells (asurf_cuvol.h)
                        reinterpret_cast<unsigned long long*>(L.ws + L.ML.off_fine_work),
                        reinterpret_cast<unsigned long long*>(L.ws + L.ML.off_fine_live),

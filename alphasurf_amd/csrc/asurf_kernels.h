@@ -50,24 +50,17 @@ k_build_masks(KGrid g, float sigma_thresh, int need_surf, unsigned long long* fi
               int orient_live, int nzg) {
     const TlScope tl(1);
     const int t = threadIdx.x;
-    const int l = t & 63;
-    // (block b runs on XCD b % 8: with zg = b % nzg an XCD would own one z-quarter of a 256^3 volume, and the XCDs of
-    // the outer quarters idle while those of the middle work -- the last third of the kernel's span on the bench
-    // scene, variants/timeline.py; the rotation gives every XCD every z)
+    const int ly = t >> 6, l = t & 63;
+    const int zg = blockIdx.x % nzg;
     const int bxy = blockIdx.x / nzg;
-    const int zg = (blockIdx.x + bxy) % nzg;
     const int by = bxy % g.nb[1];
     const int bx = bxy / g.nb[1];
     __shared__ unsigned long long s_xw[64], s_xl[64], s_z[64];  // [x-slab][brick], [x-slab][brick], [brick][lz]
     if (t < 64) s_xw[t] = s_xl[t] = s_z[t] = 0ull;
     __syncthreads();
-    const size_t brick0 = ((size_t)bx * g.nb[1] + by) * g.nb[2] + (size_t)zg * 8;
-    const int nbr = min(8, g.nb[2] - zg * 8);  // bricks of the row that exist
-    unsigned long long acc_z = 0ull;
-    for (int ly = t >> 6; ly < 8; ly += (int)(blockDim.x >> 6)) {  // (a wave takes 8 / waves-per-block y rows)
     const int y = by * 8 + ly, z = zg * 64 + l;
     const bool inside_yz = y + 1 < g.size[1] && z + 1 < g.size[2];
-    unsigned long long acc_y = 0ull;
+    unsigned long long acc_y = 0ull, acc_z = 0ull;
     // The kernel streams `links` and is as fast as the bytes it keeps in flight (one 256-byte request per wave
     // would be 2 MB on the whole chip: 1 TB/s at the 2 us such a request takes): all eight slabs' first links
     // are asked for before the first one is looked at.
@@ -136,10 +129,11 @@ k_build_masks(KGrid g, float sigma_thresh, int need_surf, unsigned long long* fi
         }
         if (orient_live ? live : work) acc_z |= 1ull << (lx * 8 + ly);
     }
-    if (fine_y && l < nbr) fine_y[(brick0 + l) * 8 + ly] = acc_y;
-    }
     if (fine_y && acc_z) atomicOr(&s_z[l], acc_z);
     __syncthreads();
+    const size_t brick0 = ((size_t)bx * g.nb[1] + by) * g.nb[2] + (size_t)zg * 8;
+    const int nbr = min(8, g.nb[2] - zg * 8);  // bricks of the row that exist
+    if (fine_y && l < nbr) fine_y[(brick0 + l) * 8 + ly] = acc_y;
     if (t < 64) {
         const int lx = t >> 3, j = t & 7;
         if (j < nbr) {
