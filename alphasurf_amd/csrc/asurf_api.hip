@@ -46,6 +46,8 @@ struct MaskLayout {
     size_t n_bricks;
     size_t coarse_words;
     size_t off_fine_work, off_fine_live, off_coarse_work, off_coarse_live, off_fine_y, off_fine_z;
+    size_t off_mask_hdr, off_live_rows;  // MaskHdr and the list of rows of bricks that are not empty space
+    int n_rows;                          // rows of 8 bricks along z
     size_t off_cache_a, off_cache_w, off_cache_t, off_cache_n;
     size_t off_rec_v, off_rec_m, off_rec_n, off_rec_neff, off_rec_sws, off_rec_f;
     size_t off_p_items, off_p_citem, off_p_nitems, off_p_cut, off_p_flagged, off_p_counters, off_p_pool;
@@ -94,6 +96,11 @@ MaskLayout layout_for(const int32_t size[3], int64_t n_rays, int32_t M) {
     off = align_up(off + L.n_bricks * 64, 256);
     L.off_fine_z = off;
     off = align_up(off + L.n_bricks * 64, 256);
+    L.n_rows = (int)((size_t)L.nb[0] * L.nb[1] * ((L.nb[2] + 7) / 8));
+    L.off_mask_hdr = off;
+    off = align_up(off + sizeof(MaskHdr), 256);
+    L.off_live_rows = off;
+    off = align_up(off + (size_t)L.n_rows * 4, 256);
     const size_t plane = (size_t)(M > 0 ? M : 0) * (size_t)(n_rays > 0 ? n_rays : 0) * 4;
     L.off_cache_a = off;
     off = align_up(off + plane, 256);
@@ -311,6 +318,86 @@ int launch_error(const char* what) {
     return 0;
 }
 
+// --- asurf_grid::links_epoch: which workspaces hold a list of live rows, and for what ---
+// Host-side table (the device-side header is what k_build_masks_live checks before it reads anything): a few
+// entries, least recently used replaced.  The length of the list is read back once, asynchronously, into pinned
+// memory; until it has arrived the short pass is launched with one block per row and the blocks beyond the list
+// leave at once.
+struct MaskCacheEntry {
+    void* ws = nullptr;
+    unsigned long long epoch = 0;
+    const int32_t* links = nullptr;
+    int32_t size[3] = {0, 0, 0};
+    int* h_count = nullptr;   // pinned
+    hipEvent_t ev = nullptr;  // the copy into h_count
+    bool pending = false;
+    int count = -1;
+    unsigned long long used = 0;
+};
+constexpr int kMaskCacheEntries = 8;
+std::mutex g_mask_cache_mu;
+MaskCacheEntry g_mask_cache[kMaskCacheEntries];
+unsigned long long g_mask_cache_clock = 0;
+
+// 1: the workspace holds the list for this epoch (live_blocks = blocks to launch); 0: it does not;
+// -1: epoch 0 (whatever the table says about this workspace is dropped: its planes are about to be rewritten in full,
+// which keeps the list true, but nothing promises `links` is what it was)
+int mask_cache_lookup(void* ws, unsigned long long epoch, const asurf_grid* grid, int n_rows, int* live_blocks) {
+    std::lock_guard<std::mutex> lock(g_mask_cache_mu);
+    for (MaskCacheEntry& e : g_mask_cache) {
+        if (e.ws != ws) continue;
+        if (epoch == 0ull) {
+            e.ws = nullptr;
+            return -1;
+        }
+        if (e.epoch != epoch || e.links != grid->links || e.size[0] != grid->size[0] || e.size[1] != grid->size[1] ||
+            e.size[2] != grid->size[2])
+            return 0;
+        if (e.pending && hipEventQuery(e.ev) == hipSuccess) {
+            e.pending = false;
+            e.count = *e.h_count;
+        }
+        e.used = ++g_mask_cache_clock;
+        *live_blocks = (e.pending || e.count < 0) ? n_rows : std::max(1, std::min(e.count, n_rows));
+        return 1;
+    }
+    return epoch == 0ull ? -1 : 0;
+}
+
+void mask_cache_store(void* ws, unsigned long long epoch, const asurf_grid* grid, const int* d_count, hipStream_t stream) {
+    std::lock_guard<std::mutex> lock(g_mask_cache_mu);
+    MaskCacheEntry* slot = nullptr;
+    for (MaskCacheEntry& e : g_mask_cache)
+        if (e.ws == ws) slot = &e;
+    if (!slot) {
+        slot = &g_mask_cache[0];
+        for (MaskCacheEntry& e : g_mask_cache)
+            if (e.ws == nullptr || e.used < slot->used) {
+                slot = &e;
+                if (e.ws == nullptr) break;
+            }
+    }
+    if (slot->pending) (void)hipEventSynchronize(slot->ev);  // (its old copy still writes h_count)
+    slot->ws = ws;
+    slot->epoch = epoch;
+    slot->links = grid->links;
+    for (int i = 0; i < 3; ++i) slot->size[i] = grid->size[i];
+    slot->count = -1;
+    slot->pending = false;
+    slot->used = ++g_mask_cache_clock;
+    if (!slot->h_count && hipHostMalloc(reinterpret_cast<void**>(&slot->h_count), sizeof(int)) != hipSuccess) {
+        slot->h_count = nullptr;
+        return;  // the list is used all the same, with the long grid
+    }
+    if (!slot->ev && hipEventCreateWithFlags(&slot->ev, hipEventDisableTiming) != hipSuccess) {
+        slot->ev = nullptr;
+        return;
+    }
+    if (hipMemcpyAsync(slot->h_count, d_count, sizeof(int), hipMemcpyDeviceToHost, stream) == hipSuccess &&
+        hipEventRecord(slot->ev, stream) == hipSuccess)
+        slot->pending = true;
+}
+
 // Common prologue: validation, workspace carve-up and the occupancy-pyramid pass.
 int prepare(const asurf_grid* grid, const asurf_rays* rays, const asurf_render_options* opt,
             int32_t M, void* workspace, size_t workspace_bytes, void* stream, Launch& L,
@@ -339,15 +426,36 @@ int prepare(const asurf_grid* grid, const asurf_rays* rays, const asurf_render_o
     L.sweep = !cuvol && !masks_only && want_sweep(use_live, L.o);
     prof_begin(L.stream);
     const int nzg = (L.ML.nb[2] + 7) / 8;  // groups of 8 bricks along z
-    hipLaunchKernelGGL(k_build_masks, dim3((unsigned)((size_t)L.ML.nb[0] * L.ML.nb[1] * nzg)), dim3(512), 0, L.stream, L.g,
-                       opt->sigma_thresh, cuvol ? 2 : (need_surf ? 1 : 0),  // 2: cuvol cells (asurf_cuvol.h)
-                       reinterpret_cast<unsigned long long*>(L.ws + L.ML.off_fine_work),
-                       reinterpret_cast<unsigned long long*>(L.ws + L.ML.off_fine_live),
-                       reinterpret_cast<unsigned int*>(L.ws + L.ML.off_coarse_work),
-                       reinterpret_cast<unsigned int*>(L.ws + L.ML.off_coarse_live),
-                       L.sweep ? reinterpret_cast<unsigned long long*>(L.ws + L.ML.off_fine_y) : nullptr,
-                       L.sweep ? reinterpret_cast<unsigned long long*>(L.ws + L.ML.off_fine_z) : nullptr,
-                       use_live ? 1 : 0, nzg);
+    unsigned long long* fw = reinterpret_cast<unsigned long long*>(L.ws + L.ML.off_fine_work);
+    unsigned long long* fl = reinterpret_cast<unsigned long long*>(L.ws + L.ML.off_fine_live);
+    unsigned int* cw = reinterpret_cast<unsigned int*>(L.ws + L.ML.off_coarse_work);
+    unsigned int* cl = reinterpret_cast<unsigned int*>(L.ws + L.ML.off_coarse_live);
+    unsigned long long* fy = reinterpret_cast<unsigned long long*>(L.ws + L.ML.off_fine_y);
+    unsigned long long* fz = reinterpret_cast<unsigned long long*>(L.ws + L.ML.off_fine_z);
+    MaskHdr* hdr = reinterpret_cast<MaskHdr*>(L.ws + L.ML.off_mask_hdr);
+    int* live_rows = reinterpret_cast<int*>(L.ws + L.ML.off_live_rows);
+    const int mode = cuvol ? 2 : (need_surf ? 1 : 0);  // 2: cuvol cells (asurf_cuvol.h)
+    // links_epoch (include/asurf.h): the rows of bricks that are not empty space are remembered in the workspace
+    const unsigned long long epoch = cuvol ? 0ull : (unsigned long long)grid->links_epoch;
+    int live_blocks = 0;
+    const int cached = mask_cache_lookup(workspace, epoch, grid, L.ML.n_rows, &live_blocks);
+    if (cached == 1) {
+        hipLaunchKernelGGL(k_build_masks_live, dim3((unsigned)live_blocks), dim3(512), 0, L.stream, L.g, opt->sigma_thresh,
+                           mode, fw, fl, cw, cl, L.sweep ? fy : nullptr, L.sweep ? fz : nullptr, use_live ? 1 : 0, nzg, hdr,
+                           live_rows, epoch, L.ML.n_rows);
+    } else if (cached == 0 && epoch != 0ull) {
+        // first call with this value: the full pass, leaving the list (and zeros in EVERY plane of the empty rows)
+        if (hipMemsetAsync(hdr, 0, sizeof(MaskHdr), L.stream) != hipSuccess)
+            return fail(ASURF_E_LAUNCH, "hipMemsetAsync(mask header) failed");
+        hipLaunchKernelGGL(k_build_masks, dim3((unsigned)L.ML.n_rows), dim3(512), 0, L.stream, L.g, opt->sigma_thresh, mode,
+                           fw, fl, cw, cl, fy, fz, use_live ? 1 : 0, nzg, hdr, live_rows);
+        hipLaunchKernelGGL(k_mask_seal, dim3(1), dim3(1), 0, L.stream, hdr, epoch);
+        mask_cache_store(workspace, epoch, grid, &hdr->n_live, L.stream);
+    } else {
+        hipLaunchKernelGGL(k_build_masks, dim3((unsigned)L.ML.n_rows), dim3(512), 0, L.stream, L.g, opt->sigma_thresh, mode,
+                           fw, fl, cw, cl, L.sweep ? fy : nullptr, L.sweep ? fz : nullptr, use_live ? 1 : 0, nzg,
+                           static_cast<MaskHdr*>(nullptr), static_cast<int*>(nullptr));
+    }
     prof_after("k_build_masks", 0, L.stream);
     return launch_error("k_build_masks");
 }

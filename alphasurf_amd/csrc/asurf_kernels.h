@@ -43,24 +43,74 @@ __device__ __forceinline__ unsigned long long spread_bits_to_bytes(unsigned b) {
     return ((((x & lo7) + lo7) | x) >> 7) & 0x0101010101010101ull;
 }
 
-__global__ void __launch_bounds__(512)
-k_build_masks(KGrid g, float sigma_thresh, int need_surf, unsigned long long* fine_work,
-              unsigned long long* fine_live, unsigned int* coarse_work,
-              unsigned int* coarse_live, unsigned long long* fine_y, unsigned long long* fine_z,
-              int orient_live, int nzg) {
-    const TlScope tl(1);
+struct MaskTables {  // per block
+    unsigned long long xw[64], xl[64], z[64];  // [x-slab][brick], [x-slab][brick], [brick][lz]
+    int alive;
+};
+
+// one row of 8 bricks along z (row = (bx * nb1 + by) * nzg + zg); returns whether this wave saw a vertex in it
+// the end of a row: the block's tables go out as the bricks' words (x, y and z cuts) and the coarse bytes
+__device__ __forceinline__ void build_masks_row_finish(const KGrid& g, unsigned long long* fine_work,
+                                                       unsigned long long* fine_live, unsigned int* coarse_work,
+                                                       unsigned int* coarse_live, unsigned long long* fine_y,
+                                                       unsigned long long* fine_z, int bx, int by, int bxy, int zg,
+                                                       unsigned long long acc_y, unsigned long long acc_z,
+                                                       MaskTables& S) {
+    unsigned long long* s_xw = S.xw;
+    unsigned long long* s_xl = S.xl;
+    unsigned long long* s_z = S.z;
     const int t = threadIdx.x;
     const int ly = t >> 6, l = t & 63;
-    const int zg = blockIdx.x % nzg;
-    const int bxy = blockIdx.x / nzg;
+    if (fine_y && acc_z) atomicOr(&s_z[l], acc_z);
+    __syncthreads();
+    const size_t brick0 = ((size_t)bx * g.nb[1] + by) * g.nb[2] + (size_t)zg * 8;
+    const int nbr = min(8, g.nb[2] - zg * 8);  // bricks of the row that exist
+    if (fine_y && l < nbr) fine_y[(brick0 + l) * 8 + ly] = acc_y;
+    if (t < 64) {
+        const int lx = t >> 3, j = t & 7;
+        if (j < nbr) {
+            fine_work[(brick0 + j) * 8 + lx] = s_xw[t];
+            fine_live[(brick0 + j) * 8 + lx] = s_xl[t];
+        }
+        const int j2 = t >> 3, lz = t & 7;
+        if (fine_y && j2 < nbr) fine_z[(brick0 + j2) * 8 + lz] = s_z[t];
+    }
+    if (t == 0) {
+        unsigned cw = 0, cl = 0;
+        for (int j = 0; j < 8; ++j) {
+            unsigned long long aw = 0ull, al = 0ull;
+            for (int lx = 0; lx < 8; ++lx) {
+                aw |= s_xw[lx * 8 + j];
+                al |= s_xl[lx * 8 + j];
+            }
+            cw |= (aw != 0ull ? 1u : 0u) << j;
+            cl |= (al != 0ull ? 1u : 0u) << j;
+        }
+        reinterpret_cast<unsigned char*>(coarse_work)[(size_t)bxy * g.nwz * 4 + zg] = (unsigned char)cw;
+        reinterpret_cast<unsigned char*>(coarse_live)[(size_t)bxy * g.nwz * 4 + zg] = (unsigned char)cl;
+    }
+}
+
+__device__ __forceinline__ bool build_masks_row(const KGrid& g, float sigma_thresh, int need_surf,
+                                                unsigned long long* fine_work, unsigned long long* fine_live,
+                                                unsigned int* coarse_work, unsigned int* coarse_live,
+                                                unsigned long long* fine_y, unsigned long long* fine_z, int orient_live,
+                                                int nzg, unsigned row, MaskTables& S) {
+    unsigned long long* s_xw = S.xw;
+    unsigned long long* s_xl = S.xl;
+    unsigned long long* s_z = S.z;
+    const int t = threadIdx.x;
+    const int ly = t >> 6, l = t & 63;
+    const int zg = (int)(row % (unsigned)nzg);
+    const int bxy = (int)(row / (unsigned)nzg);
     const int by = bxy % g.nb[1];
     const int bx = bxy / g.nb[1];
-    __shared__ unsigned long long s_xw[64], s_xl[64], s_z[64];  // [x-slab][brick], [x-slab][brick], [brick][lz]
     if (t < 64) s_xw[t] = s_xl[t] = s_z[t] = 0ull;
     __syncthreads();
     const int y = by * 8 + ly, z = zg * 64 + l;
     const bool inside_yz = y + 1 < g.size[1] && z + 1 < g.size[2];
     unsigned long long acc_y = 0ull, acc_z = 0ull;
+    bool alive = false;  // some run of this wave holds a vertex (a function of `links` alone)
     // The kernel streams `links` and is as fast as the bytes it keeps in flight (one 256-byte request per wave
     // would be 2 MB on the whole chip: 1 TB/s at the 2 us such a request takes): all eight slabs' first links
     // are asked for before the first one is looked at.
@@ -81,6 +131,7 @@ k_build_masks(KGrid g, float sigma_thresh, int need_surf, unsigned long long* fi
         // most of a sparse grid is empty space: when no cell of the run has its own vertex (and the surf_trav
         // planes need all eight), the other seven loads are skipped for the whole wave
         const bool run_dead = need_surf != 2 && __ballot(l0 >= 0) == 0ull;
+        alive = alive || !run_dead;
         if (inside && !run_dead) {
             const int32_t l1 = p[1], l2 = p[g.offy], l3 = p[g.offy + 1];
             const int32_t l4 = p[g.offx], l5 = p[g.offx + 1], l6 = p[g.offx + g.offy],
@@ -129,33 +180,61 @@ k_build_masks(KGrid g, float sigma_thresh, int need_surf, unsigned long long* fi
         }
         if (orient_live ? live : work) acc_z |= 1ull << (lx * 8 + ly);
     }
-    if (fine_y && acc_z) atomicOr(&s_z[l], acc_z);
-    __syncthreads();
-    const size_t brick0 = ((size_t)bx * g.nb[1] + by) * g.nb[2] + (size_t)zg * 8;
-    const int nbr = min(8, g.nb[2] - zg * 8);  // bricks of the row that exist
-    if (fine_y && l < nbr) fine_y[(brick0 + l) * 8 + ly] = acc_y;
-    if (t < 64) {
-        const int lx = t >> 3, j = t & 7;
-        if (j < nbr) {
-            fine_work[(brick0 + j) * 8 + lx] = s_xw[t];
-            fine_live[(brick0 + j) * 8 + lx] = s_xl[t];
-        }
-        const int j2 = t >> 3, lz = t & 7;
-        if (fine_y && j2 < nbr) fine_z[(brick0 + j2) * 8 + lz] = s_z[t];
+    build_masks_row_finish(g, fine_work, fine_live, coarse_work, coarse_live, fine_y, fine_z, bx, by, bxy, zg, acc_y, acc_z,
+                           S);
+    return alive;
+}
+
+// MaskHdr: what a workspace remembers about `links` between calls (asurf_grid::links_epoch, include/asurf.h): the
+// rows of bricks in which some 64-run of vertices along z holds a link >= 0.  Every other row is empty space whatever
+// the densities and surfaces: its words in all planes are zero and stay zero.
+struct MaskHdr {
+    unsigned long long magic, epoch;
+    int n_live, pad;
+};
+constexpr unsigned long long kMaskMagic = 0x61737572666d736bull;
+
+__global__ void __launch_bounds__(512)
+k_build_masks(KGrid g, float sigma_thresh, int need_surf, unsigned long long* fine_work,
+              unsigned long long* fine_live, unsigned int* coarse_work,
+              unsigned int* coarse_live, unsigned long long* fine_y, unsigned long long* fine_z,
+              int orient_live, int nzg, MaskHdr* hdr, int* live_rows) {
+    const TlScope tl(1);
+    __shared__ MaskTables S;
+    if (threadIdx.x == 0) S.alive = 0;
+    const bool alive = build_masks_row(g, sigma_thresh, need_surf, fine_work, fine_live, coarse_work, coarse_live, fine_y,
+                                       fine_z, orient_live, nzg, blockIdx.x, S);
+    if (hdr != nullptr) {  // (wave-uniform) leave the list of rows that are not empty space
+        if (alive && (threadIdx.x & 63) == 0) S.alive = 1;
+        __syncthreads();
+        if (threadIdx.x == 0 && S.alive) live_rows[atomicAdd(&hdr->n_live, 1)] = (int)blockIdx.x;
     }
-    if (t == 0) {
-        unsigned cw = 0, cl = 0;
-        for (int j = 0; j < 8; ++j) {
-            unsigned long long aw = 0ull, al = 0ull;
-            for (int lx = 0; lx < 8; ++lx) {
-                aw |= s_xw[lx * 8 + j];
-                al |= s_xl[lx * 8 + j];
-            }
-            cw |= (aw != 0ull ? 1u : 0u) << j;
-            cl |= (al != 0ull ? 1u : 0u) << j;
-        }
-        reinterpret_cast<unsigned char*>(coarse_work)[(size_t)bxy * g.nwz * 4 + zg] = (unsigned char)cw;
-        reinterpret_cast<unsigned char*>(coarse_live)[(size_t)bxy * g.nwz * 4 + zg] = (unsigned char)cl;
+    tl.end();
+}
+
+__global__ void k_mask_seal(MaskHdr* hdr, unsigned long long epoch) {
+    hdr->magic = kMaskMagic;
+    hdr->epoch = epoch;
+}
+
+// The same pass over the rows of the list only.  (Its waves are all resident from the start and each is a chain of
+// 24 dependent round trips; with the loads of four x-slabs in flight together the chain is 6 long and the registers
+// halve the resident waves: 0.055 ms either way at 256^3, a third of the rows live.)
+__global__ void __launch_bounds__(512)
+k_build_masks_live(KGrid g, float sigma_thresh, int need_surf, unsigned long long* fine_work,
+                   unsigned long long* fine_live, unsigned int* coarse_work, unsigned int* coarse_live,
+                   unsigned long long* fine_y, unsigned long long* fine_z, int orient_live, int nzg,
+                   const MaskHdr* hdr, const int* live_rows, unsigned long long epoch, int n_rows) {
+    const TlScope tl(1);
+    __shared__ MaskTables S;
+    if (hdr->magic != kMaskMagic || hdr->epoch != epoch) return;  // not the buffer the caller promised: nothing is read
+    const int n = min(hdr->n_live, n_rows);
+    for (int i = blockIdx.x; i < n; i += gridDim.x) {
+        const int row = live_rows[i];
+        if (row >= 0 && row < n_rows)
+            build_masks_row(g, sigma_thresh, need_surf, fine_work, fine_live, coarse_work, coarse_live, fine_y, fine_z,
+                            orient_live, nzg, (unsigned)row, S);
+        __syncthreads();  // (the next row zeroes the tables)
     }
     tl.end();
 }

@@ -36,6 +36,9 @@ class SparseGridSpec:
         self.background_data = None
         self.fake_sample_std = 1.0
         self.truncated_vol_render_a = 1.0
+        # (no reference counterpart) non-zero: "`links` has not changed since the last call that carried this value"
+        # -- include/asurf.h, asurf_grid::links_epoch; 0: the occupancy pass reads the whole link volume
+        self.links_epoch = 0
 
 
 class CameraSpec:
@@ -163,6 +166,11 @@ def _pack_grid(grid, need_surface=True):
     g.level_set_data = _ptr(grid.level_set_data) if has_surface else C.c_void_p(0)
     g.capacity = grid.density_data.shape[0]
     g.size = (C.c_int32 * 3)(*grid.links.shape)
+    # links_epoch (include/asurf.h): a spec that carries a non-zero `links_epoch` vouches for raw-pointer writes to
+    # `links`; the tensor's own identity and version counter are mixed in here, the workspace's in _workspace()
+    g.links_epoch = 0
+    ep = int(getattr(grid, "links_epoch", 0) or 0)
+    g._epoch_base = (ep, grid.links.data_ptr(), grid.links._version, tuple(grid.links.shape)) if ep else None
     g.level_set_num = grid.level_set_data.numel() if has_surface else 0
     g.basis_dim = int(grid.basis_dim)
     g.basis_type = int(grid.basis_type)
@@ -227,19 +235,27 @@ def _pack_grads(grads, grid):
 
 _ws_cache = {}
 _ws_lock = threading.Lock()
+_ws_nonce = {}
 
 
-def _workspace(device, nbytes):
+def _workspace(device, nbytes, g=None):
     """Scratch for one call.  A per-(device, stream) buffer is grown on demand and reused: the launches are
     stream-ordered, so calls on one stream may share it whichever host thread issues them (a caller that was
     handed the old buffer keeps it alive until its own launches are queued; the caching allocator does not
-    reuse the block before the stream has passed them).  The lock only guards the dictionary."""
+    reuse the block before the stream has passed them).  The lock only guards the dictionary.
+    g: the call's AsurfGrid -- when the spec carried a `links_epoch`, it is mixed here with the buffer's own
+    incarnation number, which is what include/asurf.h asks of the value (same links AND same, untouched buffer)."""
     key = (device.type, device.index, torch.cuda.current_stream(device).cuda_stream)
     with _ws_lock:
         buf = _ws_cache.get(key)
         if buf is None or buf.numel() < nbytes:
             buf = torch.empty(int(nbytes), dtype=torch.uint8, device=device)
             _ws_cache[key] = buf
+            _ws_nonce[key] = _ws_nonce.get(key, 0) + 1
+        nonce = _ws_nonce.get(key, 0)
+    base = getattr(g, "_epoch_base", None) if g is not None else None
+    if base:
+        g.links_epoch = (hash((base, nonce, buf.data_ptr())) & 0xFFFFFFFFFFFFFFFF) | 1
     return buf
 
 
@@ -266,7 +282,7 @@ def volume_render_surf_trav(grid, rays, opt, counters=None):
     with torch.cuda.device(dev):
         out = torch.empty_like(rays.origins)
         nb = _L.workspace_bytes(grid.links.shape, r.n_rays, 0)
-        ws = _workspace(dev, nb)
+        ws = _workspace(dev, nb, g)
         _L.check(_L.lib().asurf_volume_render_surf_trav(
             C.byref(g), C.byref(r), C.byref(o), _ptr(out), _ptr(ws), nb, _counters_ptr(counters),
             _stream(dev)))
@@ -285,7 +301,7 @@ def volume_render_surf_trav_backward(grid, rays, opt, grad_out, color_cache, gra
     dev = grid.sh_data.device
     with torch.cuda.device(dev):
         nb = _L.workspace_bytes(grid.links.shape, r.n_rays, 0)
-        ws = _workspace(dev, nb)
+        ws = _workspace(dev, nb, g)
         _L.check(_L.lib().asurf_volume_render_surf_trav_backward(
             C.byref(g), C.byref(r), C.byref(o), _ptr(grad_out), _ptr(color_cache), C.byref(gg),
             _ptr(ws), nb, C.c_void_p(0), _stream(dev)))
@@ -334,7 +350,7 @@ def volume_render_surf_trav_fused(grid, rays, opt, rgb_gt, beta_loss, sparsity_l
     dev = grid.sh_data.device
     with torch.cuda.device(dev):
         nb = _L.workspace_bytes(grid.links.shape, r.n_rays, int(l_dist_max_sample))
-        ws = _workspace(dev, nb)
+        ws = _workspace(dev, nb, g)
         _L.check(_L.lib().asurf_volume_render_surf_trav_fused(
             C.byref(g), C.byref(r), C.byref(o), C.byref(f), _ptr(rgb_out), C.byref(gg), _ptr(ws),
             nb, _counters_ptr(counters), _stream(dev)))
@@ -697,7 +713,7 @@ def _render_eval(grid, rays, opt, mode, param, max_sample=1):
             out0 = torch.empty((q,), dtype=torch.float32, device=dev)
             out1 = None
         nb = _L.workspace_bytes(grid.links.shape, q, 0)  # (with the per-ray tables: the render runs behind k_sweep)
-        ws = _workspace(dev, nb)
+        ws = _workspace(dev, nb, g)
         _L.check(_L.lib().asurf_render_eval_surf_trav(
             C.byref(g), C.byref(r), C.byref(o), int(mode), float(param), int(max_sample), _ptr(out0),
             _ptr(out1) if out1 is not None else None, _ptr(ws), nb, _stream(dev)))

@@ -471,6 +471,8 @@ class SparseGrid(nn.Module):
             g.fake_sample_std = float(self.fake_sample_std.item()) if torch.is_tensor(self.fake_sample_std) \
                 else float(self.fake_sample_std)
         g.truncated_vol_render_a = self.truncated_vol_render_a
+        # (no reference counterpart) the renders keep their list of non-empty brick rows while `links` stays what it is
+        g.links_epoch = (id(self) << 20) + self.__dict__.get("_links_epoch", 0) + 1
         return g
 
     def _get_data_grads(self):
@@ -789,6 +791,7 @@ class SparseGrid(nn.Module):
         assert self.links.is_cuda, "the HIP extension is required for accelerate"
         _C.accel_dist_prop(self.links)
         self.__dict__["_non_empty_cache"] = None  # links were rewritten through a raw pointer
+        self._bump_links_epoch()
 
     def safe_fetch_data(self, xyz, data, default=0):
         """data rows at integer grid coordinates, `default` outside the grid / at empty links (:2859-2872)."""
@@ -1057,7 +1060,14 @@ class SparseGrid(nn.Module):
     def __setattr__(self, name, value):
         if name == "links":
             self.__dict__["_non_empty_cache"] = None
+            self._bump_links_epoch()
         super().__setattr__(name, value)
+
+    def _bump_links_epoch(self):
+        """`links` was replaced, or written through a raw pointer: the spec's links_epoch (include/asurf.h) changes,
+        and the next render rebuilds its list of non-empty brick rows.  In-place tensor writes need no call: the
+        tensor's version counter is part of the value (csrc_api._pack_grid)."""
+        self.__dict__["_links_epoch"] = self.__dict__.get("_links_epoch", 0) + 1
 
     def _get_data_to_links(self):
         """:6378-6382"""

@@ -25,6 +25,7 @@ class AsurfGrid(C.Structure):
         ("basis_type", C.c_int32), ("surface_type", C.c_int32), ("offset", C.c_float * 3),
         ("scaling", C.c_float * 3), ("fake_sample_std", C.c_float),
         ("truncated_vol_render_a", C.c_float), ("background_nlayers", C.c_int32),
+        ("links_epoch", C.c_uint64),
     ]
 
 
@@ -170,7 +171,7 @@ def lib():
         L.asurf_ray_order_tmp_bytes.restype = C.c_size_t
         L.asurf_ray_order.argtypes = [vp, vp, C.c_int64, vp, vp, C.c_size_t, vp]
         L.asurf_test_quotient.argtypes = [vp, vp, C.c_int64, vp, vp, vp]
-        if L.asurf_abi_version() != 1:
+        if L.asurf_abi_version() != 2:
             raise RuntimeError("libasurf_hip.so ABI version mismatch")
         _lib = L
     return _lib

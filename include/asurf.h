@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define ASURF_ABI_VERSION 1
+#define ASURF_ABI_VERSION 2
 
 /* error codes */
 #define ASURF_OK 0
@@ -79,6 +79,15 @@ typedef struct asurf_grid {
     float fake_sample_std;
     float truncated_vol_render_a;
     int32_t background_nlayers;  /* must be 0: MSI background is outside this build's scope */
+    /* 0, or a promise that saves most of the occupancy-pyramid pass: a non-zero value says "since the last call that
+     * carried this same value on this same workspace buffer, neither the contents of `links` nor the buffer (not
+     * freed, not written by the caller) have changed".  The pass then keeps the list of the rows of bricks that hold
+     * any vertex -- the rest of the link volume is empty space it need not read again.  A training loop changes
+     * densities and surfaces in every iteration and `links` only when it prunes or up-samples: pass a counter
+     * bumped there, mixed with one bumped whenever the workspace is reallocated.  (No reference counterpart: the
+     * reference walks `links` in every kernel.)  The first call with a new value runs the full pass, reads one
+     * counter back asynchronously and is not graph-capturable. */
+    uint64_t links_epoch;
 } asurf_grid;
 
 /* Replaces RaysSpec / PackedRaysSpec (data_spec.hpp:142-154). */

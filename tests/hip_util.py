@@ -25,13 +25,23 @@ def dev():
     return torch.device("cuda:0")
 
 
-def grid_spec(sc):
+_links_keep = {}
+
+
+def grid_spec(sc, links_epoch=0):
     d = dev()
     g = _C.SparseGridSpec()
+    if links_epoch:
+        # the promise of links_epoch is about one `links` tensor that stays where it is: keep it between calls
+        key = (id(sc["links"]), links_epoch)
+        if key not in _links_keep:
+            _links_keep.clear()
+            _links_keep[key] = (sc["links"], torch.from_numpy(sc["links"]).to(d))
+        g.links_epoch = links_epoch
     g.density_data = torch.from_numpy(sc["density"]).to(d)
     g.surface_data = torch.from_numpy(sc["surface"]).to(d)
     g.sh_data = torch.from_numpy(sc["sh"]).to(d)
-    g.links = torch.from_numpy(sc["links"]).to(d)
+    g.links = _links_keep[(id(sc["links"]), links_epoch)][1] if links_epoch else torch.from_numpy(sc["links"]).to(d)
     g.level_set_data = torch.from_numpy(sc["level_set"]).to(d)
     g._offset = torch.from_numpy(np.asarray(sc["offset"], np.float32))
     g._scaling = torch.from_numpy(np.asarray(sc["scaling"], np.float32))
@@ -101,8 +111,8 @@ def render_backward(sc, origins, dirs, opts, grad_out, color_cache):
     return grads_np(gr)
 
 
-def render_fused(sc, origins, dirs, opts, rgb_gt, fused=None, global_n_rays=0, counters=False):
-    g, r, o = grid_spec(sc), rays_spec(origins, dirs), opt_spec(opts)
+def render_fused(sc, origins, dirs, opts, rgb_gt, fused=None, global_n_rays=0, counters=False, links_epoch=0):
+    g, r, o = grid_spec(sc, links_epoch), rays_spec(origins, dirs), opt_spec(opts)
     gr = zero_grads(g)
     fused = dict(fused or {})
     args = [fused.pop(k, dflt) for k, dflt in FUSED_ORDER]
