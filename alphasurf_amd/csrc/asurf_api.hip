@@ -456,7 +456,7 @@ int prepare(const asurf_grid* grid, const asurf_rays* rays, const asurf_render_o
                            fw, fl, cw, cl, L.sweep ? fy : nullptr, L.sweep ? fz : nullptr, use_live ? 1 : 0, nzg,
                            static_cast<MaskHdr*>(nullptr), static_cast<int*>(nullptr));
     }
-    prof_after("k_build_masks", 0, L.stream);
+    prof_after(cached == 1 ? "k_build_masks_live" : "k_build_masks", 0, L.stream);
     return launch_error("k_build_masks");
 }
 

@@ -64,6 +64,7 @@ def algorithmic_bytes_per_kernel(n_rays, v_t, v_a, s, D, stat_loss, M):
     cache = 2 * 3 * 4 * min(s, n_rays * M) if stat_loss else 0
     return {
         "k_build_masks": 0.0,                                   # no counterpart in the model
+        "k_build_masks_live": 0.0,                              # (the same pass over the non-empty brick rows)
         "k_sweep": float(24 * n_rays + 32 * v_t),               # ray + 8 links per visited voxel: the search for the
         "k_walk": float(24 * n_rays + 32 * v_t),                # work voxels (k_sweep, or k_walk with ASURF_WALK=step)
         "k_geom": float(64 * v_a),                              # 8 density + 8 surface values
