@@ -518,14 +518,16 @@ int find_candidates(const Launch& L, const asurf_rays* rays, bool record, PipeBu
             // rays per block from the (ray, brick layer) pairs a block takes; threads from the measured optimum (the
             // pairs are strided over them): 256 threads x 16 rays at 256^3 -- with 512 the phases that occupy one
             // wave leave seven waiting (0.50 ms against 0.35), with 128 a block takes too many rounds (0.39)
-            // (at least 8 rays per block: its fixed costs -- barriers, set-up, allocation -- are per block)
-            const int rpb = std::max(8, std::min(kSweepLanes >> lpr_log2, kSweepMaxRays));
+            // 16 rays per block whatever the grid: the block's fixed costs -- barriers, set-up, allocation -- are per
+            // block (8 rays at 512^3 and 768^3, as the 512 pairs of round 2's first half allowed: k_sweep 0.62 against
+            // 0.51 ms at 512^3, 3.39 against 3.05 at 768^3)
+            const int rpb = 16;
             const int sweep_threads = std::min(kSweepThreads, std::max(64, rpb << lpr_log2));
             // at least 128 keys per ray: a ray that finds more is handed to the one-kernel path, whose latency
             // (that of one wave walking a whole ray) is then the call's
-            const int keys = std::max(kSweepKeys, rpb * 128);
+            const int keys = std::max(kSweepKeys, rpb * (lpr_log2 >= 7 ? 256 : 128));  // (longer rays on larger grids)
             const int K = keys / rpb;
-            const int task_cap = (rpb << lpr_log2) * kSweepTasksPerLane2 / 2;
+            const int task_cap = std::min((rpb << lpr_log2) * kSweepTasksPerLane2 / 2, 2560);  // (20 KB; k_sweep takes fewer rays a pass beyond)
             const size_t lds = (size_t)rpb * sizeof(SweepRay) + (size_t)task_cap * 8 + (size_t)keys * 4;
             const dim3 sgrid((unsigned)((Q + rpb - 1) / rpb));
             hipLaunchKernelGGL(k_sweep, sgrid, dim3(sweep_threads), lds, L.stream, L.g, L.o, rays->origins,

@@ -183,7 +183,8 @@ k_sweep(KGrid g, KOpt o, const float* __restrict__ origins, const float* __restr
     }
 
     // Phases 1 and 2 run once over all rays of the block; if the task list would not hold them (scenes where
-    // most bricks hold a flagged voxel) they run again in four passes over a quarter of the rays each, which
+    // most bricks hold a flagged voxel) they run again in four passes over a quarter of the rays each (one ray a pass
+    // where the brick layers are so many that a quarter could still overflow), which
     // fits whatever the scene: (pairs per block / 4) x 9 bricks <= task_cap.
     int passes = 1;
     for (int pass = 0; pass < passes; ++pass) {
@@ -227,7 +228,7 @@ k_sweep(KGrid g, KOpt o, const float* __restrict__ origins, const float* __restr
         __syncthreads();
         if (tid == 0) s_ntask = 0;
         __syncthreads();
-        passes = min(4, rpb);
+        passes = (((rpb / 4) << lpr_log2) * 9 <= task_cap) ? min(4, rpb) : rpb;  // (a pass always fits: 9 bricks a pair)
         pass = -1;
         continue;
     }
