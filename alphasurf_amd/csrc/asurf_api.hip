@@ -531,7 +531,7 @@ int find_candidates(const Launch& L, const asurf_rays* rays, bool record, PipeBu
             const size_t lds = (size_t)rpb * sizeof(SweepRay) + (size_t)task_cap * 8 + (size_t)keys * 4;
             const dim3 sgrid((unsigned)((Q + rpb - 1) / rpb));
             hipLaunchKernelGGL(k_sweep, sgrid, dim3(sweep_threads), lds, L.stream, L.g, L.o, rays->origins,
-                               rays->dirs, Q, P, lpr_log2, rpb, K, record ? 1 : 0, task_cap);
+                               rays->dirs, Q, P, lpr_log2, rpb, K, record ? 1 : 0, task_cap, nbmax);
         } else if (seg > 1) {
             const dim3 seg_grid((unsigned)((Q * seg + kBlock - 1) / kBlock));
 #define ASURF_WALK_SEG(S_)                                                                                   \

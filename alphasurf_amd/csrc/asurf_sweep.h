@@ -74,7 +74,7 @@ __device__ __forceinline__ int sweep_clampi(int v, int lo, int hi) { return min(
 // read from global memory (4 KB at 256^3: it lives in L1).
 __global__ void __launch_bounds__(kSweepMaxThreads)
 k_sweep(KGrid g, KOpt o, const float* __restrict__ origins, const float* __restrict__ dirs, long long Q,
-        PipeBuf P, int lpr_log2, int rpb, int K, int want_cut, int task_cap) {
+        PipeBuf P, int lpr_log2, int rpb, int K, int want_cut, int task_cap, int n_layers) {
     extern __shared__ uint4 s_dyn4[];   // [rpb rays] [task_cap tasks] [rpb * K keys]
     SweepRay* s_ray = reinterpret_cast<SweepRay*>(s_dyn4);
     uint2* s_tasks = reinterpret_cast<uint2*>(s_ray + rpb);  // x: ray | layer | brick b | brick c, y: brick index
@@ -190,8 +190,11 @@ k_sweep(KGrid g, KOpt o, const float* __restrict__ origins, const float* __restr
     for (int pass = 0; pass < passes; ++pass) {
     const int r_lo = (pass * rpb) / passes, r_hi = ((pass + 1) * rpb) / passes;
     // ---- phase 1: (ray, brick layer) -> tasks ----
-    for (int lt = tid; lt < (rpb << lpr_log2); lt += nthreads) {
-        const int rl = lt >> lpr_log2, A = lt & ((1 << lpr_log2) - 1);
+    // (pairs = rays x the layers of the longest axis, not rounded up to a power of two: 96 at 768^3, 48 at 384^3;
+    // the quotient through a float reciprocal is exact for these sizes, pairs < 2^12 and layers <= 128)
+    const float inv_layers = 1.f / (float)n_layers;
+    for (int lt = tid; lt < rpb * n_layers; lt += nthreads) {
+        const int rl = (int)(((float)lt + 0.5f) * inv_layers), A = lt - rl * n_layers;
         if (rl >= r_lo && rl < r_hi) {
             const SweepRay R = s_ray[rl];
             if (R.state == 1 && A < R.na) {
