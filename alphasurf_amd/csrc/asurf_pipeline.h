@@ -665,8 +665,11 @@ k_geom(KGrid g, KOpt o, const float* __restrict__ origins, const float* __restri
 }
 
 // ------------------------------------------------------------------------------------
+#ifndef ASURF_COMP_WAVES
+#define ASURF_COMP_WAVES 5
+#endif
 template <int B, bool CACHE>
-__global__ void __launch_bounds__(kBlock)
+__global__ void __launch_bounds__(kBlock, (B <= 9 ? ASURF_COMP_WAVES : 4))
 k_comp(KGrid g, KOpt o, const float* __restrict__ dirs, long long Q, PipeBuf P,
        float* __restrict__ rgb_out, int M, float* __restrict__ cache_a, float* __restrict__ cache_w,
        float* __restrict__ cache_t, int* __restrict__ cache_n, int* __restrict__ rec_v,
