@@ -627,7 +627,8 @@ int run_forward(const Launch& L, const asurf_rays* rays, float* rgb_out, int M, 
 // 3: record replay as three kernels (asurf_bwd_pipeline.h)
 template <int B>
 int run_backward(const Launch& L, const asurf_rays* rays, const KLoss& loss, const KGrads& G,
-                 const float* grad_in, const float* color_cache, int M, bool fused, int mode) {
+                 const float* grad_in, const float* color_cache, int M, bool fused, int mode,
+                 bool counters_zeroed = false) {
     const float* ca = reinterpret_cast<const float*>(L.ws + L.ML.off_cache_a);
     const float* cw = reinterpret_cast<const float*>(L.ws + L.ML.off_cache_w);
     const float* ct = reinterpret_cast<const float*>(L.ws + L.ML.off_cache_t);
@@ -673,7 +674,9 @@ int run_backward(const Launch& L, const asurf_rays* rays, const KLoss& loss, con
         S.sws = reinterpret_cast<float*>(L.ws + L.ML.off_rec_sws);
         S.R = kRecDepth;
         const long long Q = rays->n_rays;
-        if (hipMemsetAsync(S.n_list, 0, sizeof(int), L.stream) != hipSuccess)
+        // (the list's cursor lies among the pipeline's counters: the forward of this call has zeroed it if it ran the
+        // pipeline -- a memset node of its own is 4 us on the stream)
+        if (!counters_zeroed && hipMemsetAsync(S.n_list, 0, sizeof(int), L.stream) != hipSuccess)
             return fail(ASURF_E_LAUNCH, "hipMemsetAsync failed");
         hipLaunchKernelGGL(k_bwd_seq, L.ray_grid, dim3(kBlock), 0, L.stream, L.o, loss, L.g.trunc_a, Q,
                            grad_in, color_cache, M, ca, cw, ct, cn, S);
@@ -976,7 +979,7 @@ int asurf_volume_render_surf_trav_fused(const asurf_grid* grid, const asurf_rays
         const int replay_mode =
             ((nosplit && atoi(nosplit)) || rays->n_rays >= (1ll << kListRayBits)) ? 1 : 3;
         ASURF_DISPATCH_B(grid->basis_dim,
-                         run_backward<B_>(L, rays, loss, G, fused->rgb_gt, rgb_out, M, true, replay_mode));
+                         run_backward<B_>(L, rays, loss, G, fused->rgb_gt, rgb_out, M, true, replay_mode, pipe));
         if (rc) return rc;
         ASURF_DISPATCH_B(grid->basis_dim, run_backward<B_>(L, rays, loss, G, fused->rgb_gt, rgb_out, M, true, 2));
     } else {

@@ -156,11 +156,17 @@ class GradArena:
         self.grad_surface = self.flat[offs[2]:offs[2] + sizes[2]].view(n_rows, 1)
         self.touched = self.flat[offs[3]:offs[3] + sizes[3]]
         self.grad_fake_sample_std = self.flat[offs[4]:offs[4] + 1].view(1, 1)
-        self.mask = torch.zeros(n_rows, dtype=torch.bool, device=device)
+        # the mask lives in 8-byte words: torch's fill kernel for bool takes 15 us for 1.3 M rows, for the same bytes
+        # as int64 2 us (rocprofv3, profiles/r2_kernel_stats.csv)
+        self._mask_words = torch.zeros((n_rows + 7) // 8, dtype=torch.int64, device=device)
+        self.mask = self._mask_words.view(torch.bool)[:n_rows]
+
+    def zero_mask(self):
+        self._mask_words.zero_()
 
     def zero_(self):
         self.flat.zero_()
-        self.mask.zero_()
+        self.zero_mask()
 
     def all_reduce(self, group=None):
         """Sum over the ranks in place; `mask` becomes the union of the ranks' masks."""

