@@ -437,24 +437,27 @@ int prepare(const asurf_grid* grid, const asurf_rays* rays, const asurf_render_o
     const int mode = cuvol ? 2 : (need_surf ? 1 : 0);  // 2: cuvol cells (asurf_cuvol.h)
     // links_epoch (include/asurf.h): the rows of bricks that are not empty space are remembered in the workspace
     const unsigned long long epoch = cuvol ? 0ull : (unsigned long long)grid->links_epoch;
+    // the pipeline's counters (when the layout has them) are zeroed by block 0 of the pass
+    int* zero_ptr = (!masks_only && rays->n_rays > 0) ? reinterpret_cast<int*>(L.ws + L.ML.off_p_counters) : nullptr;
+    const int zero_n = zero_ptr ? kCtrTotal : 0;
     int live_blocks = 0;
     const int cached = mask_cache_lookup(workspace, epoch, grid, L.ML.n_rows, &live_blocks);
     if (cached == 1) {
         hipLaunchKernelGGL(k_build_masks_live, dim3((unsigned)live_blocks), dim3(512), 0, L.stream, L.g, opt->sigma_thresh,
                            mode, fw, fl, cw, cl, L.sweep ? fy : nullptr, L.sweep ? fz : nullptr, use_live ? 1 : 0, nzg, hdr,
-                           live_rows, epoch, L.ML.n_rows);
+                           live_rows, epoch, L.ML.n_rows, zero_ptr, zero_n);
     } else if (cached == 0 && epoch != 0ull) {
         // first call with this value: the full pass, leaving the list (and zeros in EVERY plane of the empty rows)
         if (hipMemsetAsync(hdr, 0, sizeof(MaskHdr), L.stream) != hipSuccess)
             return fail(ASURF_E_LAUNCH, "hipMemsetAsync(mask header) failed");
         hipLaunchKernelGGL(k_build_masks, dim3((unsigned)L.ML.n_rows), dim3(512), 0, L.stream, L.g, opt->sigma_thresh, mode,
-                           fw, fl, cw, cl, fy, fz, use_live ? 1 : 0, nzg, hdr, live_rows);
+                           fw, fl, cw, cl, fy, fz, use_live ? 1 : 0, nzg, hdr, live_rows, zero_ptr, zero_n);
         hipLaunchKernelGGL(k_mask_seal, dim3(1), dim3(1), 0, L.stream, hdr, epoch);
         mask_cache_store(workspace, epoch, grid, &hdr->n_live, L.stream);
     } else {
         hipLaunchKernelGGL(k_build_masks, dim3((unsigned)L.ML.n_rows), dim3(512), 0, L.stream, L.g, opt->sigma_thresh, mode,
                            fw, fl, cw, cl, L.sweep ? fy : nullptr, L.sweep ? fz : nullptr, use_live ? 1 : 0, nzg,
-                           static_cast<MaskHdr*>(nullptr), static_cast<int*>(nullptr));
+                           static_cast<MaskHdr*>(nullptr), static_cast<int*>(nullptr), zero_ptr, zero_n);
     }
     prof_after(cached == 1 ? "k_build_masks_live" : "k_build_masks", 0, L.stream);
     return launch_error("k_build_masks");
@@ -507,8 +510,7 @@ int find_candidates(const Launch& L, const asurf_rays* rays, bool record, PipeBu
         P.list = reinterpret_cast<unsigned*>(L.ws + L.ML.off_p_list);
         P.list_cap = L.ML.list_cap;
         P.band_rays = L.ML.band_rays;
-        if (hipMemsetAsync(P.counters, 0, kCtrTotal * sizeof(int), L.stream) != hipSuccess)
-            return fail(ASURF_E_LAUNCH, "hipMemsetAsync failed");
+        // (P.counters: zeroed by the occupancy pass of this call, prepare())
         const int seg = walk_segments(Q);
         if (L.sweep) {
             int nbmax = 1;
