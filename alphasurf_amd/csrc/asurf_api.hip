@@ -342,7 +342,8 @@ unsigned long long g_mask_cache_clock = 0;
 // 1: the workspace holds the list for this epoch (live_blocks = blocks to launch); 0: it does not;
 // -1: epoch 0 (whatever the table says about this workspace is dropped: its planes are about to be rewritten in full,
 // which keeps the list true, but nothing promises `links` is what it was)
-int mask_cache_lookup(void* ws, unsigned long long epoch, const asurf_grid* grid, int n_rows, int* live_blocks) {
+int mask_cache_lookup(void* ws, unsigned long long epoch, const asurf_grid* grid, int n_rows, int* live_blocks,
+                      hipStream_t stream) {
     std::lock_guard<std::mutex> lock(g_mask_cache_mu);
     for (MaskCacheEntry& e : g_mask_cache) {
         if (e.ws != ws) continue;
@@ -353,7 +354,9 @@ int mask_cache_lookup(void* ws, unsigned long long epoch, const asurf_grid* grid
         if (e.epoch != epoch || e.links != grid->links || e.size[0] != grid->size[0] || e.size[1] != grid->size[1] ||
             e.size[2] != grid->size[2])
             return 0;
-        if (e.pending && hipEventQuery(e.ev) == hipSuccess) {
+        hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+        const bool capturing = hipStreamIsCapturing(stream, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone;
+        if (e.pending && !capturing && hipEventQuery(e.ev) == hipSuccess) {  // (no query while a graph is being captured)
             e.pending = false;
             e.count = *e.h_count;
         }
@@ -441,7 +444,12 @@ int prepare(const asurf_grid* grid, const asurf_rays* rays, const asurf_render_o
     int* zero_ptr = (!masks_only && rays->n_rays > 0) ? reinterpret_cast<int*>(L.ws + L.ML.off_p_counters) : nullptr;
     const int zero_n = zero_ptr ? kCtrTotal : 0;
     int live_blocks = 0;
-    const int cached = mask_cache_lookup(workspace, epoch, grid, L.ML.n_rows, &live_blocks);
+    int cached = mask_cache_lookup(workspace, epoch, grid, L.ML.n_rows, &live_blocks, L.stream);
+    {   // building the list allocates pinned memory and reads a counter back: not while a graph is being captured
+        hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+        if (cached == 0 && hipStreamIsCapturing(L.stream, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone)
+            cached = -1;
+    }
     if (cached == 1) {
         hipLaunchKernelGGL(k_build_masks_live, dim3((unsigned)live_blocks), dim3(512), 0, L.stream, L.g, opt->sigma_thresh,
                            mode, fw, fl, cw, cl, L.sweep ? fy : nullptr, L.sweep ? fz : nullptr, use_live ? 1 : 0, nzg, hdr,

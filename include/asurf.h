@@ -85,8 +85,9 @@ typedef struct asurf_grid {
      * any vertex -- the rest of the link volume is empty space it need not read again.  A training loop changes
      * densities and surfaces in every iteration and `links` only when it prunes or up-samples: pass a counter
      * bumped there, mixed with one bumped whenever the workspace is reallocated.  (No reference counterpart: the
-     * reference walks `links` in every kernel.)  The first call with a new value runs the full pass, reads one
-     * counter back asynchronously and is not graph-capturable. */
+     * reference walks `links` in every kernel.)  The first call with a new value runs the full pass and reads one
+     * counter back asynchronously; on a stream that is being captured into a graph a new value is not learnt (the
+     * full pass runs, as with 0). */
     uint64_t links_epoch;
 } asurf_grid;
 
