@@ -62,7 +62,11 @@ struct KOpt {
     int limited_fake_sample, no_surf_grad_from_sh, alpha_activation_type, fake_sample_l_dist,
         fake_sample_normalize_surf, only_outward_intersect, truncated_vol_render;
     float trunc_vol_weight_min;
-    int debug;  // ASURF_DEBUG env var; 0 in production (bit 0: traversal only, results invalid)
+    // ASURF_DEBUG env var; 0 in production.  1, 2, 4: measurement aids of the one-kernel path (traversal only / no
+    // level sets / no candidates: results invalid); 8: per-voxel walk without brick jumps, k_walk instead of k_sweep
+    // (the tests' reference); 16: the pipeline's counters are printed after the call; 32: k_geom without its no-root
+    // filter (variants/geom_filter_check.py); 256 * n: k_sweep leaves after phase n - 1 (phase timing, results invalid)
+    int debug;
 };
 
 struct KGrads {

@@ -69,6 +69,20 @@ struct SweepRay {  // 144 bytes
 static_assert(kPipeC1 <= 64, "phase 4 holds one table slot per lane of a wave");
 __device__ __forceinline__ int sweep_clampi(int v, int lo, int hi) { return min(max(v, lo), hi); }
 
+// diagnostics (phase timing): ASURF_DEBUG = 256 * n makes the blocks leave after phase n - 1, their rays marked empty
+__device__ __forceinline__ bool sweep_debug_leaves(const KOpt& o, int n, int rpb, long long q0, long long Q,
+                                                   const PipeBuf& P) {
+    if (((o.debug >> 8) & 7) != n) return false;
+    const long long q = q0 + threadIdx.x;
+    if ((int)threadIdx.x < rpb && q < Q) {
+        P.n_items[q] = 0;
+        P.cut[q] = 0x7fffffff;
+        P.sp_base[q] = 0;
+        P.cand_mask[q] = 0ull;
+    }
+    return true;
+}
+
 // LDS is what limits the number of resident blocks (every phase waits on memory or on a barrier, so the
 // kernel's speed is the number of blocks a CU interleaves): everything sized per launch, the coarse plane is
 // read from global memory (4 KB at 256^3: it lives in L1).
@@ -177,10 +191,7 @@ k_sweep(KGrid g, KOpt o, const float* __restrict__ origins, const float* __restr
         s_cnt[tid] = 0;
     }
     __syncthreads();
-    if (((o.debug >> 8) & 7) == 1) {  // diagnostics: ASURF_DEBUG = 256 * n leaves after phase n - 1 (phase timing; nothing is found)
-        if (tid < rpb && q0 + tid < Q) { P.n_items[q0 + tid] = 0; P.cut[q0 + tid] = 0x7fffffff; P.sp_base[q0 + tid] = 0; P.cand_mask[q0 + tid] = 0ull; }
-        return;
-    }
+    if (sweep_debug_leaves(o, 1, rpb, q0, Q, P)) return;
 
     // Phases 1 and 2 run once over all rays of the block; if the task list would not hold them (scenes where
     // most bricks hold a flagged voxel) they run again in four passes over a quarter of the rays each (one ray a pass
@@ -236,10 +247,7 @@ k_sweep(KGrid g, KOpt o, const float* __restrict__ origins, const float* __restr
         continue;
     }
 
-    if (((o.debug >> 8) & 7) == 2) {  // diagnostics: ASURF_DEBUG = 256 * n leaves after phase n - 1 (phase timing; nothing is found)
-        if (tid < rpb && q0 + tid < Q) { P.n_items[q0 + tid] = 0; P.cut[q0 + tid] = 0x7fffffff; P.sp_base[q0 + tid] = 0; P.cand_mask[q0 + tid] = 0ull; }
-        return;
-    }
+    if (sweep_debug_leaves(o, 2, rpb, q0, Q, P)) return;
     // ---- phase 2: lane = task.  The brick's 8 words (one 64-byte line); the ray's (b, c) position at the 9 slab
     // planes, each shared by two slabs; per slab the rectangle mask of the cells between two planes ----
     const int ntask = min(s_ntask, task_cap);
@@ -300,10 +308,7 @@ k_sweep(KGrid g, KOpt o, const float* __restrict__ origins, const float* __restr
     }
     }  // passes
 
-    if (((o.debug >> 8) & 7) == 3) {  // diagnostics: ASURF_DEBUG = 256 * n leaves after phase n - 1 (phase timing; nothing is found)
-        if (tid < rpb && q0 + tid < Q) { P.n_items[q0 + tid] = 0; P.cut[q0 + tid] = 0x7fffffff; P.sp_base[q0 + tid] = 0; P.cand_mask[q0 + tid] = 0ull; }
-        return;
-    }
+    if (sweep_debug_leaves(o, 3, rpb, q0, Q, P)) return;
     // ---- phase 3: exact membership, lane = entry.  s_eend: inclusive prefix of the rays' FOUND counts ----
     if (tid < 64) {
         const int found = (tid < rpb) ? min(s_cnt[tid], K) : 0;
@@ -366,10 +371,7 @@ k_sweep(KGrid g, KOpt o, const float* __restrict__ origins, const float* __restr
     }
     __syncthreads();
 
-    if (((o.debug >> 8) & 7) == 4) {  // diagnostics: ASURF_DEBUG = 256 * n leaves after phase n - 1 (phase timing; nothing is found)
-        if (tid < rpb && q0 + tid < Q) { P.n_items[q0 + tid] = 0; P.cut[q0 + tid] = 0x7fffffff; P.sp_base[q0 + tid] = 0; P.cand_mask[q0 + tid] = 0ull; }
-        return;
-    }
+    if (sweep_debug_leaves(o, 4, rpb, q0, Q, P)) return;
     // ---- phase 4: per ray, counts and allocations ----
     if (tid < rpb) {
         const long long q = q0 + tid;
@@ -420,10 +422,7 @@ k_sweep(KGrid g, KOpt o, const float* __restrict__ origins, const float* __restr
     }
     __syncthreads();
 
-    if (((o.debug >> 8) & 7) == 5) {  // diagnostics: ASURF_DEBUG = 256 * n leaves after phase n - 1 (phase timing; nothing is found)
-        if (tid < rpb && q0 + tid < Q) { P.n_items[q0 + tid] = 0; P.cut[q0 + tid] = 0x7fffffff; P.sp_base[q0 + tid] = 0; P.cand_mask[q0 + tid] = 0ull; }
-        return;
-    }
+    if (sweep_debug_leaves(o, 5, rpb, q0, Q, P)) return;
     // ---- phase 5: per surviving entry, its rank among the ray's keys is its slot ----
     for (int t = tid; t < n_found; t += nthreads) {
         int rl = 0;
