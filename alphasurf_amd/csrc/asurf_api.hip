@@ -53,7 +53,7 @@ struct MaskLayout {
     size_t off_p_items, off_p_citem, off_p_nitems, off_p_cut, off_p_flagged, off_p_counters, off_p_pool;
     size_t off_p_cand;  // cand_mask [Q]
     size_t off_p_spbase, off_p_spill, off_p_list, off_rec_list;
-    int pool_shard_cap, sp_cap, list_cap, band_rays;
+    int pool_shard_cap, sp_cap, list_cap, band_rays, rec_list_cap;
     size_t total;
 };
 
@@ -153,8 +153,10 @@ MaskLayout layout_for(const int32_t size[3], int64_t n_rays, int32_t M) {
     while (L.band_rays > kBandRaysMin && (long long)L.band_rays * 64 > nr) L.band_rays >>= 1;
     L.list_cap = kPipeC1 * (int)(((nr + kListGroups - 1) / kListGroups + L.band_rays) / kListShards + 256);
     off = align_up(off + (size_t)L.list_cap * kListSegs * 4, 256);
-    L.off_rec_list = off;    // dense list of visited records (k_bwd_seq -> k_bwd_geo)
-    off = align_up(off + rplane, 256);
+    L.off_rec_list = off;    // dense list of visited records (k_bwd_seq -> k_bwd_sh, k_bwd_geo), kRecShards segments:
+                             // block b of k_bwd_seq (256 rays, kRecDepth records each at most) fills segment b % 8
+    L.rec_list_cap = (int)(((nr + kBlock - 1) / kBlock + kRecShards - 1) / kRecShards) * kBlock * kRecDepth;
+    off = align_up(off + (size_t)L.rec_list_cap * kRecShards * 4, 256);
     L.off_p_counters = off;  // n_flagged, spill cursor, kPoolShards pool cursors, 2 list lengths
     off = align_up(off + kCtrTotal * 4, 256);
     L.pool_shard_cap = (int)((8 * nr + kPoolShards - 1) / kPoolShards) + 256;  // (a wave of k_geom may ask for 3 x 64 at once)
@@ -679,14 +681,16 @@ int run_backward(const Launch& L, const asurf_rays* rays, const KLoss& loss, con
         S.gy = f + 15 * plane;
         S.gz = f + 16 * plane;
         S.list = reinterpret_cast<unsigned*>(L.ws + L.ML.off_rec_list);
-        S.n_list = reinterpret_cast<int*>(L.ws + L.ML.off_p_counters) + kCtrList + 1;
+        S.n_list = reinterpret_cast<int*>(L.ws + L.ML.off_p_counters) + kCtrRecShard0;
+        S.list_cap = L.ML.rec_list_cap;
         S.n_eff = reinterpret_cast<int*>(L.ws + L.ML.off_rec_neff);
         S.sws = reinterpret_cast<float*>(L.ws + L.ML.off_rec_sws);
         S.R = kRecDepth;
         const long long Q = rays->n_rays;
         // (the list's cursor lies among the pipeline's counters: the forward of this call has zeroed it if it ran the
         // pipeline -- a memset node of its own is 4 us on the stream)
-        if (!counters_zeroed && hipMemsetAsync(S.n_list, 0, sizeof(int), L.stream) != hipSuccess)
+        if (!counters_zeroed &&
+            hipMemsetAsync(S.n_list, 0, kRecShards * kCtrShardStride * sizeof(int), L.stream) != hipSuccess)
             return fail(ASURF_E_LAUNCH, "hipMemsetAsync failed");
         hipLaunchKernelGGL(k_bwd_seq, L.ray_grid, dim3(kBlock), 0, L.stream, L.o, loss, L.g.trunc_a, Q,
                            grad_in, color_cache, M, ca, cw, ct, cn, S);

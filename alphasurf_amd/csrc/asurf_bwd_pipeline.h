@@ -50,11 +50,35 @@ struct SampleRec {  // planes [R][Q]
     float* gy;
     float* gz;
     int* n;      // [Q] records of the ray (< 0: overflowed, ray belongs to the walking kernel)
-    unsigned* list;  // dense list of visited (record, ray) cells: record << 27 | ray (k_bwd_seq)
-    int* n_list;     // its length
+    unsigned* list;  // dense list of visited (record, ray) cells: record << 27 | ray (k_bwd_seq); kRecShards segments
+    int* n_list;     // their cursors, kCtrShardStride ints apart
+    int list_cap;    // cells per segment
     int* n_eff;  // [Q] records the backward actually visits (stop_thresh)
     float* sws;  // [Q] clamped sum of the cached weights (sparsity term)
     int R;
+};
+
+// The list as the consumers see it: the segments' running sums turn a position in their concatenation into a cell.
+struct RecList {
+    int seg_end[kRecShards];
+    int n;
+    __device__ __forceinline__ void init(const SampleRec& S) {
+        n = 0;
+#pragma unroll
+        for (int sh = 0; sh < kRecShards; ++sh) {
+            n += min(S.n_list[sh * kCtrShardStride], S.list_cap);
+            seg_end[sh] = n;
+        }
+    }
+    __device__ __forceinline__ unsigned cell(const SampleRec& S, int i) const {  // i < n
+        int sh = 0;
+#pragma unroll
+        for (int k = 0; k < kRecShards - 1; ++k) sh += (i >= seg_end[k]) ? 1 : 0;
+        int seg0 = 0;
+#pragma unroll
+        for (int k = 0; k < kRecShards - 1; ++k) seg0 = (sh == k + 1) ? seg_end[k] : seg0;
+        return S.list[(size_t)sh * S.list_cap + (i - seg0)];
+    }
 };
 
 // ------------------------------------------------------------------------------------
@@ -250,7 +274,8 @@ k_bwd_seq(KOpt o, KLoss L, float trunc_a, long long Q, const float* __restrict__
             s_tot[w] = sum;
             sum += t;
         }
-        s_tot[kBlock / 64] = sum > 0 ? atomicAdd(S.n_list, sum) : 0;
+        const int shard = (int)(blockIdx.x % kRecShards);
+        s_tot[kBlock / 64] = shard * S.list_cap + (sum > 0 ? atomicAdd(&S.n_list[shard * kCtrShardStride], sum) : 0);
     }
     __syncthreads();
     if (wave_total > 0) {
@@ -278,7 +303,9 @@ k_bwd_sh(KGrid g, KGrads G, int want_dpos, const float* __restrict__ dirs, long 
     __shared__ float s_carry[(kBlock / 64) * 8 * C::D];  // per wave: the run's sums while they change corner slots
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    const int n_list = *S.n_list;
+    RecList RL;
+    RL.init(S);
+    const int n_list = RL.n;
     const int wave_id = blockIdx.x * (kBlock / 64) + (tid >> 6);
     const int wbase = tid & ~63;
     const float* sph_wave = s_sph + wbase * SP;
@@ -297,7 +324,7 @@ k_bwd_sh(KGrid g, KGrads G, int want_dpos, const float* __restrict__ dirs, long 
   const int chunk = n_list >= (1 << 18) ? 64 : n_list >= (1 << 17) ? 32 : n_list >= (1 << 16) ? 16 : 8;
   for (int base = wave_id * chunk; base < n_list; base += (int)gridDim.x * (kBlock / 64) * chunk) {
     const bool mine = lane < chunk && base + lane < n_list;
-    const unsigned cell = mine ? S.list[base + lane] : 0u;
+    const unsigned cell = mine ? RL.cell(S, base + lane) : 0u;
     const long long q = (long long)(cell & ((1u << kListRayBits) - 1u));
     const int r = (int)(cell >> kListRayBits);
     const unsigned long long need0 = __ballot(mine);
@@ -458,7 +485,9 @@ k_bwd_geo(KGrid g, KOpt o, KLoss L, KGrads G, const float* __restrict__ origins,
     const TlScope tl(7);
   __shared__ float s_head_d[kBlock / 64][64][9], s_head_s[kBlock / 64][64][9];  // per wave: the heads' rows (see the scatter)
   __shared__ int s_head_l[kBlock / 64][64][9];
-  const int n_list = *S.n_list;
+  RecList RL;
+  RL.init(S);
+  const int n_list = RL.n;
   const int lane = threadIdx.x & 63;
   const int wave_id = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
   for (int base = wave_id * 64; base < n_list; base += (int)gridDim.x * kBlock) {
@@ -470,7 +499,7 @@ k_bwd_geo(KGrid g, KOpt o, KLoss L, KGrads G, const float* __restrict__ origins,
     int key = -1 - lane;  // lanes without a sample never join a run
     float gstd_acc = 0.f;
     if (mine) {
-    const unsigned cell = S.list[i];
+    const unsigned cell = RL.cell(S, i);
     const long long q = (long long)(cell & ((1u << kListRayBits) - 1u));
     const int r_i = (int)(cell >> kListRayBits);
     const size_t idx = (size_t)r_i * Q + q;

@@ -74,7 +74,11 @@ constexpr int kCtrListShard0 = kCtrList + 2;
 constexpr int kListGroups = ASURF_LIST_GROUPS;
 constexpr int kListSegs = kListGroups * kListShards;
 constexpr int kBandRaysMax = 8192, kBandRaysMin = 256;  // powers of two; every producer block lies within a band
-constexpr int kCtrTotal = kCtrListShard0 + kListSegs * kCtrShardStride;
+// the backward's list of visited sample records (asurf_bwd_pipeline.h) is cut likewise: k_bwd_seq block b appends to
+// segment b % kRecShards (2500 blocks adding to one cursor were 12 of that kernel's 42 us)
+constexpr int kRecShards = 8;
+constexpr int kCtrRecShard0 = kCtrListShard0 + kListSegs * kCtrShardStride;
+constexpr int kCtrTotal = kCtrRecShard0 + kRecShards * kCtrShardStride;
 constexpr int kListRayBits = 27;  // rays per call < 2^27 for the list-driven kernels
 // The kernels that work through a dense list are launched with a fixed number of blocks and
 // stride over it: the list length is only known on the device, and tens of thousands of
@@ -92,7 +96,7 @@ struct PipeBuf {
     int* sp_ray;     // [sp_cap] owning ray
     int* flagged;    // [Q] compacted ids of the rays handed back
     int* counters;   // [0] n_flagged, [1] spill cursor, [2 .. 2+kPoolShards) pool cursors,
-                     // [kCtrList] entries in `list`, [kCtrList + 1] entries in the backward's list
+                     // kListSegs cursors of `list`, kRecShards cursors of the backward's list (asurf_bwd_pipeline.h)
     unsigned* list;  // dense list of the occupied (slot, ray) cells of `items`: slot << 27 | ray; kListShards
                      // segments of list_cap cells
     int list_cap;
