@@ -76,7 +76,10 @@ constexpr int kListSegs = kListGroups * kListShards;
 constexpr int kBandRaysMax = 8192, kBandRaysMin = 256;  // powers of two; every producer block lies within a band
 // the backward's list of visited sample records (asurf_bwd_pipeline.h) is cut likewise: k_bwd_seq block b appends to
 // segment b % kRecShards (2500 blocks adding to one cursor were 12 of that kernel's 42 us)
-constexpr int kRecShards = 8;
+#ifndef ASURF_REC_SHARDS
+#define ASURF_REC_SHARDS 8
+#endif
+constexpr int kRecShards = ASURF_REC_SHARDS;
 constexpr int kCtrRecShard0 = kCtrListShard0 + kListSegs * kCtrShardStride;
 constexpr int kCtrTotal = kCtrRecShard0 + kRecShards * kCtrShardStride;
 constexpr int kListRayBits = 27;  // rays per call < 2^27 for the list-driven kernels
