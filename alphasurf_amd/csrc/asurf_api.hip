@@ -442,7 +442,8 @@ int prepare(const asurf_grid* grid, const asurf_rays* rays, const asurf_render_o
     const int mode = cuvol ? 2 : (need_surf ? 1 : 0);  // 2: cuvol cells (asurf_cuvol.h)
     // links_epoch (include/asurf.h): the rows of bricks that are not empty space are remembered in the workspace
     const unsigned long long epoch = cuvol ? 0ull : (unsigned long long)grid->links_epoch;
-    // the pipeline's counters (when the layout has them) are zeroed by block 0 of the pass
+    // the pipeline's counters (when the layout has them): zeroed by block 0 of the pass over the live rows, by a memset
+    // in front of the full pass
     int* zero_ptr = (!masks_only && rays->n_rays > 0) ? reinterpret_cast<int*>(L.ws + L.ML.off_p_counters) : nullptr;
     const int zero_n = zero_ptr ? kCtrTotal : 0;
     int live_blocks = 0;
@@ -452,6 +453,8 @@ int prepare(const asurf_grid* grid, const asurf_rays* rays, const asurf_render_o
         if (cached == 0 && hipStreamIsCapturing(L.stream, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone)
             cached = -1;
     }
+    if (cached != 1 && zero_ptr && hipMemsetAsync(zero_ptr, 0, (size_t)zero_n * sizeof(int), L.stream) != hipSuccess)
+        return fail(ASURF_E_LAUNCH, "hipMemsetAsync(pipeline counters) failed");
     if (cached == 1) {
         hipLaunchKernelGGL(k_build_masks_live, dim3((unsigned)live_blocks), dim3(512), 0, L.stream, L.g, opt->sigma_thresh,
                            mode, fw, fl, cw, cl, L.sweep ? fy : nullptr, L.sweep ? fz : nullptr, use_live ? 1 : 0, nzg, hdr,
@@ -461,13 +464,13 @@ int prepare(const asurf_grid* grid, const asurf_rays* rays, const asurf_render_o
         if (hipMemsetAsync(hdr, 0, sizeof(MaskHdr), L.stream) != hipSuccess)
             return fail(ASURF_E_LAUNCH, "hipMemsetAsync(mask header) failed");
         hipLaunchKernelGGL(k_build_masks, dim3((unsigned)L.ML.n_rows), dim3(512), 0, L.stream, L.g, opt->sigma_thresh, mode,
-                           fw, fl, cw, cl, fy, fz, use_live ? 1 : 0, nzg, hdr, live_rows, zero_ptr, zero_n);
+                           fw, fl, cw, cl, fy, fz, use_live ? 1 : 0, nzg, hdr, live_rows);
         hipLaunchKernelGGL(k_mask_seal, dim3(1), dim3(1), 0, L.stream, hdr, epoch);
         mask_cache_store(workspace, epoch, grid, &hdr->n_live, L.stream);
     } else {
         hipLaunchKernelGGL(k_build_masks, dim3((unsigned)L.ML.n_rows), dim3(512), 0, L.stream, L.g, opt->sigma_thresh, mode,
                            fw, fl, cw, cl, L.sweep ? fy : nullptr, L.sweep ? fz : nullptr, use_live ? 1 : 0, nzg,
-                           static_cast<MaskHdr*>(nullptr), static_cast<int*>(nullptr), zero_ptr, zero_n);
+                           static_cast<MaskHdr*>(nullptr), static_cast<int*>(nullptr));
     }
     prof_after(cached == 1 ? "k_build_masks_live" : "k_build_masks", 0, L.stream);
     return launch_error("k_build_masks");
@@ -520,7 +523,7 @@ int find_candidates(const Launch& L, const asurf_rays* rays, bool record, PipeBu
         P.list = reinterpret_cast<unsigned*>(L.ws + L.ML.off_p_list);
         P.list_cap = L.ML.list_cap;
         P.band_rays = L.ML.band_rays;
-        // (P.counters: zeroed by the occupancy pass of this call, prepare())
+        // (P.counters: zeroed in prepare(), with the occupancy pass of this call)
         const int seg = walk_segments(Q);
         if (L.sweep) {
             int nbmax = 1;

@@ -198,12 +198,9 @@ __global__ void __launch_bounds__(512)
 k_build_masks(KGrid g, float sigma_thresh, int need_surf, unsigned long long* fine_work,
               unsigned long long* fine_live, unsigned int* coarse_work,
               unsigned int* coarse_live, unsigned long long* fine_y, unsigned long long* fine_z,
-              int orient_live, int nzg, MaskHdr* hdr, int* live_rows, int* zero_ptr, int zero_n) {
+              int orient_live, int nzg, MaskHdr* hdr, int* live_rows) {
     const TlScope tl(1);
     __shared__ MaskTables S;
-    // (the pipeline's counters, zeroed here for the kernels that follow: a memset node of their own is 4 us)
-    if (blockIdx.x == 0)
-        for (int i = threadIdx.x; i < zero_n; i += blockDim.x) zero_ptr[i] = 0;
     if (threadIdx.x == 0) S.alive = 0;
     const bool alive = build_masks_row(g, sigma_thresh, need_surf, fine_work, fine_live, coarse_work, coarse_live, fine_y,
                                        fine_z, orient_live, nzg, blockIdx.x, S);
@@ -231,6 +228,8 @@ k_build_masks_live(KGrid g, float sigma_thresh, int need_surf, unsigned long lon
                    int zero_n) {
     const TlScope tl(1);
     __shared__ MaskTables S;
+    // (the pipeline's counters, zeroed here for the kernels that follow: a memset node of their own is 4 us.  Not in
+    // k_build_masks: the same five stores in its block 0 cost that kernel 9 us -- 0.067 -> 0.076 ms, measured both ways)
     if (blockIdx.x == 0)
         for (int i = threadIdx.x; i < zero_n; i += blockDim.x) zero_ptr[i] = 0;
     if (hdr->magic != kMaskMagic || hdr->epoch != epoch) return;  // not the buffer the caller promised: nothing is read

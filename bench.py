@@ -37,8 +37,10 @@ def parse():
     ap.add_argument("--sort", action="store_true",
                     help="order the batch for coherence inside the timed step (asurf_ray_order), scatter rgb back")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-links-epoch", action="store_true",
-                    help="every step reads the whole link volume again (no links_epoch promise)")
+    ap.add_argument("--links-epoch", action="store_true",
+                    help="tell the renders that `links` is the same from step to step, as it is in the training loop "
+                         "(asurf_grid::links_epoch): the occupancy pass then reads the non-empty brick rows only.  Off by "
+                         "default: every timed step does all of its work from the inputs alone")
     ap.add_argument("--graph", action="store_true",
                     help="capture one step in a HIP graph after the warm-up and replay it in the timed region")
     ap.add_argument("--cpu-rays", type=int, default=40000)
@@ -147,9 +149,10 @@ def main():
     g._scaling = torch.from_numpy(sc["scaling"])
     g.basis_dim, g.basis_type, g.surface_type = B, 1, 102
     g.fake_sample_std, g.truncated_vol_render_a = sc["fake_sample_std"], sc["truncated_vol_render_a"]
-    # as in the training loop, `links` stays what it is from step to step (densities, surfaces and SH do not): the
-    # renders are told so and keep their list of non-empty brick rows (asurf_grid::links_epoch, include/asurf.h)
-    g.links_epoch = 0 if args.no_links_epoch else 1
+    # --links-epoch: as in the training loop, `links` stays what it is from step to step (densities, surfaces and SH
+    # do not): the renders are told so and keep their list of non-empty brick rows (asurf_grid::links_epoch,
+    # include/asurf.h).  The default measures a step that owes nothing to the step before it.
+    g.links_epoch = 1 if args.links_epoch else 0
     r = _C.RaysSpec()
     r.origins, r.dirs = torch.from_numpy(o_np).to(dev), torch.from_numpy(d_np).to(dev)
     r.masks = torch.ones(Q, dtype=torch.bool, device=dev)
@@ -345,7 +348,7 @@ def main():
                                    f"({'shuffled' if args.shuffle else 'image-order'} rays"
                                    f"{', ordered per step' if args.sort else ''}), "
                                    "volume_render_surf_trav_fused fwd+bwd, surface_cuda_syn.yaml options"
-                                   + ("" if args.no_links_epoch else "; links unchanged from step to step (links_epoch)"),
+                                   + ("; links unchanged from step to step (links_epoch)" if args.links_epoch else ""),
                        "rays_per_step_per_gpu": Q, "active_voxels": int(g.density_data.shape[0]),
                        "avg_per_ray": {"V_t": round(v_t / Q, 2), "V_a": round(v_a / Q, 2), "S": round(s_cnt / Q, 3)},
                        "parallelism": f"ray-sharded dp{world}, {args.exchange} RCCL exchange of grads" if world > 1 else "single GPU"},
