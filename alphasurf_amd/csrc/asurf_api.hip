@@ -487,6 +487,22 @@ unsigned list_blocks(long long n_rays, int per_ray) {
     return (unsigned)std::min<long long>((std::max<long long>(want, 64) + 7) & ~7ll, kListBlocks);  // (k_geom: 8 groups)
 }
 
+// Rays a wave of the ray-per-lane kernels of the pipeline takes (k_comp, k_bwd_seq): 64 when the batch fills the chip
+// several times over, fewer below -- a wave works its rays' samples off in turns, and with few waves the kernel is as
+// slow as one of them.  ASURF_RPW = 4 ... 64 overrides (measurement).
+int rays_per_wave(long long n_rays) {
+    if (const char* e = getenv("ASURF_RPW")) {
+        const int n = atoi(e);
+        if (n == 4 || n == 8 || n == 16 || n == 32 || n == 64) return n;
+    }
+    // fused step, shuffled rays of the bench scene, 64 / 32 / 16 / 8 rays a wave: 5 k rays 0.176 / 0.165 / 0.160 / 0.159 ms,
+    // 40 k 0.259 / 0.251 / 0.247 / 0.249, 160 k 0.541 / 0.541 / 0.557
+    if (n_rays <= 8192) return 8;
+    if (n_rays <= 65536) return 16;
+    if (n_rays <= 262144) return 32;
+    return 64;
+}
+
 // The three-kernel forward is used unless the call needs what only the one-kernel path keeps:
 // exact V_t/V_a/S counters (a ray stopped by stop_thresh must not be walked further),
 // stop_thresh > 1 (the reference then stops at the first voxel that passes the gates even if
@@ -594,12 +610,14 @@ int run_forward(const Launch& L, const asurf_rays* rays, float* rgb_out, int M, 
     if (pipeline) {
         PipeBuf P;
         if (int e = find_candidates(L, rays, record, P)) return e;
+        const int rpw = rays_per_wave(Q);
+        const dim3 comp_grid((unsigned)((Q + (kBlock / 64) * rpw - 1) / ((kBlock / 64) * rpw)));
         if (cache)
-            hipLaunchKernelGGL((k_comp<B, true>), L.ray_grid, dim3(kBlock), 0, L.stream, L.g, L.o,
-                               rays->dirs, Q, P, rgb_out, M, ca, cw, ct, cn, rv, rm, rn, kRecDepth, rf);
+            hipLaunchKernelGGL((k_comp<B, true>), comp_grid, dim3(kBlock), 0, L.stream, L.g, L.o,
+                               rays->dirs, Q, P, rgb_out, M, ca, cw, ct, cn, rv, rm, rn, kRecDepth, rf, rpw);
         else
-            hipLaunchKernelGGL((k_comp<B, false>), L.ray_grid, dim3(kBlock), 0, L.stream, L.g, L.o,
-                               rays->dirs, Q, P, rgb_out, M, ca, cw, ct, cn, rv, rm, rn, kRecDepth, rf);
+            hipLaunchKernelGGL((k_comp<B, false>), comp_grid, dim3(kBlock), 0, L.stream, L.g, L.o,
+                               rays->dirs, Q, P, rgb_out, M, ca, cw, ct, cn, rv, rm, rn, kRecDepth, rf, rpw);
         prof_after("k_comp", 1, L.stream);
         if (int e = launch_error("forward pipeline")) return e;
         if (L.o.debug & 16) {  // diagnostics: what the pipeline's counters hold after this call
@@ -695,8 +713,9 @@ int run_backward(const Launch& L, const asurf_rays* rays, const KLoss& loss, con
         if (!counters_zeroed &&
             hipMemsetAsync(S.n_list, 0, kRecShards * kCtrShardStride * sizeof(int), L.stream) != hipSuccess)
             return fail(ASURF_E_LAUNCH, "hipMemsetAsync failed");
-        hipLaunchKernelGGL(k_bwd_seq, L.ray_grid, dim3(kBlock), 0, L.stream, L.o, loss, L.g.trunc_a, Q,
-                           grad_in, color_cache, M, ca, cw, ct, cn, S);
+        const int rpw = rays_per_wave(Q);
+        hipLaunchKernelGGL(k_bwd_seq, dim3((unsigned)((Q + (kBlock / 64) * rpw - 1) / ((kBlock / 64) * rpw))), dim3(kBlock), 0,
+                           L.stream, L.o, loss, L.g.trunc_a, Q, grad_in, color_cache, M, ca, cw, ct, cn, S, rpw);
         prof_after("k_bwd_seq", 2, L.stream);
         hipLaunchKernelGGL((k_bwd_sh<B>), dim3(list_blocks(Q, 8)), dim3(kBlock), 0, L.stream, L.g, G,
                            L.o.no_surf_grad_from_sh ? 0 : 1, rays->dirs, Q, S);

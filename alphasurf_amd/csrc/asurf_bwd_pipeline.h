@@ -256,10 +256,11 @@ __global__ void __launch_bounds__(kBlock)
 k_bwd_seq(KOpt o, KLoss L, float trunc_a, long long Q, const float* __restrict__ rgb_gt,
           const float* __restrict__ rgb_out, int M, const float* __restrict__ cache_a,
           const float* __restrict__ cache_w, const float* __restrict__ cache_t,
-          const int* __restrict__ cache_n, SampleRec S) {
-    const long long q = (long long)blockIdx.x * kBlock + threadIdx.x;
+          const int* __restrict__ cache_n, SampleRec S, int rpw) {
+    // (rpw rays a wave, as k_comp)
+    const long long q = ((long long)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6)) * rpw + (threadIdx.x & 63);
     int nt = 0;
-    if (q < Q) nt = bwd_seq_ray(o, L, trunc_a, Q, q, rgb_gt, rgb_out, M, cache_a, cache_w, cache_t, cache_n, S);
+    if ((int)(threadIdx.x & 63) < rpw && q < Q) nt = bwd_seq_ray(o, L, trunc_a, Q, q, rgb_gt, rgb_out, M, cache_a, cache_w, cache_t, cache_n, S);
     // dense list of the (record, ray) cells the backward visits, record-major within the wave
     int wave_total;
     wave_excl_scan(nt, &wave_total);

@@ -680,14 +680,17 @@ __global__ void __launch_bounds__(kBlock, (B <= 9 ? ASURF_COMP_WAVES : 4))
 k_comp(KGrid g, KOpt o, const float* __restrict__ dirs, long long Q, PipeBuf P,
        float* __restrict__ rgb_out, int M, float* __restrict__ cache_a, float* __restrict__ cache_w,
        float* __restrict__ cache_t, int* __restrict__ cache_n, int* __restrict__ rec_v,
-       int* __restrict__ rec_m, int* __restrict__ rec_n, int R, float* __restrict__ rec_f) {
+       int* __restrict__ rec_m, int* __restrict__ rec_n, int R, float* __restrict__ rec_f, int rpw) {
     __shared__ float s_sph[kBlock * kSphPad];
     __shared__ LaneRec s_rec[kBlock];
     const int tid = threadIdx.x;
     const float* sph_wave = s_sph + (tid & ~63) * kSphPad;
     const LaneRec* rec_wave = s_rec + (tid & ~63);
-    const long long q = (long long)blockIdx.x * kBlock + tid;
-    const bool in_range = q < Q;
+    // rpw rays a wave (lanes 0 .. rpw - 1 hold them, all 64 shade): a wave's time is the sum of its rays' shading
+    // turns, and a batch that does not fill the chip is as slow as one wave -- fewer rays a wave then (rays_per_wave,
+    // asurf_api.hip)
+    const long long q = ((long long)blockIdx.x * (kBlock / 64) + (tid >> 6)) * rpw + (tid & 63);
+    const bool in_range = (tid & 63) < rpw && q < Q;
     const int n = in_range ? P.n_items[q] : 0;
     const bool valid = in_range && n >= 0;  // handed-back rays belong to the one-kernel path
     if (valid) {
