@@ -358,9 +358,13 @@ int mask_cache_lookup(void* ws, unsigned long long epoch, const asurf_grid* grid
             return 0;
         hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
         const bool capturing = hipStreamIsCapturing(stream, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone;
-        if (e.pending && !capturing && hipEventQuery(e.ev) == hipSuccess) {  // (no query while a graph is being captured)
-            e.pending = false;
-            e.count = *e.h_count;
+        if (e.pending && !capturing) {  // (no query while a graph is being captured)
+            if (hipEventQuery(e.ev) == hipSuccess) {
+                e.pending = false;
+                e.count = *e.h_count;
+            } else {
+                (void)hipGetLastError();  // "not ready" is no error of this call: keep it out of launch_error()
+            }
         }
         e.used = ++g_mask_cache_clock;
         *live_blocks = (e.pending || e.count < 0) ? n_rows : std::max(1, std::min(e.count, n_rows));

@@ -50,3 +50,19 @@ def test_links_change_is_seen(hip):
     assert np.array_equal(rgb, ref_rgb)
     rgb, _ = H.render_fused(sc, o, d, OPTION_SETS["syn_yaml"], gt, fused, links_epoch=13)
     assert np.array_equal(rgb, ref_rgb)
+
+
+def test_back_to_back_calls_before_the_count_has_arrived(hip):
+    """Calls issued faster than the list's length travels to the host: the pass runs with the long grid meanwhile
+    (and the query that says "not ready" must not surface as an error of the call)."""
+    import torch
+    import hip_util as H
+    from alphasurf_amd import csrc_api as _C
+    sc, o, d = sparse_case(4, level_set=(0.0,))
+    gt = np.random.RandomState(4).rand(o.shape[0], 3).astype(np.float32)
+    ref_rgb, _ = H.render_fused(sc, o, d, OPTION_SETS["syn_yaml"], gt, dict(lambda_l2=1.0))
+    g, r, op = H.grid_spec(sc, links_epoch=21), H.rays_spec(o, d), H.opt_spec(OPTION_SETS["syn_yaml"])
+    outs = [_C.volume_render_surf_trav(g, r, op) for _ in range(6)]  # no synchronisation in between
+    torch.cuda.synchronize()
+    for rgb in outs:
+        assert np.array_equal(rgb.cpu().numpy(), ref_rgb)
