@@ -40,6 +40,63 @@ int fail(int code, const char* fmt, ...) {
 
 using namespace asurf;
 
+// --- internal switches ---------------------------------------------------------------------------------------------
+// Every switch selects between internal forms that compute the SAME results (the tests compare them with each other);
+// none is read on the call path.  The ASURF_* environment variables are read once, when the first entry point runs;
+// after that only asurf_config_set() (include/asurf.h) changes a switch.  The measurement aids that make results
+// invalid (ASURF_DEBUG bits 1, 2, 4 and 256 * n) exist in the instrumented build only (`make timeline`,
+// -DASURF_INSTRUMENT): the shipped library masks them off here and compiles their code out (asurf_device.h).
+struct Config {
+    int debug = 0;         // ASURF_DEBUG: 8 per-voxel walk (k_walk, no brick jumps), 16 print the pipeline's counters,
+                           // 32 k_geom without its no-root filter
+    int walk_seg = 0;      // ASURF_WALK_SEG = 1, 2, 4, 8: lanes per ray of the stepping walk (0: by batch size)
+    int walk_step = 0;     // ASURF_WALK=step: the stepping walk instead of k_sweep
+    int rpw = 0;           // ASURF_RPW = 4 .. 64: rays per wave of k_comp / k_bwd_seq (0: by batch size)
+    int no_pipeline = 0;   // ASURF_NO_PIPELINE: the one-kernel forward
+    int cuvol_rpw = 0;     // ASURF_CUVOL_RPW = 1 .. 64
+    int no_replay = 0;     // ASURF_NO_REPLAY: the walking backward
+    int no_split_bwd = 0;  // ASURF_NO_SPLIT_BWD: the one-kernel replay
+    int eval_walk = 0;     // ASURF_EVAL=walk: the stepping evaluation renders
+    int timeline = 0;      // ASURF_TIMELINE = kernel id (instrumented build)
+};
+#ifdef ASURF_INSTRUMENT
+constexpr int kDebugMask = 1 | 2 | 4 | 8 | 16 | 32 | (7 << 8);
+#else
+constexpr int kDebugMask = 8 | 16 | 32;
+#endif
+std::mutex g_cfg_mu;
+Config g_cfg;
+std::once_flag g_cfg_once;
+
+bool config_assign(Config& c, const char* name, const char* value) {
+    const int n = value ? atoi(value) : 0;
+    if (!strcmp(name, "ASURF_DEBUG")) c.debug = n & kDebugMask;
+    else if (!strcmp(name, "ASURF_WALK_SEG")) c.walk_seg = (n == 1 || n == 2 || n == 4 || n == 8) ? n : 0;
+    else if (!strcmp(name, "ASURF_WALK")) c.walk_step = (value && !strcmp(value, "step")) ? 1 : 0;
+    else if (!strcmp(name, "ASURF_RPW")) c.rpw = (n == 4 || n == 8 || n == 16 || n == 32 || n == 64) ? n : 0;
+    else if (!strcmp(name, "ASURF_NO_PIPELINE")) c.no_pipeline = n ? 1 : 0;
+    else if (!strcmp(name, "ASURF_CUVOL_RPW")) c.cuvol_rpw = (n >= 1 && n <= 64 && (n & (n - 1)) == 0) ? n : 0;
+    else if (!strcmp(name, "ASURF_NO_REPLAY")) c.no_replay = n ? 1 : 0;
+    else if (!strcmp(name, "ASURF_NO_SPLIT_BWD")) c.no_split_bwd = n ? 1 : 0;
+    else if (!strcmp(name, "ASURF_EVAL")) c.eval_walk = (value && !strcmp(value, "walk")) ? 1 : 0;
+    else if (!strcmp(name, "ASURF_TIMELINE")) c.timeline = n;
+    else return false;
+    return true;
+}
+
+Config config() {  // a copy: a call works with one consistent set
+    std::call_once(g_cfg_once, [] {
+        static const char* const names[] = {"ASURF_DEBUG", "ASURF_WALK_SEG", "ASURF_WALK", "ASURF_RPW", "ASURF_NO_PIPELINE",
+                                            "ASURF_CUVOL_RPW", "ASURF_NO_REPLAY", "ASURF_NO_SPLIT_BWD", "ASURF_EVAL",
+                                            "ASURF_TIMELINE"};
+        std::lock_guard<std::mutex> lock(g_cfg_mu);
+        for (const char* nm : names)
+            if (const char* v = getenv(nm)) config_assign(g_cfg, nm, v);
+    });
+    std::lock_guard<std::mutex> lock(g_cfg_mu);
+    return g_cfg;
+}
+
 struct MaskLayout {
     int nb[3];
     int nwz;
@@ -62,10 +119,7 @@ struct MaskLayout {
 // 1.3 k rays 0.64 / 0.48 / 0.39, 20 k 0.77 / 0.56 / 0.55, 80 k 0.86 / 0.64 / 0.67, 160 k 0.95 / 0.79 / 0.85,
 // 640 k 1.52 / 1.65 / 1.79.  ASURF_WALK_SEG = 1, 2, 4 or 8 overrides (tests, measurement).
 static int walk_segments(long long n_rays) {
-    if (const char* e = getenv("ASURF_WALK_SEG")) {
-        const int n = atoi(e);
-        if (n == 1 || n == 2 || n == 4 || n == 8) return n;
-    }
+    if (const int n = config().walk_seg) return n;
     if (n_rays <= 8192) return 8;
     if (n_rays <= 262144) return 4;
     return 1;
@@ -99,6 +153,10 @@ MaskLayout layout_for(const int32_t size[3], int64_t n_rays, int32_t M) {
     L.n_rows = (int)((size_t)L.nb[0] * L.nb[1] * ((L.nb[2] + 7) / 8));
     L.off_mask_hdr = off;
     off = align_up(off + sizeof(MaskHdr), 256);
+    // the pipeline's counters lie right behind the header: a pass that does not vouch for the header clears both with
+    // one memset (n_flagged, spill cursor, kPoolShards pool cursors, the lists' cursors)
+    L.off_p_counters = off;
+    off = align_up(off + kCtrTotal * 4, 256);
     L.off_live_rows = off;
     off = align_up(off + (size_t)L.n_rows * 4, 256);
     const size_t plane = (size_t)(M > 0 ? M : 0) * (size_t)(n_rays > 0 ? n_rays : 0) * 4;
@@ -157,8 +215,6 @@ MaskLayout layout_for(const int32_t size[3], int64_t n_rays, int32_t M) {
                              // block b of k_bwd_seq (256 rays, kRecDepth records each at most) fills segment b % 8
     L.rec_list_cap = (int)(((nr + kBlock - 1) / kBlock + kRecShards - 1) / kRecShards) * kBlock * kRecDepth;
     off = align_up(off + (size_t)L.rec_list_cap * kRecShards * 4, 256);
-    L.off_p_counters = off;  // n_flagged, spill cursor, kPoolShards pool cursors, 2 list lengths
-    off = align_up(off + kCtrTotal * 4, 256);
     L.pool_shard_cap = (int)((8 * nr + kPoolShards - 1) / kPoolShards) + 256;  // (a wave of k_geom may ask for 3 x 64 at once)
     L.off_p_pool = off;
     off = align_up(off + (size_t)L.pool_shard_cap * kPoolShards * sizeof(CandRec), 256);
@@ -250,13 +306,12 @@ KOpt make_kopt(const asurf_render_options* o) {
     k.only_outward_intersect = o->only_outward_intersect;
     k.truncated_vol_render = o->truncated_vol_render;
     k.trunc_vol_weight_min = o->trunc_vol_weight_min;
-    const char* dbg = getenv("ASURF_DEBUG");
-    k.debug = dbg ? atoi(dbg) : 0;
+    const Config c = config();
+    k.debug = c.debug;
 #ifdef ASURF_TIMELINE
     static std::once_flag tl_once;  // ASURF_TIMELINE=<kernel id>: that kernel's waves leave their times (asurf_device.h)
-    std::call_once(tl_once, [] {
-        const char* tl = getenv("ASURF_TIMELINE");
-        const int id = tl ? atoi(tl) : 0;
+    std::call_once(tl_once, [&c] {
+        const int id = c.timeline;
         if (id > 0) (void)hipMemcpyToSymbol(HIP_SYMBOL(g_tl_kernel), &id, sizeof(int));
     });
 #endif
@@ -282,8 +337,7 @@ struct Launch {
 // ASURF_DEBUG & 8 (the per-voxel reference walk of the tests) keep k_walk.
 bool want_sweep(bool use_live, const KOpt& o) {
     if (use_live || (o.debug & 8)) return false;
-    const char* e = getenv("ASURF_WALK");
-    return !(e && strcmp(e, "step") == 0);
+    return !config().walk_step;
 }
 
 // --- optional per-kernel timing (asurf_profile_enable): one hipEvent after every launch ---
@@ -345,7 +399,7 @@ unsigned long long g_mask_cache_clock = 0;
 // -1: epoch 0 (whatever the table says about this workspace is dropped: its planes are about to be rewritten in full,
 // which keeps the list true, but nothing promises `links` is what it was)
 int mask_cache_lookup(void* ws, unsigned long long epoch, const asurf_grid* grid, int n_rows, int* live_blocks,
-                      hipStream_t stream) {
+                      bool capturing) {
     std::lock_guard<std::mutex> lock(g_mask_cache_mu);
     for (MaskCacheEntry& e : g_mask_cache) {
         if (e.ws != ws) continue;
@@ -354,10 +408,13 @@ int mask_cache_lookup(void* ws, unsigned long long epoch, const asurf_grid* grid
             return -1;
         }
         if (e.epoch != epoch || e.links != grid->links || e.size[0] != grid->size[0] || e.size[1] != grid->size[1] ||
-            e.size[2] != grid->size[2])
+            e.size[2] != grid->size[2]) {
+            // another grid's pass is about to overwrite the planes.  Outside a capture the caller stores the new value
+            // over this entry; a capturing call stores nothing, so the entry goes now (the replays clear the
+            // device-side header themselves)
+            if (capturing) e.ws = nullptr;
             return 0;
-        hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
-        const bool capturing = hipStreamIsCapturing(stream, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone;
+        }
         if (e.pending && !capturing) {  // (no query while a graph is being captured)
             if (hipEventQuery(e.ev) == hipSuccess) {
                 e.pending = false;
@@ -446,35 +503,39 @@ int prepare(const asurf_grid* grid, const asurf_rays* rays, const asurf_render_o
     const int mode = cuvol ? 2 : (need_surf ? 1 : 0);  // 2: cuvol cells (asurf_cuvol.h)
     // links_epoch (include/asurf.h): the rows of bricks that are not empty space are remembered in the workspace
     const unsigned long long epoch = cuvol ? 0ull : (unsigned long long)grid->links_epoch;
-    // the pipeline's counters (when the layout has them): zeroed by block 0 of the pass over the live rows, by a memset
-    // in front of the full pass
-    int* zero_ptr = (!masks_only && rays->n_rays > 0) ? reinterpret_cast<int*>(L.ws + L.ML.off_p_counters) : nullptr;
-    const int zero_n = zero_ptr ? kCtrTotal : 0;
+    // the pipeline's counters: zeroed by block 0 of the pass over the live rows, otherwise by the memset that also
+    // clears the header in front of them
+    int* zero_ptr = reinterpret_cast<int*>(L.ws + L.ML.off_p_counters);
+    const int zero_n = kCtrTotal;
+    const size_t hdr_and_counters = (L.ML.off_p_counters - L.ML.off_mask_hdr) + (size_t)kCtrTotal * sizeof(int);
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    const bool capturing = hipStreamIsCapturing(L.stream, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone;
     int live_blocks = 0;
-    int cached = mask_cache_lookup(workspace, epoch, grid, L.ML.n_rows, &live_blocks, L.stream);
-    {   // building the list allocates pinned memory and reads a counter back: not while a graph is being captured
-        hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
-        if (cached == 0 && hipStreamIsCapturing(L.stream, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone)
-            cached = -1;
-    }
-    if (cached != 1 && zero_ptr && hipMemsetAsync(zero_ptr, 0, (size_t)zero_n * sizeof(int), L.stream) != hipSuccess)
-        return fail(ASURF_E_LAUNCH, "hipMemsetAsync(pipeline counters) failed");
+    int cached = mask_cache_lookup(workspace, epoch, grid, L.ML.n_rows, &live_blocks, capturing);
+    // building the list allocates pinned memory and reads a counter back: not while a graph is being captured
+    if (cached == 0 && capturing) cached = -1;
     if (cached == 1) {
+        // (a header that is not what the host table says -- a captured full pass of another grid replayed over this
+        // workspace since -- makes the kernel take every row)
         hipLaunchKernelGGL(k_build_masks_live, dim3((unsigned)live_blocks), dim3(512), 0, L.stream, L.g, opt->sigma_thresh,
                            mode, fw, fl, cw, cl, L.sweep ? fy : nullptr, L.sweep ? fz : nullptr, use_live ? 1 : 0, nzg, hdr,
                            live_rows, epoch, L.ML.n_rows, zero_ptr, zero_n);
-    } else if (cached == 0 && epoch != 0ull) {
-        // first call with this value: the full pass, leaving the list (and zeros in EVERY plane of the empty rows)
-        if (hipMemsetAsync(hdr, 0, sizeof(MaskHdr), L.stream) != hipSuccess)
-            return fail(ASURF_E_LAUNCH, "hipMemsetAsync(mask header) failed");
-        hipLaunchKernelGGL(k_build_masks, dim3((unsigned)L.ML.n_rows), dim3(512), 0, L.stream, L.g, opt->sigma_thresh, mode,
-                           fw, fl, cw, cl, fy, fz, use_live ? 1 : 0, nzg, hdr, live_rows);
-        hipLaunchKernelGGL(k_mask_seal, dim3(1), dim3(1), 0, L.stream, hdr, epoch);
-        mask_cache_store(workspace, epoch, grid, &hdr->n_live, L.stream);
     } else {
-        hipLaunchKernelGGL(k_build_masks, dim3((unsigned)L.ML.n_rows), dim3(512), 0, L.stream, L.g, opt->sigma_thresh, mode,
-                           fw, fl, cw, cl, L.sweep ? fy : nullptr, L.sweep ? fz : nullptr, use_live ? 1 : 0, nzg,
-                           static_cast<MaskHdr*>(nullptr), static_cast<int*>(nullptr));
+        // a full pass rewrites every plane: whatever the header said is void from here on, on this call and on every
+        // replay of a graph this call is captured into (the memset is a node of that graph)
+        if (hipMemsetAsync(hdr, 0, hdr_and_counters, L.stream) != hipSuccess)
+            return fail(ASURF_E_LAUNCH, "hipMemsetAsync(mask header, pipeline counters) failed");
+        if (cached == 0 && epoch != 0ull) {
+            // first call with this value: the full pass, leaving the list (and zeros in EVERY plane of the empty rows)
+            hipLaunchKernelGGL(k_build_masks, dim3((unsigned)L.ML.n_rows), dim3(512), 0, L.stream, L.g, opt->sigma_thresh,
+                               mode, fw, fl, cw, cl, fy, fz, use_live ? 1 : 0, nzg, hdr, live_rows);
+            hipLaunchKernelGGL(k_mask_seal, dim3(1), dim3(1), 0, L.stream, hdr, epoch);
+            mask_cache_store(workspace, epoch, grid, &hdr->n_live, L.stream);
+        } else {
+            hipLaunchKernelGGL(k_build_masks, dim3((unsigned)L.ML.n_rows), dim3(512), 0, L.stream, L.g, opt->sigma_thresh,
+                               mode, fw, fl, cw, cl, L.sweep ? fy : nullptr, L.sweep ? fz : nullptr, use_live ? 1 : 0, nzg,
+                               static_cast<MaskHdr*>(nullptr), static_cast<int*>(nullptr));
+        }
     }
     prof_after(cached == 1 ? "k_build_masks_live" : "k_build_masks", 0, L.stream);
     return launch_error("k_build_masks");
@@ -495,10 +556,7 @@ unsigned list_blocks(long long n_rays, int per_ray) {
 // several times over, fewer below -- a wave works its rays' samples off in turns, and with few waves the kernel is as
 // slow as one of them.  ASURF_RPW = 4 ... 64 overrides (measurement).
 int rays_per_wave(long long n_rays) {
-    if (const char* e = getenv("ASURF_RPW")) {
-        const int n = atoi(e);
-        if (n == 4 || n == 8 || n == 16 || n == 32 || n == 64) return n;
-    }
+    if (const int n = config().rpw) return n;
     // fused step, shuffled rays of the bench scene, 64 / 32 / 16 / 8 rays a wave: 5 k rays 0.176 / 0.165 / 0.160 / 0.159 ms,
     // 40 k 0.259 / 0.251 / 0.247 / 0.249, 160 k 0.541 / 0.541 / 0.557
     if (n_rays <= 8192) return 8;
@@ -513,8 +571,7 @@ int rays_per_wave(long long n_rays) {
 // it holds no sample), or more level sets than a record encodes.
 bool use_pipeline(const asurf_grid* grid, const asurf_rays* rays, const asurf_render_options* opt,
                   const uint64_t* counters) {
-    const char* off = getenv("ASURF_NO_PIPELINE");
-    if (off && atoi(off)) return false;
+    if (config().no_pipeline) return false;
     return counters == nullptr && !(opt->stop_thresh > 1.f) && grid->level_set_num <= 32 &&
            rays->n_rays < (1ll << kListRayBits) &&
            grid->size[0] <= 1024 && grid->size[1] <= 1024 && grid->size[2] <= 1024;
@@ -851,10 +908,7 @@ int launch_eval(const Launch& L, const asurf_rays* rays, float param, int max_sa
 // 80 k 6.26 / 6.48 / 7.06 / 9.86 (8 / 16 / 32 / 64); 160 k 10.8 / 10.3 / 11.0 / 11.7; 320 k 17.6 / 18.7 (32 / 64);
 // 640 k 32.4 / 31.9.  ASURF_CUVOL_RPW = 1 .. 64 (a power of two) overrides.
 static int cuvol_rays_per_wave(long long n_rays) {
-    if (const char* e = getenv("ASURF_CUVOL_RPW")) {
-        const int n = atoi(e);
-        if (n == 1 || n == 2 || n == 4 || n == 8 || n == 16 || n == 32 || n == 64) return n;
-    }
+    if (const int n = config().cuvol_rpw) return n;
     if (n_rays <= 6000) return 1;
     if (n_rays <= 12000) return 2;
     if (n_rays <= 30000) return 4;
@@ -1008,16 +1062,14 @@ int asurf_volume_render_surf_trav_fused(const asurf_grid* grid, const asurf_rays
     // Replay instead of re-walking when the backward provably visits the forward's samples:
     // not with 0 < stop_thresh < 2e-8 (the two passes clamp log(1-alpha) differently,
     // surf_trav.cu:397 vs :2099) and not with more level sets than the record encodes.
-    const char* norec = getenv("ASURF_NO_REPLAY");
-    const bool replay = !(norec && atoi(norec)) && grid->level_set_num <= 32 &&
+    const Config cfg = config();
+    const bool replay = !cfg.no_replay && grid->level_set_num <= 32 &&
                         (opt->stop_thresh <= 0.f || opt->stop_thresh >= 2e-8f);
     const bool pipe = use_pipeline(grid, rays, opt, counters);
     ASURF_DISPATCH_B(grid->basis_dim, run_forward<B_>(L, rays, rgb_out, M, true, replay, counters, pipe));
     if (rc) return rc;
     if (replay) {
-        const char* nosplit = getenv("ASURF_NO_SPLIT_BWD");
-        const int replay_mode =
-            ((nosplit && atoi(nosplit)) || rays->n_rays >= (1ll << kListRayBits)) ? 1 : 3;
+        const int replay_mode = (cfg.no_split_bwd || rays->n_rays >= (1ll << kListRayBits)) ? 1 : 3;
         ASURF_DISPATCH_B(grid->basis_dim,
                          run_backward<B_>(L, rays, loss, G, fused->rgb_gt, rgb_out, M, true, replay_mode, pipe));
         if (rc) return rc;
@@ -1136,6 +1188,14 @@ int asurf_profile_read(float* ms, int n) {
     return 0;
 }
 
+int asurf_config_set(const char* name, const char* value) {
+    if (!name) return fail(ASURF_E_INVALID, "asurf_config_set: name is NULL");
+    (void)config();  // the environment is read first, once; this call then overrides it
+    std::lock_guard<std::mutex> lock(g_cfg_mu);
+    if (!config_assign(g_cfg, name, value)) return fail(ASURF_E_INVALID, "asurf_config_set: unknown switch '%s'", name);
+    return 0;
+}
+
 int asurf_debug_read_timeline(void* dst, int max_recs) {
     if (!dst || max_recs < 1) return fail(ASURF_E_INVALID, "asurf_debug_read_timeline: NULL buffer"), -1;
 #ifdef ASURF_TIMELINE
@@ -1145,7 +1205,7 @@ int asurf_debug_read_timeline(void* dst, int max_recs) {
         return fail(ASURF_E_LAUNCH, "asurf_debug_read_timeline: copy failed"), -1;
     return n;
 #else
-    return fail(ASURF_E_INVALID, "asurf_debug_read_timeline: the library was built without TIMELINE=1"), -1;
+    return fail(ASURF_E_INVALID, "asurf_debug_read_timeline: this is not the instrumented build (make timeline)"), -1;
 #endif
 }
 
@@ -1427,8 +1487,7 @@ int asurf_render_eval_surf_trav(const asurf_grid* grid, const asurf_rays* rays,
     eo.only_outward_intersect = 0;  // (these renders take every crossing, surf_trav.cu:564-1705)
     // through k_sweep + k_geom when the caller's workspace holds the per-ray tables (asurf_workspace_bytes with the
     // call's ray count); with a pyramid-only workspace, or where the one-kernel form is needed, the stepping walk
-    const char* ev = getenv("ASURF_EVAL");
-    const bool pipe = !(ev && strcmp(ev, "walk") == 0) && check_grid(grid) == 0 && check_rays(rays) == 0 &&
+    const bool pipe = !config().eval_walk && check_grid(grid) == 0 && check_rays(rays) == 0 &&
                       rays->n_rays > 0 && workspace_bytes >= layout_for(grid->size, rays->n_rays, 0).total &&
                       use_pipeline(grid, rays, &eo, nullptr);
     Launch L;

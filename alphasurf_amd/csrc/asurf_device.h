@@ -62,12 +62,19 @@ struct KOpt {
     int limited_fake_sample, no_surf_grad_from_sh, alpha_activation_type, fake_sample_l_dist,
         fake_sample_normalize_surf, only_outward_intersect, truncated_vol_render;
     float trunc_vol_weight_min;
-    // ASURF_DEBUG env var; 0 in production.  1, 2, 4: measurement aids of the one-kernel path (traversal only / no
-    // level sets / no candidates: results invalid); 8: per-voxel walk without brick jumps, k_walk instead of k_sweep
-    // (the tests' reference); 16: the pipeline's counters are printed after the call; 32: k_geom without its no-root
-    // filter (variants/geom_filter_check.py); 256 * n: k_sweep leaves after phase n - 1 (phase timing, results invalid)
+    // The ASURF_DEBUG switch (asurf_config_set, include/asurf.h); 0 in production.  8: per-voxel walk without brick
+    // jumps, k_walk instead of k_sweep (the tests' reference); 16: the pipeline's counters are printed after the call;
+    // 32: k_geom without its no-root filter (variants/geom_filter_check.py) -- all three leave the results what they
+    // are.  The measurement aids that do not -- 1, 2, 4: traversal only / no level sets / no candidates in the
+    // one-kernel path; 256 * n: k_sweep leaves after phase n - 1 -- are compiled into the instrumented build only
+    // (`make timeline`: -DASURF_INSTRUMENT); the host masks their bits off otherwise.
     int debug;
 };
+#ifdef ASURF_INSTRUMENT
+#define ASURF_AID(o, bit) (((o).debug & (bit)) != 0)
+#else
+#define ASURF_AID(o, bit) false
+#endif
 
 struct KGrads {
     float* grad_density;
@@ -88,7 +95,7 @@ struct KLoss {  // already scaled by the launcher (surf_trav.cu:3896-3915)
     float norm_l2, norm_l1;  // 2/(3Q), 1/(3Q) with the (global) ray count
 };
 
-// Wave timeline (diagnostics; compiled in with `make TIMELINE=1` only -- the two timestamps a wave carries cost
+// Wave timeline (diagnostics; compiled in by `make -C alphasurf_amd/csrc timeline` only -- the two timestamps a wave carries cost
 // k_geom 64 bytes of scratch per lane and 0.06 ms).  With ASURF_TIMELINE=<kernel id> the waves of ONE kernel leave
 // their start and end on the 100 MHz wall clock and where they ran; asurf_debug_read_timeline() copies the table out
 // (variants/timeline.py).  ids: 1 k_build_masks, 2 k_sweep, 3 k_geom, 6 k_bwd_sh, 7 k_bwd_geo.

@@ -232,10 +232,13 @@ k_build_masks_live(KGrid g, float sigma_thresh, int need_surf, unsigned long lon
     // k_build_masks: the same five stores in its block 0 cost that kernel 9 us -- 0.067 -> 0.076 ms, measured both ways)
     if (blockIdx.x == 0)
         for (int i = threadIdx.x; i < zero_n; i += blockDim.x) zero_ptr[i] = 0;
-    if (hdr->magic != kMaskMagic || hdr->epoch != epoch) return;  // not the buffer the caller promised: nothing is read
-    const int n = min(hdr->n_live, n_rows);
+    // Not the header the host table promised (a full pass captured for another grid has been replayed over this
+    // workspace: it cleared the header and rewrote every plane): the list means nothing, and the rows that were empty
+    // space may hold the other grid's bits -- every row is rebuilt.
+    const bool listed = hdr->magic == kMaskMagic && hdr->epoch == epoch;
+    const int n = listed ? min(hdr->n_live, n_rows) : n_rows;
     for (int i = blockIdx.x; i < n; i += gridDim.x) {
-        const int row = live_rows[i];
+        const int row = listed ? live_rows[i] : i;
         if (row >= 0 && row < n_rows)
             build_masks_row(g, sigma_thresh, need_surf, fine_work, fine_live, coarse_work, coarse_live, fine_y, fine_z,
                             orient_live, nzg, (unsigned)row, S);
@@ -1186,7 +1189,7 @@ k_forward(KGrid g, KOpt o, const float* __restrict__ origins, const float* __res
                 if (!links_present(g, w)) rec_cut = n_pushed;
             }
         }
-        if (o.debug & 1) qn = 0;  // measurement aid: traversal only
+        if (ASURF_AID(o, 1)) qn = 0;  // measurement aid: traversal only
         if (!__any(qn > 0)) break;
       // (B,C) drain the FIFOs in order, slot by slot
       for (int qi = 0; __any(qi < qn); ++qi) {
@@ -1200,7 +1203,7 @@ k_forward(KGrid g, KOpt o, const float* __restrict__ origins, const float* __res
         // (C) real intersections, one level set at a time
         for (int li = 0; li < g.level_set_num; ++li) {
             const float lvf = g.level_set[li];
-            const bool lv_ok = found && !(lvf < v.smin || lvf > v.smax) && !(o.debug & 2);
+            const bool lv_ok = found && !(lvf < v.smin || lvf > v.smax) && !ASURF_AID(o, 2);
             if (!__any(lv_ok)) continue;
             double st[3] = {-1, -1, -1};
             if (lv_ok) {
@@ -1209,7 +1212,7 @@ k_forward(KGrid g, KOpt o, const float* __restrict__ origins, const float* __res
             }
 #pragma unroll
             for (int j = 0; j < 3; ++j) {
-                bool cand = lv_ok && (st[j] > 0) && !(o.debug & 4);
+                bool cand = lv_ok && (st[j] > 0) && !ASURF_AID(o, 4);
                 float pos[3] = {0.f, 0.f, 0.f};
                 if (cand) cand = root_position(r, v, st[j], pos);
                 if (cand) vox_has_sample = true;
@@ -1540,7 +1543,7 @@ k_backward(KGrid g, KOpt o, KLoss L, KGrads G, const float* __restrict__ origins
                     ++qn;
                 }
             }
-            if (o.debug & 1) qn = 0;  // measurement aid: traversal only
+            if (ASURF_AID(o, 1)) qn = 0;  // measurement aid: traversal only
         }
         if (!__any(qn > 0)) break;
       for (int qi = 0; __any(qi < qn); ++qi) {

@@ -69,9 +69,12 @@ struct SweepRay {  // 144 bytes
 static_assert(kPipeC1 <= 64, "phase 4 holds one table slot per lane of a wave");
 __device__ __forceinline__ int sweep_clampi(int v, int lo, int hi) { return min(max(v, lo), hi); }
 
-// diagnostics (phase timing): ASURF_DEBUG = 256 * n makes the blocks leave after phase n - 1, their rays marked empty
+// diagnostics (phase timing; instrumented build only): ASURF_DEBUG = 256 * n makes the blocks leave after phase n - 1, their rays marked empty
 __device__ __forceinline__ bool sweep_debug_leaves(const KOpt& o, int n, int rpb, long long q0, long long Q,
                                                    const PipeBuf& P) {
+#ifndef ASURF_INSTRUMENT
+    return false;
+#endif
     if (((o.debug >> 8) & 7) != n) return false;
     const long long q = q0 + threadIdx.x;
     if ((int)threadIdx.x < rpb && q < Q) {

@@ -10,6 +10,7 @@ Functions outside the build's scope raise NotImplementedError naming the SURVEY.
 section 8(f) row they belong to.
 """
 import ctypes as C
+import itertools
 import threading
 
 import torch
@@ -235,7 +236,9 @@ def _pack_grads(grads, grid):
 
 _ws_cache = {}
 _ws_lock = threading.Lock()
-_ws_nonce = {}
+_ws_nonce = {}                      # (device, stream) -> incarnation number of its buffer
+_ws_incarnations = itertools.count(1)   # ... drawn from one process-wide counter: a freed buffer's address may come
+                                        # back under another stream, and must not bring an old epoch back with it
 
 
 def _workspace(device, nbytes, g=None):
@@ -251,7 +254,7 @@ def _workspace(device, nbytes, g=None):
         if buf is None or buf.numel() < nbytes:
             buf = torch.empty(int(nbytes), dtype=torch.uint8, device=device)
             _ws_cache[key] = buf
-            _ws_nonce[key] = _ws_nonce.get(key, 0) + 1
+            _ws_nonce[key] = next(_ws_incarnations)
         nonce = _ws_nonce.get(key, 0)
     base = getattr(g, "_epoch_base", None) if g is not None else None
     if base:

@@ -7,6 +7,8 @@ Own code; reference locations are cited for parity checking (paths relative to t
 checkout, `svox2/svox2.py` unless stated).  Everything that leaves the hot path raises
 NotImplementedError naming the SURVEY.md section 8(f) row it belongs to.
 """
+import itertools
+import os
 from dataclasses import dataclass
 from functools import reduce
 from typing import List, Optional, Tuple, Union
@@ -17,6 +19,10 @@ from torch import autograd, nn
 
 from . import csrc_api as _C
 from . import gridinit, shutils
+
+# identities of `links` tensors as the renders see them (asurf_grid::links_epoch): one monotonic, process-wide
+# counter -- every SparseGrid draws a fresh value when it is built and whenever its links change
+_LINKS_EPOCHS = itertools.count(1)
 
 # enums of data_spec.hpp:8-36 / svox2/defs.py
 CONSTANTS = dict(
@@ -304,8 +310,19 @@ class _SampleGridAutogradFunction(autograd.Function):
                 grad_sh if ctx.needs_input_grad[1] else None, None, None, None)
 
 
-# rays per call of the whole-image renders (the caller's batch_size is a lower bound)
+# rays per call of the whole-image renders when the caller names no batch size
 _IMAGE_RAYS = 1 << 20
+
+
+def _image_batch(batch_size):
+    """Rays per call of the whole-image renders.  The reference's `batch_size` (default 5000) guards its [Q, 64] sample
+    buffers; here rays are independent and every call pays for the occupancy pyramid of the whole grid once, so a
+    caller that names no batch size gets up to _IMAGE_RAYS rays a call (ASURF_IMAGE_RAYS overrides) -- at about
+    1.8 KB of cached workspace per ray (tables, candidate pool, sample records: 2 GB per stream at 2^20 rays).
+    A batch size the caller passes is a memory bound and is kept as it is."""
+    if batch_size is not None:
+        return max(1, int(batch_size))
+    return max(1, int(os.environ.get("ASURF_IMAGE_RAYS", _IMAGE_RAYS)))
 
 
 class SparseGrid(nn.Module):
@@ -472,7 +489,9 @@ class SparseGrid(nn.Module):
                 else float(self.fake_sample_std)
         g.truncated_vol_render_a = self.truncated_vol_render_a
         # (no reference counterpart) the renders keep their list of non-empty brick rows while `links` stays what it is
-        g.links_epoch = (id(self) << 20) + self.__dict__.get("_links_epoch", 0) + 1
+        if "_links_epoch" not in self.__dict__:
+            self._bump_links_epoch()
+        g.links_epoch = self.__dict__["_links_epoch"]
         return g
 
     def _get_data_grads(self):
@@ -608,7 +627,7 @@ class SparseGrid(nn.Module):
         return finish(rgb_out)
 
     def volume_render_image(self, camera: Camera, use_kernel: bool = True, randomize: bool = False,
-                            batch_size: int = 5000, return_raylen: bool = False, debug_pixels=None,
+                            batch_size: Optional[int] = None, return_raylen: bool = False, debug_pixels=None,
                             **kwargs):
         """Whole-image render in ray batches (:3641-3691): no image kernel is registered for
         surf_trav in the reference either (svox2.cpp:153); `no_surface=True` renders with cuvol
@@ -618,9 +637,8 @@ class SparseGrid(nn.Module):
         if debug_pixels is not None:
             ids = debug_pixels[:, 0] + debug_pixels[:, 1] * camera.width
             return self.volume_render(rays[ids], **kw)["rgb"]
-        # `batch_size` is the reference's guard for its [Q, 64] sample buffers; rays are independent, and every call
-        # pays for the occupancy pyramid of the whole grid once: the batches are merged up to _IMAGE_RAYS rays
-        step = max(int(batch_size), _IMAGE_RAYS)
+        # (rays per call: _image_batch)
+        step = _image_batch(batch_size)
         parts = [self.volume_render(rays[s:s + step], **kw)["rgb"]
                  for s in range(0, camera.height * camera.width, step)]
         return torch.cat(parts, dim=0).view(camera.height, camera.width, -1)
@@ -952,29 +970,29 @@ class SparseGrid(nn.Module):
         return _C.volume_render_alpha_surf_trav(self._to_cpp(), rays._to_cpp(), self.opt._to_cpp(), thresh)
 
     def _image_batches(self, camera: Camera, batch_size: int, fn):
-        batch_size = max(int(batch_size), _IMAGE_RAYS)  # (see volume_render_image)
+        batch_size = _image_batch(batch_size)
         rays = camera.gen_rays()
         return torch.cat([fn(rays[s:s + batch_size]) for s in range(0, camera.height * camera.width, batch_size)],
                          dim=0)
 
     def volume_render_depth_image(self, camera: Camera, sigma_thresh: Optional[float] = None,
-                                  batch_size: int = 5000, **kwargs):
+                                  batch_size: Optional[int] = None, **kwargs):
         """:3808-3826"""
         out = self._image_batches(camera, batch_size, lambda r: self.volume_render_depth(r, sigma_thresh, **kwargs))
         return out.view(camera.height, camera.width)
 
-    def volume_render_normal_image(self, camera: Camera, batch_size: int = 5000, **kwargs):
+    def volume_render_normal_image(self, camera: Camera, batch_size: Optional[int] = None, **kwargs):
         """:3828-3845"""
         out = self._image_batches(camera, batch_size, lambda r: self.volume_render_normal(r, **kwargs))
         return out.view(camera.height, camera.width, 3)
 
-    def volume_render_alpha_image(self, camera: Camera, thresh: float = -1, batch_size: int = 5000, **kwargs):
+    def volume_render_alpha_image(self, camera: Camera, thresh: float = -1, batch_size: Optional[int] = None, **kwargs):
         """:3847-3864"""
         out = self._image_batches(camera, batch_size, lambda r: self.volume_render_alpha_map(r, thresh, **kwargs))
         return out.view(camera.height, camera.width, 1)
 
     def volume_render_extract_pts(self, camera: Camera, sigma_thresh: Optional[float] = None,
-                                  batch_size: int = 5000, depth_type="mean", **kwargs):
+                                  batch_size: Optional[int] = None, depth_type="mean", **kwargs):
         """One 3-D point per ray that has a depth (:3866-3912)."""
         rays = camera.gen_rays()
         depth = self._image_batches(
@@ -983,12 +1001,12 @@ class SparseGrid(nn.Module):
         return pts[(depth != 0.0) & (~torch.isnan(depth))]
 
     def volume_render_extract_pts_with_alpha(self, camera: Camera, sigma_thresh: Optional[float] = None,
-                                             batch_size: int = 5000, max_sample: int = 20, **kwargs):
+                                             batch_size: Optional[int] = None, max_sample: int = 20, **kwargs):
         """Every intersection with alpha above `sigma_thresh`, up to max_sample per ray (:3914-3961)."""
         self._eval_backend(kwargs)
         rays = camera.gen_rays()
         all_pts, all_alpha = [], []
-        batch_size = max(int(batch_size), _IMAGE_RAYS)  # (see volume_render_image)
+        batch_size = _image_batch(batch_size)
         for s in range(0, camera.height * camera.width, batch_size):
             rb = rays[s:s + batch_size]
             depths, alphas = _C.extract_pts_surf_trav(self._to_cpp(), rb._to_cpp(), self.opt._to_cpp(), max_sample,
@@ -1015,20 +1033,23 @@ class SparseGrid(nn.Module):
         return 2.0 * float(self.radius.mean()) / float(self._grid_size().mean())
 
     def _get_rand_cells(self, sparse_frac: float, force: bool = False, contiguous: bool = True):
-        """:6335-6352: a random (contiguous, wrapping) block of flat cell indices, or None = all cells."""
-        if sparse_frac < 1.0 or force:
-            assert self.sparse_grad_indexer is None or self.sparse_grad_indexer.dtype == torch.bool, \
-                "please call sparse loss after rendering and before gradient updates"
-            grid_size = self.links.numel()
-            sparse_num = max(int(sparse_frac * grid_size), 1)
-            if contiguous:
-                start = np.random.randint(0, grid_size)
-                arr = torch.arange(start, start + sparse_num, dtype=torch.int32, device=self.links.device)
-                if start > grid_size - sparse_num:
-                    arr[grid_size - sparse_num - start:] -= grid_size
-                return arr
-            return torch.randint(0, grid_size, (sparse_num,), dtype=torch.int32, device=self.links.device)
-        return None
+        """Cell ids for a stochastic regulariser pass (reference: svox2.py:6335-6352): None stands for "every cell";
+        otherwise max(1, frac * cells) flat ids, either one run that starts at a random cell and wraps around the end
+        of the volume, or independent draws.  The host / device generators are consulted exactly as the reference
+        does (one numpy draw for the run's start, one torch draw for the independent ids), so seeded runs line up."""
+        if not force and sparse_frac >= 1.0:
+            return None
+        if self.sparse_grad_indexer is not None and self.sparse_grad_indexer.dtype != torch.bool:
+            raise AssertionError("sparse regularisers come after the render and before the optimizer step "
+                                 "(the row indexer has already been turned into an index list)")
+        n_cells = self.links.numel()
+        count = max(1, int(sparse_frac * n_cells))
+        dev = self.links.device
+        if not contiguous:
+            return torch.randint(0, n_cells, (count,), dtype=torch.int32, device=dev)
+        first = int(np.random.randint(0, n_cells))
+        run = torch.arange(count, dtype=torch.int64, device=dev).add_(first)
+        return run.remainder_(n_cells).to(torch.int32)
 
     def _get_rand_cells_non_empty(self, sparse_frac: float, frac_of_remaining: bool = True,
                                   contiguous: bool = True):
@@ -1068,8 +1089,10 @@ class SparseGrid(nn.Module):
     def _bump_links_epoch(self):
         """`links` was replaced, or written through a raw pointer: the spec's links_epoch (include/asurf.h) changes,
         and the next render rebuilds its list of non-empty brick rows.  In-place tensor writes need no call: the
-        tensor's version counter is part of the value (csrc_api._pack_grid)."""
-        self.__dict__["_links_epoch"] = self.__dict__.get("_links_epoch", 0) + 1
+        tensor's version counter is part of the value (csrc_api._pack_grid).  The value comes from ONE process-wide
+        counter: an object's id() is reused as soon as the object is freed, so two successive grids of the same
+        shape could otherwise present the same epoch (and often the same links pointer and version)."""
+        self.__dict__["_links_epoch"] = next(_LINKS_EPOCHS)
 
     def _get_data_to_links(self):
         """:6378-6382"""

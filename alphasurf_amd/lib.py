@@ -92,6 +92,7 @@ EXPORTS = [
     "asurf_volume_render_surf_trav_fused", "asurf_volume_render_surface",
     "asurf_volume_render_surface_backward", "asurf_volume_render_surface_fused",
     "asurf_test_cubic_root_grad", "asurf_profile_enable", "asurf_profile_read", "asurf_debug_read_timeline",
+    "asurf_config_set",
     "asurf_profile_read_spans",
     "asurf_rmsprop_step", "asurf_sgd_step", "asurf_optim_scratch_bytes", "asurf_rmsprop_step_masked",
     "asurf_sgd_step_masked", "asurf_ray_voxel_count", "asurf_ray_voxel_fill",
@@ -171,6 +172,7 @@ def lib():
         L.asurf_ray_order_tmp_bytes.restype = C.c_size_t
         L.asurf_ray_order.argtypes = [vp, vp, C.c_int64, vp, vp, C.c_size_t, vp]
         L.asurf_test_quotient.argtypes = [vp, vp, C.c_int64, vp, vp, vp]
+        L.asurf_config_set.argtypes = [C.c_char_p, C.c_char_p]
         if L.asurf_abi_version() != 2:
             raise RuntimeError("libasurf_hip.so ABI version mismatch")
         _lib = L
@@ -182,6 +184,12 @@ def check(rc):
     RuntimeError through TORCH_CHECK for the same class of misuse)."""
     if rc != 0:
         raise RuntimeError(f"asurf: {lib().asurf_last_error().decode()} (code {rc})")
+
+
+def config_set(name, value=None):
+    """One of the library's internal switches (include/asurf.h, asurf_config_set): `value` None = default.  The
+    library reads the ASURF_* environment once, when its first entry point runs; later changes go through here."""
+    check(lib().asurf_config_set(name.encode(), None if value is None else str(value).encode()))
 
 
 def profile_enable(on=True):

@@ -438,6 +438,16 @@ int asurf_profile_enable(int on);
 int asurf_profile_read(float* ms, int n);
 int asurf_profile_read_spans(char* names, size_t names_cap, float* ms, int max_spans);
 
+/* Internal switches (no reference counterpart).  Each selects between internal forms that compute the same results
+ * -- the parity tests compare the forms with each other: ASURF_DEBUG (8: per-voxel stepping walk, 16: print the
+ * pipeline's counters after a call, 32: k_geom without its no-root filter), ASURF_WALK ("step"), ASURF_WALK_SEG,
+ * ASURF_RPW, ASURF_CUVOL_RPW, ASURF_NO_PIPELINE, ASURF_NO_REPLAY, ASURF_NO_SPLIT_BWD, ASURF_EVAL ("walk").  The
+ * environment variables of these names are read ONCE, by the first entry point that runs; afterwards only this
+ * function changes a switch (value NULL = default).  Nothing on the call path reads the environment.  The
+ * measurement aids that make results invalid (ASURF_DEBUG bits 1, 2, 4, 256 * n) exist in the instrumented build
+ * only (`make -C alphasurf_amd/csrc timeline`); the shipped library ignores them.  Returns 0 or ASURF_E_INVALID. */
+int asurf_config_set(const char* name, const char* value);
+
 /* Diagnostics: with ASURF_TIMELINE=<kernel id> in the environment (1 k_build_masks, 2 k_sweep, 3 k_geom, 6 k_bwd_sh,
  * 7 k_bwd_geo) every wave of that kernel records {start, end} on the 100 MHz wall clock and {HW_ID, XCC_ID};
  * this copies the first max_recs records (24 bytes each: u64 t0, u64 t1, u32 hw_id, u32 xcc_id; index = wave number

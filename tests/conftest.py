@@ -18,3 +18,18 @@ def oracle():
     from oracle import oracle as O
     O.build()
     return O
+
+
+_SWITCHES = ("ASURF_DEBUG", "ASURF_WALK_SEG", "ASURF_WALK", "ASURF_RPW", "ASURF_NO_PIPELINE", "ASURF_CUVOL_RPW",
+             "ASURF_NO_REPLAY", "ASURF_NO_SPLIT_BWD", "ASURF_EVAL")
+
+
+@pytest.fixture(autouse=True)
+def _reset_library_switches():
+    """The internal switches a test sets through lib.config_set() do not outlive it (a failing test would otherwise
+    leave the library in its configuration for every test that follows).  Only when the library is loaded already."""
+    yield
+    from alphasurf_amd import lib
+    if lib._lib is not None:
+        for name in _SWITCHES:
+            lib.config_set(name, None)

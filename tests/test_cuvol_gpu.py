@@ -4,6 +4,8 @@ the CPU oracle.  `pytest -m gpu`."""
 import numpy as np
 import pytest
 
+from alphasurf_amd import lib as _asurf_lib
+
 from golden_util import grad_close
 from test_hip_parity import hip  # noqa: F401  (fixture)
 from test_oracle_cuvol import CUVOL_CASES, load_cuvol
@@ -279,9 +281,9 @@ def test_rays_per_wave_is_transparent(hip, monkeypatch):
     opts = OPTION_SETS["plenoxels"]
     ref = None
     for rpw in ("64", "16", "4", "1"):
-        monkeypatch.setenv("ASURF_CUVOL_RPW", rpw)
+        _asurf_lib.config_set("ASURF_CUVOL_RPW", rpw)
         rgb, g = hip.cuvol_fused(sc, o, d, opts, gt, beta_loss=0.05, sparsity_loss=0.01)
-        monkeypatch.delenv("ASURF_CUVOL_RPW")
+        _asurf_lib.config_set("ASURF_CUVOL_RPW", None)
         if ref is None:
             ref = (rgb, g)
             continue

@@ -3,6 +3,8 @@ reference goldens.  `pytest -m gpu`."""
 import numpy as np
 import pytest
 
+from alphasurf_amd import lib as _asurf_lib
+
 from golden_util import load_case
 from test_hip_parity import OPTION_SETS, hip, scene_of, sparse_case  # noqa: F401
 from test_oracle_eval import delta_scale
@@ -91,9 +93,9 @@ def test_both_forms_agree(hip, monkeypatch):
     sc, o, d = sparse_case(4, level_set=(-0.3, 0.0, 0.4))
     for what, param, ms in (("expected", 0.0, 1), ("mode", 0.2, 1), ("sigma_thresh", 0.3, 1), ("alpha", 0.3, 1),
                             ("normal", 0.0, 1), ("extract_pts", 0.05, 6)):
-        monkeypatch.delenv("ASURF_EVAL", raising=False)
+        _asurf_lib.config_set("ASURF_EVAL", None)
         a = hip.render_eval(sc, o, d, OPTION_SETS["syn_yaml"], what, param, ms)
-        monkeypatch.setenv("ASURF_EVAL", "walk")
+        _asurf_lib.config_set("ASURF_EVAL", "walk")
         b = hip.render_eval(sc, o, d, OPTION_SETS["syn_yaml"], what, param, ms)
         for x, y in zip(a if isinstance(a, tuple) else (a,), b if isinstance(b, tuple) else (b,)):
             np.testing.assert_allclose(x, y, rtol=2e-6, atol=2e-6, err_msg=what)

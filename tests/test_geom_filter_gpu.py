@@ -6,6 +6,8 @@ millions of rays: variants/geom_filter_check.py.)  `pytest -m gpu`."""
 import numpy as np
 import pytest
 
+from alphasurf_amd import lib as _asurf_lib
+
 from alphasurf_amd import synth
 from test_hip_parity import hip  # noqa: F401
 
@@ -33,9 +35,9 @@ def test_filter_changes_nothing(hip, monkeypatch, level_set, extra):
     gt = rs.rand(o.shape[0], 3).astype(np.float32)
     opts = dict(synth.SYN_OPTS, **extra)
     fused = dict(lambda_l2=1.0, lambda_l_entropy=1e-4)
-    monkeypatch.setenv("ASURF_DEBUG", "32")
+    _asurf_lib.config_set("ASURF_DEBUG", "32")
     rgb_ref, g_ref = H.render_fused(sc, o, d, opts, gt, fused)
-    monkeypatch.delenv("ASURF_DEBUG")
+    _asurf_lib.config_set("ASURF_DEBUG", None)
     rgb, g = H.render_fused(sc, o, d, opts, gt, fused)
     assert (rgb != 0).any()
     assert np.array_equal(rgb, rgb_ref)

@@ -79,3 +79,20 @@ def test_learned_basis_checkpoint_is_rejected(tmp_path):
     np.savez(path, **z)
     with pytest.raises(NotImplementedError):
         G.SparseGrid.load(path)
+
+
+def test_links_epoch_is_unique_per_grid_and_per_links_change():
+    """asurf_grid::links_epoch must never repeat inside a process: grids that are built and freed back to back reuse
+    their id() (and often the links pointer and version), so the value comes from one global counter."""
+    seen = set()
+    for _ in range(5):
+        g = _grid()
+        ep = g._to_cpp().links_epoch
+        assert ep > 0 and ep not in seen
+        assert g._to_cpp().links_epoch == ep          # stable while links stay what they are
+        seen.add(ep)
+        g.links = g.links.clone()                      # reassignment: a new value
+        ep2 = g._to_cpp().links_epoch
+        assert ep2 not in seen
+        seen.add(ep2)
+        del g

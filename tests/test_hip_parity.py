@@ -5,6 +5,8 @@ import os
 import numpy as np
 import pytest
 
+from alphasurf_amd import lib as _asurf_lib
+
 from golden_util import ALL_CASES, fused_args, grad_close, load_case
 
 pytestmark = pytest.mark.gpu
@@ -240,17 +242,17 @@ def test_replay_equals_walking_backward(hip, monkeypatch):
     for optname in ("syn_yaml", "fake_all", "sigmoid_stop"):
         sc, o, d = sparse_case(9, level_set=(-0.2, 0.0, 0.3), trunc_a=4.0)
         fused = dict(lambda_l2=1.0, lambda_l_entropy=0.05, lambda_l_dist=0.01)
-        monkeypatch.delenv("ASURF_NO_REPLAY", raising=False)
+        _asurf_lib.config_set("ASURF_NO_REPLAY", None)
         rgb1, g1 = hip.render_fused(sc, o, d, OPTION_SETS[optname], gt, fused)
-        monkeypatch.setenv("ASURF_NO_REPLAY", "1")
+        _asurf_lib.config_set("ASURF_NO_REPLAY", "1")
         rgb2, g2 = hip.render_fused(sc, o, d, OPTION_SETS[optname], gt, fused)
-        monkeypatch.delenv("ASURF_NO_REPLAY", raising=False)
+        _asurf_lib.config_set("ASURF_NO_REPLAY", None)
         # replay in one kernel instead of three, and the one-kernel forward instead of the pipeline
-        monkeypatch.setenv("ASURF_NO_SPLIT_BWD", "1")
-        monkeypatch.setenv("ASURF_NO_PIPELINE", "1")
+        _asurf_lib.config_set("ASURF_NO_SPLIT_BWD", "1")
+        _asurf_lib.config_set("ASURF_NO_PIPELINE", "1")
         rgb3, g3 = hip.render_fused(sc, o, d, OPTION_SETS[optname], gt, fused)
-        monkeypatch.delenv("ASURF_NO_SPLIT_BWD", raising=False)
-        monkeypatch.delenv("ASURF_NO_PIPELINE", raising=False)
+        _asurf_lib.config_set("ASURF_NO_SPLIT_BWD", None)
+        _asurf_lib.config_set("ASURF_NO_PIPELINE", None)
         assert np.abs(rgb1 - rgb2).max() <= 1e-6 and np.abs(rgb1 - rgb3).max() <= 1e-6
         for k in ("sh", "density", "surface"):
             grad_close(g1[k], g2[k], 1e-5, f"{optname} grad_{k} (replay vs walk)")
@@ -335,11 +337,11 @@ def test_sweep_dense_scene_and_long_rays(hip, monkeypatch):
     gt = rs.rand(o.shape[0], 3).astype(np.float32)
     opts = dict(OPTION_SETS["syn_yaml"], step_size=0.5)
     fused = dict(lambda_l2=1.0, lambda_l_entropy=1e-3)
-    monkeypatch.setenv("ASURF_DEBUG", "8")
-    monkeypatch.setenv("ASURF_WALK_SEG", "1")
+    _asurf_lib.config_set("ASURF_DEBUG", "8")
+    _asurf_lib.config_set("ASURF_WALK_SEG", "1")
     rgb_ref, g_ref = hip.render_fused(sc, o, d, opts, gt, fused)
-    monkeypatch.delenv("ASURF_DEBUG")
-    monkeypatch.delenv("ASURF_WALK_SEG")
+    _asurf_lib.config_set("ASURF_DEBUG", None)
+    _asurf_lib.config_set("ASURF_WALK_SEG", None)
     rgb, g = hip.render_fused(sc, o, d, opts, gt, fused)
     # (the rays handed to the one-kernel path sum their colours in another order than k_comp: an ulp)
     assert np.abs(rgb - rgb_ref).max() <= 5e-7, np.abs(rgb - rgb_ref).max()
@@ -371,11 +373,11 @@ def test_sweep_small_and_odd_grids(hip, monkeypatch):
         sc = dict(base, links=np.arange(keep.size, dtype=np.int32).reshape(shape),
                   density=base["density"][keep], surface=base["surface"][keep], sh=base["sh"][keep],
                   offset=(0.5 * np.array(shape)).astype(np.float32), scaling=(0.5 * np.array(shape)).astype(np.float32))
-        monkeypatch.setenv("ASURF_DEBUG", "8")
-        monkeypatch.setenv("ASURF_WALK_SEG", "1")
+        _asurf_lib.config_set("ASURF_DEBUG", "8")
+        _asurf_lib.config_set("ASURF_WALK_SEG", "1")
         rgb_ref, g_ref = hip.render_fused(sc, o, d, opts, gt, fused)
-        monkeypatch.delenv("ASURF_DEBUG")
-        monkeypatch.delenv("ASURF_WALK_SEG")
+        _asurf_lib.config_set("ASURF_DEBUG", None)
+        _asurf_lib.config_set("ASURF_WALK_SEG", None)
         rgb, g = hip.render_fused(sc, o, d, opts, gt, fused)
         assert np.abs(rgb - rgb_ref).max() <= 5e-7, (shape, np.abs(rgb - rgb_ref).max())
         assert (g["mask"] == g_ref["mask"]).all(), shape
@@ -431,21 +433,21 @@ def test_brick_skipping_is_exact(hip, monkeypatch):
         crop = dict(sc, links=np.ascontiguousarray(sc["links"][: reso - 5, : reso - 19, : reso // 2 + 3]))
         for scene, extra in ((sc, {}), (crop, dict(near_clip=0.3)), (sc, dict(use_spheric_clip=True))):
             op = dict(opts, **extra)
-            monkeypatch.setenv("ASURF_DEBUG", "8")        # per-voxel walk only,
-            monkeypatch.setenv("ASURF_WALK_SEG", "1")     # one lane per ray
+            _asurf_lib.config_set("ASURF_DEBUG", "8")        # per-voxel walk only,
+            _asurf_lib.config_set("ASURF_WALK_SEG", "1")     # one lane per ray
             rgb_ref, g_ref = hip.render_fused(scene, o, d, op, gt, fused)
-            monkeypatch.delenv("ASURF_DEBUG")
-            monkeypatch.delenv("ASURF_WALK_SEG")
+            _asurf_lib.config_set("ASURF_DEBUG", None)
+            _asurf_lib.config_set("ASURF_WALK_SEG", None)
             # ... against the closed-form sweep (the default), and the hierarchical walk with the ray on 1, 2, 4 and
             # 8 lanes (k_walk_seg: every lane but the first enters its segment at a landing point in the middle of
             # the ray)
             for seg in ("sweep", "1", "2", "4", "8"):
                 if seg != "sweep":
-                    monkeypatch.setenv("ASURF_WALK", "step")
-                    monkeypatch.setenv("ASURF_WALK_SEG", seg)
+                    _asurf_lib.config_set("ASURF_WALK", "step")
+                    _asurf_lib.config_set("ASURF_WALK_SEG", seg)
                 rgb, g = hip.render_fused(scene, o, d, op, gt, fused)
-                monkeypatch.delenv("ASURF_WALK", raising=False)
-                monkeypatch.delenv("ASURF_WALK_SEG", raising=False)
+                _asurf_lib.config_set("ASURF_WALK", None)
+                _asurf_lib.config_set("ASURF_WALK_SEG", None)
                 assert np.array_equal(rgb, rgb_ref), f"reso {reso} {extra} seg {seg}: {np.abs(rgb - rgb_ref).max()}"
                 assert (g["mask"] == g_ref["mask"]).all()
                 for k in ("sh", "density", "surface"):
@@ -558,9 +560,9 @@ def test_segmented_walk_with_long_voxel_lists(hip, oracle, monkeypatch):
     fused = dict(lambda_l2=1.0)
     res = {}
     for seg in ("1", "4", "8"):
-        monkeypatch.setenv("ASURF_WALK_SEG", seg)
+        _asurf_lib.config_set("ASURF_WALK_SEG", seg)
         res[seg] = hip.render_fused(sc, o, d, opts, gt, fused, counters=True)
-        monkeypatch.delenv("ASURF_WALK_SEG")
+        _asurf_lib.config_set("ASURF_WALK_SEG", None)
     rgb1, g1, c1 = res["1"]
     assert c1[1] / o.shape[0] > 20          # V_a: many active voxels per ray
     for seg in ("4", "8"):

@@ -66,3 +66,97 @@ def test_back_to_back_calls_before_the_count_has_arrived(hip):
     torch.cuda.synchronize()
     for rgb in outs:
         assert np.array_equal(rgb.cpu().numpy(), ref_rgb)
+
+
+def test_same_shape_grids_back_to_back():
+    """Two different grids of one shape, built and freed one after the other (a test suite, an evaluation loop over
+    checkpoints): the second must not render with the first one's list of live rows.  Each SparseGrid render (which
+    passes its links_epoch) is compared with the same render through a spec that carries links_epoch = 0."""
+    import torch
+    import svox2
+    from alphasurf_amd import csrc_api as _C
+    assert torch.cuda.is_available()
+    o, d = None, None
+    for seed in range(4):
+        g = svox2.SparseGrid(reso=32, center=[0.0, 0.0, 0.0], radius=[1.0, 1.0, 1.0], basis_dim=4,
+                             device="cuda:0", basis_type=svox2.BASIS_TYPE_SH, surface_type=svox2.SURFACE_TYPE_SDF,
+                             surface_init="sphere", use_sphere_bound=False)
+        g.opt.backend = "surf_trav"
+        g.opt.step_size = 0.5
+        g.opt.sigma_thresh = -20.0
+        g.level_set_data = torch.tensor([0.0], device="cuda:0")
+        rs = np.random.RandomState(seed)
+        # a different half-space of the volume is empty in every grid
+        links = g.links.clone()
+        ax, side = seed % 3, seed // 3
+        sl = [slice(None)] * 3
+        sl[ax] = slice(0, 14) if side == 0 else slice(18, 32)
+        links[tuple(sl)] = -1
+        g.links = links
+        with torch.no_grad():
+            g.density_data.data[:] = torch.from_numpy(rs.normal(2.0, 0.3, size=(g.capacity, 1)).astype(np.float32)).cuda()
+            g.sh_data.data[:] = torch.from_numpy(rs.normal(0, 0.3, size=(g.capacity, 12)).astype(np.float32)).cuda()
+            g.surface_data.data += torch.from_numpy((rs.rand(g.capacity, 1).astype(np.float32) - 0.5) * 0.2).cuda()
+        if o is None:
+            rr = np.random.RandomState(100)
+            o = rr.randn(600, 3).astype(np.float32)
+            o = 2.5 * o / np.linalg.norm(o, axis=1, keepdims=True)
+            t = (rr.rand(600, 3).astype(np.float32) - 0.5) * 0.8
+            d = t - o
+            d /= np.linalg.norm(d, axis=1, keepdims=True)
+        rays = svox2.Rays(torch.from_numpy(o).cuda(), torch.from_numpy(d).cuda())
+        for _ in range(2):   # the second call takes the short pass
+            rgb = g.volume_render(rays, use_kernel=True).detach()
+        spec = g._to_cpp()
+        assert spec.links_epoch != 0
+        spec.links_epoch = 0
+        ref = _C.volume_render_surf_trav(spec, rays._to_cpp(), g.opt._to_cpp())
+        assert torch.equal(rgb, ref), seed
+        del g, spec
+
+
+def test_replayed_full_pass_of_another_grid_invalidates_the_list(hip):
+    """A full occupancy pass captured into a HIP graph for grid B, replayed over the workspace that holds grid A's list
+    of live rows: the replay rewrites every plane, so it must also void A's header on the device -- the next call
+    for A (the host table still says "listed") has to rebuild every row, not only A's live ones."""
+    import torch
+    import hip_util as H
+    from alphasurf_amd import csrc_api as _C
+    sc, o, d = sparse_case(4, level_set=(0.0,))
+    links_b = sc["links"].copy()
+    links_b[links_b.shape[0] // 2:] = -1            # B: the other half is empty space ...
+    sc_b = dict(sc, links=links_b)
+    links_a = sc["links"].copy()
+    links_a[: links_a.shape[0] // 2] = -1           # ... than in A
+    sc_a = dict(sc, links=links_a)
+    ref_a = H.render_forward(sc_a, o, d, OPTION_SETS["syn_yaml"])
+    ref_b = H.render_forward(sc_b, o, d, OPTION_SETS["syn_yaml"])
+    assert not np.array_equal(ref_a, ref_b)
+    r, op = H.rays_spec(o, d), H.opt_spec(OPTION_SETS["syn_yaml"])
+    ga = H.grid_spec(sc_a, links_epoch=0)
+    ga.links_epoch = 41
+    gb = H.grid_spec(sc_b, links_epoch=0)
+    gb.links_epoch = 42
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        for _ in range(2):
+            rgb = _C.volume_render_surf_trav(ga, r, op)
+        _C.volume_render_surf_trav(gb, r, op)       # (sizes the stream's workspace before the capture)
+        rgb_a0 = _C.volume_render_surf_trav(ga, r, op)
+    s.synchronize()
+    assert np.array_equal(rgb.cpu().numpy(), ref_a) and np.array_equal(rgb_a0.cpu().numpy(), ref_a)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph, stream=s):
+        rgb_b = _C.volume_render_surf_trav(gb, r, op)
+    with torch.cuda.stream(s):
+        rgb_a1 = _C.volume_render_surf_trav(ga, r, op)       # the host table learns A again (full pass + list)
+        rgb_a2 = _C.volume_render_surf_trav(ga, r, op)       # short pass
+        graph.replay()                                        # B's full pass over the same workspace
+        rgb_b_np = rgb_b.clone()
+        rgb_a3 = _C.volume_render_surf_trav(ga, r, op)       # the host says "listed", the device header says no
+        rgb_a4 = _C.volume_render_surf_trav(ga, r, op)
+    s.synchronize()
+    assert np.array_equal(rgb_b_np.cpu().numpy(), ref_b)
+    for t in (rgb_a1, rgb_a2, rgb_a3, rgb_a4):
+        assert np.array_equal(t.cpu().numpy(), ref_a)

@@ -5,7 +5,7 @@ import numpy as np
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, root); sys.path.insert(0, os.path.join(root, "tests"))
 import hip_util as hip
-from alphasurf_amd import synth
+from alphasurf_amd import lib as _lib, synth
 from oracle import oracle as oracle_mod
 oracle_mod.build()
 
@@ -50,10 +50,10 @@ for it in range(want + 1):
                       ("walking backward", {"ASURF_NO_REPLAY": "1"}), ("no pipeline", {"ASURF_NO_PIPELINE": "1"}),
                       ("k_walk", {"ASURF_WALK": "step"})):
         for k, v in env.items():
-            os.environ[k] = v
+            _lib.config_set(k, v)
         rgb, g = hip.render_fused(sc, o, d, opts, gt, fused)
         for k in env:
-            del os.environ[k]
+            _lib.config_set(k)
         line = [name, "rgb %.2e" % float(np.abs(rgb - rgb_o).max())]
         for k in ("sh", "density", "surface"):
             scale = max(float(np.abs(go[k]).max()), 1e-30)

@@ -7,7 +7,7 @@ import numpy as np
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests"))
 import hip_util
-from alphasurf_amd import synth
+from alphasurf_amd import lib as _lib, synth
 
 n_rand = int(sys.argv[1]) if len(sys.argv) > 1 else 400000
 rs = np.random.RandomState(1)
@@ -32,9 +32,9 @@ for reso, crop, lv in ((256, None, (0.0,)), (256, None, (-0.4, 0.0, 0.3)), (130,
     fused = dict(lambda_l2=1.0, lambda_l_entropy=1e-4, lambda_conv_mode_samp=1e-6)
     for extra in ({}, dict(only_outward_intersect=False), dict(near_clip=0.4)):
         opts = dict(synth.SYN_OPTS, **extra)
-        os.environ["ASURF_DEBUG"] = "32"
+        _lib.config_set("ASURF_DEBUG", 32)
         rgb_ref, g_ref = hip_util.render_fused(sc, o, d, opts, gt, fused)
-        del os.environ["ASURF_DEBUG"]
+        _lib.config_set("ASURF_DEBUG")
         rgb, g = hip_util.render_fused(sc, o, d, opts, gt, fused)
         dif = np.abs(rgb - rgb_ref).max(axis=1)
         neq = int((dif > 0).sum())

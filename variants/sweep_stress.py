@@ -7,7 +7,7 @@ import numpy as np
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests"))
 import hip_util
-from alphasurf_amd import synth
+from alphasurf_amd import lib as _lib, synth
 
 n_rand = int(sys.argv[1]) if len(sys.argv) > 1 else 400000
 rs = np.random.RandomState(1)
@@ -33,9 +33,9 @@ for reso, crop in ((256, None), (130, (125, 111, 68))):
     fused = dict(lambda_l2=1.0, lambda_l_entropy=1e-4, lambda_conv_mode_samp=1e-6)
     for extra in ({}, dict(near_clip=0.4), dict(use_spheric_clip=True)):
         opts = dict(synth.SYN_OPTS, **extra)
-        os.environ["ASURF_DEBUG"] = "8"; os.environ["ASURF_WALK_SEG"] = "1"
+        _lib.config_set("ASURF_DEBUG", 8); _lib.config_set("ASURF_WALK_SEG", 1)
         rgb_ref, g_ref = hip_util.render_fused(sc, o, d, opts, gt, fused)
-        del os.environ["ASURF_DEBUG"]; del os.environ["ASURF_WALK_SEG"]
+        _lib.config_set("ASURF_DEBUG"); _lib.config_set("ASURF_WALK_SEG")
         rgb, g = hip_util.render_fused(sc, o, d, opts, gt, fused)
         # (a ray handed to the one-kernel path -- more candidates than its key buffer holds -- sums its colours in
         # another order than k_comp: an ulp; a ray with a different work-voxel list differs by far more)
