@@ -37,6 +37,12 @@ def parse():
     ap.add_argument("--sort", action="store_true",
                     help="order the batch for coherence inside the timed step (asurf_ray_order), scatter rgb back")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-verify", action="store_true",
+                    help="skip the self-check (a strided sample of the timed batch against the CPU oracle; a mismatch "
+                         "makes bench.py exit non-zero)")
+    ap.add_argument("--verify-rays", type=int, default=2000)
+    ap.add_argument("--counters", default=None,
+                    help="PMC counters file (default profiles/counters.json; variants/pmc_profile.sh regenerates it)")
     ap.add_argument("--links-epoch", action="store_true",
                     help="tell the renders that `links` is the same from step to step, as it is in the training loop "
                          "(asurf_grid::links_epoch): the occupancy pass then reads the non-empty brick rows only.  Off by "
@@ -77,6 +83,107 @@ def algorithmic_bytes_per_kernel(n_rays, v_t, v_a, s, D, stat_loss, M):
         "k_bwd_geo": float(24 * n_rays + 32 * v_t + 64 * v_a + s * 32 + s * 64 * 2 + s * 16),
         "k_backward_fallback": 0.0,
     }
+
+
+HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec; 6.3 TB/s is what a streaming copy reaches)
+ATOMIC_PEAK_GBPS = 1300.0       # ... "Global float atomics": ~1.3 TB/s of added bytes chip-wide
+N_SIMD, CLOCK_HZ, VALU_CYCLES = 1024, 2.4e9, 2   # 256 CUs x 4 SIMD-32; a wave64 VALU instruction holds its SIMD 2 cycles
+ATOMIC_KERNELS = ("k_bwd_sh", "k_bwd_geo", "k_backward_fallback")
+
+
+def load_counters(path, cfg_key):
+    """profiles/counters.json: per-kernel PMC counters of ONE configuration (collected by variants/pmc_profile.sh:
+    rocprofv3 --pmc passes over this very script).  Counters of another configuration say nothing about this run:
+    then None."""
+    try:
+        cj = json.load(open(path))
+    except Exception:
+        return None
+    if cj.get("config") != cfg_key:
+        return None
+    return cj.get("kernels")
+
+
+def kernel_ceilings(ms, c):
+    """Utilisation of the three ceilings this path can meet, each a fraction <= 1 of a hardware rate, from the
+    kernel's measured time and its PMC counters: HBM (FETCH_SIZE doubled + WRITE_SIZE, the guide's gfx950
+    correction), VALU issue (SQ_INSTS_VALU x 2 cycles over 1024 SIMDs at 2.4 GHz) and, for the scatter kernels, float
+    atomics (WRITE_SIZE bytes against ~1.3 TB/s of added bytes)."""
+    t = ms * 1e-3
+    out = dict(ms=round(ms, 4), hbm_bytes=None, hbm_GBps=None, hbm_frac=None, valu_issue_frac=None, atomic_frac=None,
+               wait_frac=None, bound=None)
+    if not c or t <= 0:
+        return out
+    if c.get("hbm_bytes") is not None:
+        out["hbm_bytes"] = int(c["hbm_bytes"])
+        out["hbm_GBps"] = round(c["hbm_bytes"] / t / 1e9, 1)
+        out["hbm_frac"] = round(c["hbm_bytes"] / t / 1e9 / HBM_PEAK_GBPS, 4)
+    if c.get("valu_insts") is not None:
+        out["valu_issue_frac"] = round(c["valu_insts"] * VALU_CYCLES / (N_SIMD * CLOCK_HZ * t), 4)
+    if c.get("atomic_bytes") is not None:
+        out["atomic_frac"] = round(c["atomic_bytes"] / t / 1e9 / ATOMIC_PEAK_GBPS, 4)
+    if c.get("wave_cycles"):
+        out["wait_frac"] = round(c.get("wait_any", 0.0) / c["wave_cycles"], 4)
+    fr = {k: out[k + "_frac"] for k in ("hbm", "valu_issue", "atomic") if out[k + "_frac"] is not None}
+    if fr:
+        out["bound"] = max(fr, key=fr.get)
+    return out
+
+
+def build_roofline(spans, shares, dom_name, call_ms, model_bytes, cfg_key, counters_path):
+    """The `roofline` object of the JSON line.  `frac` is a UTILISATION of the ceiling that binds the dominant kernel
+    (per-kernel table in `ceilings`); SURVEY.md 8(d)'s compulsory-traffic model of the reference algorithm is kept
+    beside it as `reference_model` -- a throughput equivalent, not a utilisation (it exceeds 1: the kernels find
+    their work voxels by bit tests and replay samples instead of walking twice)."""
+    counters = load_counters(counters_path, cfg_key)
+    ceil = {}
+    for name, ms in spans.items():
+        c = (counters or {}).get(name)
+        if c is not None:
+            c = dict(c)
+            c["atomic_bytes"] = c.get("write_bytes") if name in ATOMIC_KERNELS else None
+        ceil[name] = kernel_ceilings(ms, c)
+    dom = ceil[dom_name]
+    dom_ms = spans[dom_name]
+    model_dom = shares.get(dom_name, 0.0)
+    ref_model = dict(
+        note="SURVEY.md 8(d): compulsory bytes of the REFERENCE algorithm (8 link loads per traversed voxel, a second "
+             "traversal in the backward pass) / measured time; a throughput equivalent, not a utilisation",
+        kernel=dom_name, algorithmic_bytes_per_launch=model_dom,
+        achieved=round(model_dom / (dom_ms * 1e-3) / 1e9, 1), peak=HBM_PEAK_GBPS, unit="GB/s",
+        frac=round(model_dom / (dom_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
+        per_kernel_GBps={k: round(shares.get(k, 0.0) / (v * 1e-3) / 1e9, 1) for k, v in spans.items() if v > 0},
+        whole_call=dict(algorithmic_bytes=model_bytes, achieved=round(model_bytes / (call_ms * 1e-3) / 1e9, 1),
+                        frac=round(model_bytes / (call_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)))
+    if counters is None:
+        # no counters for this configuration: nothing measured to price a ceiling with
+        return dict(bound="hbm", kernel=dom_name, achieved=None, peak=HBM_PEAK_GBPS, unit="GB/s", frac=None, traffic=None,
+                    avg_launch_ms=round(dom_ms, 4), per_kernel_ms={k: round(v, 4) for k, v in spans.items()},
+                    note="no PMC counters on file for this configuration (variants/pmc_profile.sh collects them)",
+                    reference_model=ref_model)
+    whole = dict(ms=round(call_ms, 4))
+    tot_hbm = sum(v["hbm_bytes"] or 0 for v in ceil.values())
+    tot_valu = sum(((counters.get(k) or {}).get("valu_insts") or 0.0) for k in spans)
+    whole["hbm_bytes"] = int(tot_hbm)
+    whole["hbm_GBps"] = round(tot_hbm / (call_ms * 1e-3) / 1e9, 1)
+    whole["hbm_frac"] = round(tot_hbm / (call_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)
+    whole["valu_issue_frac"] = round(tot_valu * VALU_CYCLES / (N_SIMD * CLOCK_HZ * call_ms * 1e-3), 4)
+    bound = dom["bound"] or "hbm"
+    if bound == "hbm":
+        achieved, peak, unit = dom["hbm_GBps"], HBM_PEAK_GBPS, "GB/s"
+    elif bound == "atomic":
+        achieved, peak, unit = round(dom["atomic_frac"] * ATOMIC_PEAK_GBPS, 1), ATOMIC_PEAK_GBPS, "GB/s (float atomics)"
+    else:
+        peak = N_SIMD * CLOCK_HZ / VALU_CYCLES / 1e9
+        achieved, unit = round(dom["valu_issue_frac"] * peak, 1), "G wave-instructions/s (VALU issue)"
+    return dict(bound=bound, kernel=dom_name, achieved=achieved, peak=round(peak, 1), unit=unit,
+                frac=round(achieved / peak, 4), traffic=dom["hbm_bytes"], hbm_frac=dom["hbm_frac"],
+                avg_launch_ms=round(dom_ms, 4), per_kernel_ms={k: round(v, 4) for k, v in spans.items()},
+                ceilings=ceil, whole_call=whole, counters_file=os.path.relpath(counters_path, ROOT),
+                note="frac = utilisation of the ceiling that binds the dominant kernel; ceilings: every kernel against "
+                     "HBM bytes (PMC FETCH_SIZE x 2 + WRITE_SIZE), VALU issue (SQ_INSTS_VALU x 2 cycles / 1024 SIMDs / "
+                     "2.4 GHz) and float-atomic bytes (~1.3 TB/s); wait_frac = SQ_WAIT_ANY / SQ_WAVE_CYCLES",
+                reference_model=ref_model)
 
 
 def spawn_ranks(args):
@@ -273,48 +380,18 @@ def main():
         assert abs(sum(shares.values()) - (b_f + b_b)) <= 1e-6 * (b_f + b_b)
         # the dominant kernel = the longest-running one of the call
         dom_name = max(spans, key=spans.get)
-        dom_ms, dom_bytes = spans[dom_name], shares.get(dom_name, 0.0)
-        achieved = dom_bytes / (dom_ms * 1e-3) / 1e9
-        peak = 8000.0
-        # real HBM traffic per launch from the PMC counters (profiles/traffic.json, collected with rocprofv3 --pmc in
-        # separate passes): next to the model's bytes it shows what the kernels actually move
-        traffic, traffic_call = None, None
-        tpath = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tpath):
-            try:
-                tj = json.load(open(tpath))
-                traffic = tj.get(dom_name, {}).get("hbm_bytes_per_launch")
-                traffic_call = sum(tj[k]["hbm_bytes_per_launch"] for k in spans if k in tj)
-            except Exception:
-                traffic, traffic_call = None, None
-        roofline = dict(bound="hbm", kernel=dom_name, achieved=round(achieved, 1), peak=peak, unit="GB/s",
-                        frac=round(achieved / peak, 4), traffic=traffic,
-                        traffic_GBps=(round(traffic / (dom_ms * 1e-3) / 1e9, 1) if traffic else None),
-                        note="achieved = bytes of SURVEY.md 8(d)'s compulsory-traffic model of the REFERENCE algorithm "
-                             "(8 link loads per traversed voxel, a second traversal in the backward pass) / time; "
-                             "the kernels find the work voxels by bit tests and replay samples, so they move far "
-                             "fewer real bytes (traffic, traffic_GBps) and frac exceeds 1",
-                        algorithmic_bytes_per_launch=dom_bytes, avg_launch_ms=round(dom_ms, 4),
-                        per_kernel_ms={k: round(v, 4) for k, v in spans.items()},
-                        per_kernel_algorithmic_GBps={k: round(shares.get(k, 0.0) / (v * 1e-3) / 1e9, 1)
-                                                     for k, v in spans.items() if v > 0},
-                        groups_ms=dict(k_build_masks=round(t_mask, 4), forward=round(t_fwd, 4),
-                                       backward=round(t_bwd, 4)),
-                        whole_call=dict(algorithmic_bytes=b_f + b_b,
-                                        achieved=round((b_f + b_b) / ((t_mask + t_fwd + t_bwd) * 1e-3) / 1e9, 1),
-                                        frac=round((b_f + b_b) / ((t_mask + t_fwd + t_bwd) * 1e-3) / 1e9 / peak, 4),
-                                        traffic=traffic_call,
-                                        traffic_GBps=(round(traffic_call / ((t_mask + t_fwd + t_bwd) * 1e-3) / 1e9, 1)
-                                                      if traffic_call else None),
-                                        traffic_frac=(round(traffic_call / ((t_mask + t_fwd + t_bwd) * 1e-3) / 1e9 / peak, 4)
-                                                      if traffic_call else None)))
+        call_ms = t_mask + t_fwd + t_bwd
+        cfg_key = dict(reso=R, basis_dim=B, width=args.width, band=args.band, shuffle=bool(args.shuffle),
+                       sort=bool(args.sort), links_epoch=bool(args.links_epoch), rays=Q)
+        roofline = build_roofline(spans, shares, dom_name, call_ms, b_f + b_b, cfg_key,
+                                  args.counters or os.path.join(ROOT, "profiles", "counters.json"))
+        roofline["groups_ms"] = dict(k_build_masks=round(t_mask, 4), forward=round(t_fwd, 4), backward=round(t_bwd, 4))
 
-        cpu = None
-        if not args.no_cpu_baseline:
-            # the oracle (CPU restatement) on a bounded, strided sample of the same rays
+        cpu, verify = None, None
+        need_oracle = not (args.no_cpu_baseline and args.no_verify)
+        if need_oracle:
+            # the oracle (CPU restatement, test infrastructure): the checker of the self-check and the CPU baseline
             from oracle import oracle as O
-            n_cpu = min(args.cpu_rays, Q)
-            idx = np.linspace(0, Q - 1, n_cpu).astype(np.int64)
             if on_device:
                 sc = {k: (v.cpu().numpy() if torch.is_tensor(v) else v) for k, v in sc.items()}
             osc = O.make_scene(sc["links"], sc["density"], sc["surface"], sc["sh"], sc["level_set"],
@@ -325,6 +402,46 @@ def main():
                          lambda_conv_mode_samp=F["lambda_conv_mode_samp"], l_dist_max_sample=M,
                          l_di_alpha_thresh=F["l_di_alpha_thresh"],
                          surf_sparse_alpha_thresh=F["surf_sparse_alpha_thresh"], global_n_rays=Q_global)
+        if not args.no_verify:
+            # ---- self-check, outside the timed region: a strided sample of the TIMED batch against the oracle ----
+            # (1) the colours the timed steps left for those rays; (2) the same rays rendered on their own through
+            # the same entry point, so that their gradients and masks can be compared row by row
+            n_v = min(args.verify_rays, Q)
+            vidx = np.linspace(0, Q - 1, n_v).astype(np.int64)
+            rgb_o, go, st_o = O.render_fused(osc, o_np[vidx], d_np[vidx], synth.SYN_OPTS, gt_np[vidx], fused)
+            rgb_timed = (rgb_user if args.sort else rgb)[torch.from_numpy(vidx).to(dev)].cpu().numpy()
+            e_timed = float(np.abs(rgb_timed - rgb_o).max())
+            rv = _C.RaysSpec()
+            vt = torch.from_numpy(vidx).to(dev)
+            rv.origins, rv.dirs = r_in.origins[vt].contiguous(), r_in.dirs[vt].contiguous()
+            rv.masks = torch.ones(n_v, dtype=torch.bool, device=dev)
+            gv = _C.GridOutputGrads()
+            gv.grad_density_out = torch.zeros_like(g.density_data)
+            gv.grad_sh_out = torch.zeros_like(g.sh_data)
+            gv.grad_surface_out = torch.zeros_like(g.surface_data)
+            gv.mask_out = torch.zeros(g.density_data.shape[0], dtype=torch.bool, device=dev)
+            rgb_v = torch.zeros(n_v, 3, device=dev)
+            _C.volume_render_surf_trav_fused(
+                g, rv, opt, gt_in[vt].contiguous(), 0.0, 0.0, 0.0, True, False, F["lambda_l2"], F["lambda_l1"], 0.0,
+                F["lambda_l_entropy"], False, 0.0, 0.0, 0.0, 0.0, F["l_di_alpha_thresh"],
+                F["surf_sparse_alpha_thresh"], 0.0, 0.0, F["lambda_conv_mode_samp"], M, rgb_v, gv,
+                global_n_rays=Q_global)
+            torch.cuda.synchronize()
+            e_rgb = float(np.abs(rgb_v.cpu().numpy() - rgb_o).max())
+            e_grad = {}
+            for k, t in (("sh", gv.grad_sh_out), ("density", gv.grad_density_out), ("surface", gv.grad_surface_out)):
+                ref = go[k]
+                e_grad[k] = float(np.abs(t.cpu().numpy().reshape(ref.shape) - ref).max()) / max(float(np.abs(ref).max()), 1e-30)
+            mask_ok = bool((gv.mask_out.cpu().numpy().astype(bool) == go["mask"].astype(bool)).all())
+            ok = (e_timed <= 2e-5 and e_rgb <= 2e-5 and max(e_grad.values()) <= 2e-4 and mask_ok and
+                  int(st_o["n_samples"].sum()) > 0)
+            verify = dict(ok=ok, rays=n_v, samples=int(st_o["n_samples"].sum()), rgb_linf_timed_batch=e_timed,
+                          rgb_linf=e_rgb, grad_rel={k: round(v, 8) for k, v in e_grad.items()}, masks_equal=mask_ok,
+                          bounds=dict(rgb=2e-5, grad_rel=2e-4), checker="oracle (CPU restatement), outside the timed region")
+        if not args.no_cpu_baseline:
+            # the oracle on a bounded, strided sample of the same rays
+            n_cpu = min(args.cpu_rays, Q)
+            idx = np.linspace(0, Q - 1, n_cpu).astype(np.int64)
             O.render_fused(osc, o_np[idx[:2000]], d_np[idx[:2000]], synth.SYN_OPTS, gt_np[idx[:2000]], fused)
             reps, tc = 0, time.perf_counter()
             while True:
@@ -352,13 +469,15 @@ def main():
                        "rays_per_step_per_gpu": Q, "active_voxels": int(g.density_data.shape[0]),
                        "avg_per_ray": {"V_t": round(v_t / Q, 2), "V_a": round(v_a / Q, 2), "S": round(s_cnt / Q, 3)},
                        "parallelism": f"ray-sharded dp{world}, {args.exchange} RCCL exchange of grads" if world > 1 else "single GPU"},
-            "roofline": roofline, "cpu_baseline": cpu,
+            "roofline": roofline, "cpu_baseline": cpu, "verify": verify,
         }
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
         print(json.dumps(out))
+        if out.get("verify") is not None and not out["verify"]["ok"]:
+            sys.exit("bench.py: the timed batch does NOT match the oracle: " + json.dumps(out["verify"]))
 
 
 if __name__ == "__main__":

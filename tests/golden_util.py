@@ -11,7 +11,15 @@ STORED_CASES = [
     "r16_sh9_l2", "r16_sh9_entropy", "r16_sh9_allfake", "r16_sh9_sparsity", "r32_sh4_l2",
     "r16_sh9_legacy", "r16_sh4_legacy",
 ]
-ALL_CASES = STORED_CASES + ["cfg1_r64_sh1"]
+ALL_CASES = STORED_CASES + ["cfg1_r64_sh1", "cfg1_r64_sh1_offaxis"]
+
+# grad_surface tolerance (relative to max|g|) where it is not the tests' 2e-4.  cfg1_r64_sh1_offaxis: ONE of its 862
+# rays (689) grazes its level set, and that ray alone owns the largest element of the plane.  The reference's PyTorch
+# renderer carries the geometry in float64 end to end, the CUDA kernels (which the oracle restates) carry t_close and
+# the sample position in float32 (difference 10): perturbing that ray's origin and direction by one
+# float32 ulp moves the oracle's value for the element by up to 5e-3 of itself, and the reference's value lies inside
+# that range (it differs by 6e-4).  Every other element of the case agrees to 1e-4.
+SURFACE_GRAD_RTOL = {"cfg1_r64_sh1_offaxis": 1.5e-3}
 
 
 def load_case(name):

@@ -12,6 +12,11 @@ SYN = dict(sigma_thresh=-1e4, stop_thresh=-1e4, only_outward_intersect=True, tru
            trunc_vol_weight_min=1e-10, limited_fake_sample=True, fake_sample_l_dist=False, step_size=0.5)
 
 CONFIGS = {
+    # configs[1], the headline: exactly bench.py's workload -- the numpy-built bench scene, synth.SYN_OPTS /
+    # synth.SYN_FUSED, the WHOLE 800x800 view (640 k rays), in image order and in training (shuffled) order
+    "cfg2_256_sh9": dict(reso=256, basis_dim=9, band=3.0, width=800, min_active=1_000_000, bench=True),
+    "cfg2_256_sh9_shuffled": dict(reso=256, basis_dim=9, band=3.0, width=800, min_active=1_000_000, bench=True,
+                                  shuffle=True),
     # configs[2]: 512^3 sparse grid, SH deg 3
     "cfg3_512_sh16": dict(reso=512, basis_dim=16, band=3.0, width=800, min_active=4_000_000),
     # configs[4]: 768^3, > 40 M active voxels, SH deg 3, 1600x1600 (one GPU's share: rows of the view)
@@ -27,7 +32,13 @@ def test_full_size_config(oracle, name):
     cfg = CONFIGS[name]
     dev = hip_util.dev()
     R, B = cfg["reso"], cfg["basis_dim"]
-    sc = synth.make_sparse_scene_torch(R, B, dev, band=cfg["band"], trunc_a=5.0, **synth.BENCH_SCENE)
+    bench = cfg.get("bench", False)
+    if bench:   # as bench.py builds it
+        sc = synth.make_sparse_scene(R, B, trunc_a=5.0, **synth.BENCH_SCENE)
+        sc = {k: (torch.from_numpy(v).to(dev) if isinstance(v, np.ndarray) and k not in ("offset", "scaling") else v)
+              for k, v in sc.items()}
+    else:
+        sc = synth.make_sparse_scene_torch(R, B, dev, band=cfg["band"], trunc_a=5.0, **synth.BENCH_SCENE)
     n = sc["density"].shape[0]
     assert n >= cfg["min_active"], n
     g = _C.SparseGridSpec()
@@ -36,16 +47,21 @@ def test_full_size_config(oracle, name):
     g._offset, g._scaling = torch.from_numpy(sc["offset"]), torch.from_numpy(sc["scaling"])
     g.basis_dim, g.basis_type, g.surface_type = B, 1, 102
     g.fake_sample_std, g.truncated_vol_render_a = sc["fake_sample_std"], sc["truncated_vol_render_a"]
-    opt = hip_util.opt_spec(SYN)
+    opts = synth.SYN_OPTS if bench else SYN
+    opt = hip_util.opt_spec(opts)
 
     W = cfg["width"]
-    o_np, d_np = synth.pinhole_rays(synth.orbit_camera(1), W, W)
-    # a band of image rows through the middle of the view (every GPU's share in the 8-GPU config)
-    rows = slice((W // 2 - 100) * W, (W // 2 + 100) * W)
-    o_np, d_np = o_np[rows], d_np[rows]
+    o_np, d_np = synth.pinhole_rays(synth.orbit_camera(0 if bench else 1), W, W)
+    if not bench:
+        # a band of image rows through the middle of the view (every GPU's share in the 8-GPU config)
+        rows = slice((W // 2 - 100) * W, (W // 2 + 100) * W)
+        o_np, d_np = o_np[rows], d_np[rows]
+    if cfg.get("shuffle"):
+        perm = np.random.RandomState(11).permutation(o_np.shape[0])   # bench.py --shuffle, rank 0
+        o_np, d_np = o_np[perm], d_np[perm]
     Q = o_np.shape[0]
-    gt_np = np.random.RandomState(5).rand(Q, 3).astype(np.float32)
-    fused_kw = dict(lambda_l2=1.0, lambda_l_entropy=1e-4, lambda_conv_mode_samp=1e-6)
+    gt_np = np.random.RandomState(7 if bench else 5).rand(Q, 3).astype(np.float32)
+    fused_kw = dict(synth.SYN_FUSED) if bench else dict(lambda_l2=1.0, lambda_l_entropy=1e-4, lambda_conv_mode_samp=1e-6)
 
     def run(idx):
         r = hip_util.rays_spec(o_np[idx], d_np[idx])
@@ -83,7 +99,7 @@ def test_full_size_config(oracle, name):
                             host["offset"], host["scaling"], B, host["fake_sample_std"],
                             host["truncated_vol_render_a"])
     fused = dict(fused_kw, global_n_rays=Q)
-    rgb_o, go, st = oracle.render_fused(osc, o_np[samp], d_np[samp], SYN, gt_np[samp], fused)
+    rgb_o, go, st = oracle.render_fused(osc, o_np[samp], d_np[samp], opts, gt_np[samp], fused)
     assert st["n_samples"].sum() > 100
     assert np.abs(rgb_s.cpu().numpy() - rgb_o).max() <= 2e-5
     grad_close(gr_s.grad_sh_out.cpu().numpy(), go["sh"], 2e-4, "grad_sh")

@@ -7,7 +7,7 @@ import pytest
 
 from alphasurf_amd import lib as _asurf_lib
 
-from golden_util import ALL_CASES, fused_args, grad_close, load_case
+from golden_util import ALL_CASES, SURFACE_GRAD_RTOL, fused_args, grad_close, load_case
 
 pytestmark = pytest.mark.gpu
 
@@ -53,7 +53,8 @@ def test_golden_fused(hip, oracle, name):
     grad_close(g["sh"], z["grad_sh"], GRAD_RTOL, f"{name} grad_sh vs reference")
     grad_close(g["density"], z["grad_density"], GRAD_RTOL, f"{name} grad_density vs reference")
     if meta["conv_mode"] == 0.0:
-        grad_close(g["surface"], z["grad_surface"], GRAD_RTOL, f"{name} grad_surface vs reference")
+        grad_close(g["surface"], z["grad_surface"], SURFACE_GRAD_RTOL.get(name, GRAD_RTOL),
+                   f"{name} grad_surface vs reference")
     # against the oracle (covers the conv_mode term, which the reference's torch path
     # differentiates differently from its CUDA path)
     _, go, _ = oracle.render_fused(sc, z["origins"], z["dirs"], meta["opt"], gt, fused)
@@ -62,6 +63,32 @@ def test_golden_fused(hip, oracle, name):
     assert abs(float(g["fake_sample_std"][0]) - float(go["fake_sample_std"][0])) <= \
         1e-3 * max(abs(float(go["fake_sample_std"][0])), float(np.abs(go["density"]).max()))
     assert (g["mask"].astype(bool) == go["mask"].astype(bool)).all()
+
+
+@pytest.mark.parametrize("name", ["cfg1_r64_sh1", "cfg1_r64_sh1_offaxis"])
+def test_config1_whole_view_vs_oracle(hip, oracle, name):
+    """BASELINE.json configs[0] -- 64^3 dense SDF grid, 1 SH band, 32x32 rays -- with ALL 1024 rays of the view (the
+    reference-pinned golden keeps only the rays on which the reference's PyTorch and CUDA paths are defined alike:
+    28 from the on-axis pose, 862 from the off-axis one; the rest, rays through sliver voxels included, are checked
+    here against the oracle), under the golden's option set and under the shipped config's."""
+    z, meta = load_case(name)
+    sc = scene_of(oracle, z, meta)
+    o, d = z["rays_all_origins"], z["rays_all_dirs"]
+    assert o.shape == (1024, 3) and int(z["rays_all_keep"].sum()) == z["origins"].shape[0]
+    gt = np.random.RandomState(21).rand(1024, 3).astype(np.float32)
+    for opts, fused in ((meta["opt"], dict(lambda_l1=1.0, lambda_l2=0.0, lambda_conv_mode_samp=1e-3)),
+                        (OPTION_SETS["syn_yaml"], dict(lambda_l2=1.0, lambda_l_entropy=1e-4,
+                                                        lambda_conv_mode_samp=1e-6))):
+        rgb, g = hip.render_fused(sc, o, d, opts, gt, fused)
+        rgb_o, go, st = oracle.render_fused(sc, o, d, opts, gt, fused)
+        assert st["n_samples"].sum() > 1024
+        assert np.abs(rgb - rgb_o).max() <= RGB_TOL_ORACLE
+        for k in ("sh", "density", "surface"):
+            grad_close(g[k], go[k], GRAD_RTOL, f"{name} grad_{k} vs oracle")
+        assert (g["mask"].astype(bool) == go["mask"].astype(bool)).all()
+        # the rays the golden keeps render to the golden's colours inside the whole view too
+        if opts is meta["opt"]:
+            assert np.abs(rgb[z["rays_all_keep"]] - z["rgb"]).max() <= RGB_TOL
 
 
 def sparse_case(basis_dim, reso=48, seed=5, **kw):
@@ -457,39 +484,10 @@ def test_brick_skipping_is_exact(hip, monkeypatch):
 def test_random_option_fuzz(hip, oracle):
     """Randomised sweep over scenes, options and loss weights: every draw must agree with the
     oracle (RGB, gradients, masks).  Seeds are fixed; each draw is printed on failure."""
-    from alphasurf_amd import synth
-    rs = np.random.RandomState(int(os.environ.get("ASURF_FUZZ_SEED", "2024")))
-    for it in range(int(os.environ.get("ASURF_FUZZ_DRAWS", "24"))):     # a longer sweep: set the two variables
-        reso = int(rs.choice([24, 40, 57, 72]))
-        B = int(rs.choice([1, 4, 9, 16]))
-        lv = tuple(sorted(rs.uniform(-0.6, 0.6, size=int(rs.choice([1, 1, 2, 3]))).tolist()))
-        sc = synth.make_sparse_scene(reso, B, seed=int(rs.randint(1000)), band=float(rs.uniform(1.5, 4.0)),
-                                     dilate=int(rs.randint(0, 3)), level_set=lv,
-                                     trunc_a=float(rs.uniform(1.0, 6.0)),
-                                     fake_sample_std=float(rs.uniform(0.3, 1.5)))
-        o, d = synth.random_rays(1500, int(rs.randint(1000)))
-        opts = dict(
-            sigma_thresh=float(rs.choice([-1e4, -3.0, 0.3, 0.5])), stop_thresh=float(rs.choice([-1e4, 0.0, 1e-7, 1e-2])),
-            step_size=float(rs.choice([0.01, 0.5, 2.0])), near_clip=float(rs.choice([0.0, 0.0, 0.2])),
-            use_spheric_clip=bool(rs.rand() < 0.2), alpha_activation_type=int(rs.randint(0, 2)),
-            only_outward_intersect=bool(rs.rand() < 0.5), truncated_vol_render=bool(rs.rand() < 0.6),
-            trunc_vol_weight_min=float(rs.choice([0.0, 1e-10, 0.05])), surf_fake_sample=bool(rs.rand() < 0.5),
-            surf_fake_sample_min_vox_len=float(rs.choice([0.0, 0.05, 0.3])), limited_fake_sample=bool(rs.rand() < 0.5),
-            fake_sample_l_dist=bool(rs.rand() < 0.5), fake_sample_normalize_surf=bool(rs.rand() < 0.5),
-            no_surf_grad_from_sh=bool(rs.rand() < 0.2), background_brightness=float(rs.choice([0.0, 0.5, 1.0])))
-        fused = dict(lambda_l2=float(rs.rand()), lambda_l1=float(rs.rand()))
-        for k, hi in (("lambda_l_entropy", 0.05), ("lambda_l_dist", 0.05), ("lambda_l_dist_a", 0.05),
-                      ("lambda_l_entropy_a", 0.02), ("lambda_l_samp_dist", 0.05), ("lambda_conv_mode_samp", 1e-3),
-                      ("sparsity_loss", 0.01), ("lambda_inwards_norm_loss", 0.01), ("lambda_l_di", 0.01),
-                      ("lambda_inplace_surf_sparse", 1e-3)):
-            if rs.rand() < 0.3:
-                fused[k] = float(rs.uniform(0.1, 1.0) * hi)
-        fused["l_di_alpha_thresh"] = 0.5
-        fused["surf_sparse_alpha_thresh"] = 0.5
-        fused["no_norm_weight_l_entropy"] = bool(rs.rand() < 0.5)
-        fused["l_dist_max_sample"] = int(rs.choice([2, 8, 64]))
-        gt = rs.rand(o.shape[0], 3).astype(np.float32)
-        tag = f"draw {it}: reso {reso} B {B} lv {lv} opts {opts} fused {fused}"
+    import fuzz_util
+    seed = int(os.environ.get("ASURF_FUZZ_SEED", "2024"))
+    n_draws = int(os.environ.get("ASURF_FUZZ_DRAWS", "24"))     # a longer sweep: set the two variables
+    for it, sc, o, d, opts, fused, gt, tag in fuzz_util.draws(seed, n_draws):
         rgb, g = hip.render_fused(sc, o, d, opts, gt, fused)
         rgb_o, go, st = oracle.render_fused(sc, o, d, opts, gt, fused)
         assert np.abs(rgb - rgb_o).max() <= RGB_TOL_ORACLE, tag
@@ -499,6 +497,54 @@ def test_random_option_fuzz(hip, oracle):
         scale = max(abs(float(go["fake_sample_std"][0])), float(np.abs(go["density"]).max()), 1e-12)
         assert abs(float(g["fake_sample_std"][0]) - float(go["fake_sample_std"][0])) <= 1e-2 * scale, tag
         assert (g["mask"].astype(bool) == go["mask"].astype(bool)).all(), tag
+
+
+INTERNAL_FORMS = (("default", {}), ("no filter", {"ASURF_DEBUG": "32"}), ("one-kernel replay", {"ASURF_NO_SPLIT_BWD": "1"}),
+                  ("walking backward", {"ASURF_NO_REPLAY": "1"}), ("one-kernel forward", {"ASURF_NO_PIPELINE": "1"}),
+                  ("k_walk", {"ASURF_WALK": "step"}))
+
+
+def test_fuzz_knife_edge_draw(hip, oracle):
+    """Draw 107 of sweep seed 31337 (round 2's long sweep): one sample sits on a knife edge -- the sign test of the
+    inwards-normal loss term, decided one way by the host's libm and the other way by the device's -- and ONE element
+    of grad_surface differs from the oracle by 4 % of the plane's maximum.  Kept as a case: (1) every internal form
+    of the HIP path (pipeline or one kernel, k_sweep or the stepping walk, filter on or off, replay or walking
+    backward) gives the same result; (2) wherever the HIP path differs from the oracle by more than the usual bound,
+    the ORACLE itself moves by as much when its surface values are perturbed by 1e-6 relative."""
+    import fuzz_util
+    (it, sc, o, d, opts, fused, gt, tag), = list(fuzz_util.draws(31337, 108, only=107))
+    res = {}
+    for name, switches in INTERNAL_FORMS:
+        for k, v in switches.items():
+            _asurf_lib.config_set(k, v)
+        res[name] = hip.render_fused(sc, o, d, opts, gt, fused)
+        for k in switches:
+            _asurf_lib.config_set(k, None)
+    rgb, g = res["default"]
+    for name, (rgb_n, g_n) in res.items():
+        assert np.abs(rgb_n - rgb).max() <= 2e-6, name
+        for k in ("sh", "density", "surface"):
+            grad_close(g_n[k], g[k], 2e-5, f"{name} grad_{k} vs the default form")
+        assert (g_n["mask"] == g["mask"]).all(), name
+    rgb_o, go, _ = oracle.render_fused(sc, o, d, opts, gt, fused)
+    assert np.abs(rgb - rgb_o).max() <= RGB_TOL_ORACLE
+    assert (g["mask"].astype(bool) == go["mask"].astype(bool)).all()
+    # the oracle's own sensitivity, element by element
+    moved = {k: np.zeros_like(go[k]) for k in ("sh", "density", "surface")}
+    for eps in (1e-6, -1e-6):
+        sc2 = dict(sc, surface=(sc["surface"].astype(np.float64) * (1.0 + eps)).astype(np.float32))
+        _, go2, _ = oracle.render_fused(sc2, o, d, opts, gt, fused)
+        for k in moved:
+            moved[k] = np.maximum(moved[k], np.abs(go2[k] - go[k]))
+    n_edge = 0
+    for k in ("sh", "density", "surface"):
+        scale = float(np.abs(go[k]).max())
+        err = np.abs(g[k].reshape(go[k].shape) - go[k])
+        over = err > 3e-4 * scale
+        n_edge += int(over.sum())
+        assert (err[over] <= 1.1 * moved[k][over] + 3e-4 * scale).all(), \
+            f"grad_{k}: differs from the oracle by {float(err[over].max()):.3e} where the oracle is stable"
+    assert n_edge <= 2, n_edge
 
 
 def test_walk_quotient_is_the_ieee_quotient(hip):
