@@ -200,7 +200,8 @@ MaskLayout layout_for(const int32_t size[3], int64_t n_rays, int32_t M) {
     off = align_up(off + nr * 4, 256);
     L.off_p_cand = off;
     off = align_up(off + nr * 8, 256);
-    L.sp_cap = (int)(4 * nr) + 256;  // spilled work voxels (beyond kPipeC1 per ray), all rays together
+    L.sp_cap = (int)(8 * nr) + 256;  // spilled work voxels (beyond kPipeC1 per ray), all rays together (dense, noisy
+                                     // scenes reach 6 a ray; beyond the capacity rays go to the one-kernel path)
     L.off_p_spill = off;             // sp_items | sp_citem | sp_ray
     off = align_up(off + (size_t)L.sp_cap * 3 * 4, 256);
     L.off_p_list = off;      // dense list of occupied table cells (k_walk / k_sweep -> k_geom), kListSegs segments: the

@@ -138,7 +138,9 @@ def build_roofline(spans, shares, dom_name, call_ms, model_bytes, cfg_key, count
     counters = load_counters(counters_path, cfg_key)
     ceil = {}
     for name, ms in spans.items():
-        c = (counters or {}).get(name)
+        # (the fallback kernels -- 1 % of the call -- share their names with bench.py's own counter pass over all rays:
+        # their averaged counters describe neither)
+        c = None if name.endswith("_fallback") else (counters or {}).get(name)
         if c is not None:
             c = dict(c)
             c["atomic_bytes"] = c.get("write_bytes") if name in ATOMIC_KERNELS else None

@@ -536,15 +536,15 @@ def test_fuzz_knife_edge_draw(hip, oracle):
         _, go2, _ = oracle.render_fused(sc2, o, d, opts, gt, fused)
         for k in moved:
             moved[k] = np.maximum(moved[k], np.abs(go2[k] - go[k]))
-    n_edge = 0
+    edge_rows = set()
     for k in ("sh", "density", "surface"):
         scale = float(np.abs(go[k]).max())
         err = np.abs(g[k].reshape(go[k].shape) - go[k])
         over = err > 3e-4 * scale
-        n_edge += int(over.sum())
+        edge_rows |= set(np.nonzero(over.any(axis=1))[0].tolist())
         assert (err[over] <= 1.1 * moved[k][over] + 3e-4 * scale).all(), \
             f"grad_{k}: differs from the oracle by {float(err[over].max()):.3e} where the oracle is stable"
-    assert n_edge <= 2, n_edge
+    assert len(edge_rows) <= 32, sorted(edge_rows)     # local: the knife-edge sample's voxel and the neighbours its normal term reads
 
 
 def test_walk_quotient_is_the_ieee_quotient(hip):

@@ -105,13 +105,17 @@ def test_same_shape_grids_back_to_back():
             d = t - o
             d /= np.linalg.norm(d, axis=1, keepdims=True)
         rays = svox2.Rays(torch.from_numpy(o).cuda(), torch.from_numpy(d).cuda())
-        for _ in range(2):   # the second call takes the short pass
-            rgb = g.volume_render(rays, use_kernel=True).detach()
+        outs = [g.volume_render(rays, use_kernel=True)["rgb"].detach() for _ in range(3)]   # full pass + list, then short passes
         spec = g._to_cpp()
         assert spec.links_epoch != 0
         spec.links_epoch = 0
         ref = _C.volume_render_surf_trav(spec, rays._to_cpp(), g.opt._to_cpp())
-        assert torch.equal(rgb, ref), seed
+        for i, rgb in enumerate(outs):
+            # (an ulp, not bit equality: this dense, noisy scene can exhaust the spill list, and WHICH rays are then
+            # handed to the one-kernel path -- which sums a ray's colours in another order -- depends on timing; a
+            # stale list of live rows loses geometry and shows up at 1e-2 and more)
+            diff = (rgb - ref).abs().max(dim=1).values
+            assert float(diff.max()) <= 2.5e-7, (seed, i, int((diff > 0).sum()), float(diff.max()))
         del g, spec
 
 

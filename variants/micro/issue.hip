@@ -59,9 +59,9 @@ int main() {
         const double wave_inst_per_simd = inst_per_wave * W;          // W waves on every SIMD
         const double ghz = (double)h[0] / ((double)h[1] * 10.0);      // s_memrealtime ticks at 100 MHz
         const double cyc_24 = ms * 1e-3 * 2.4e9 / wave_inst_per_simd;
-        const double cyc_real = (double)h[0] / inst_per_wave / W;     // block 0's own cycles per instruction, per wave slot
-        printf("waves/SIMD %d: %.3f ms, %.2f cycles per wave-instruction per SIMD at 2.4 GHz; in-kernel clock %.2f GHz, "
-               "%.2f cycles by s_memtime (one wave sees %.2f cycles between its own instructions)\n",
+        const double cyc_real = cyc_24 * ghz / 2.4;                   // ... at the clock the chip really held
+        printf("waves/SIMD %d: %.3f ms, %.2f cycles per wave-instruction per SIMD at a nominal 2.4 GHz; in-kernel clock "
+               "%.2f GHz -> %.2f cycles at that clock; one wave sees %.2f cycles between its own instructions\n",
                W, ms, cyc_24, ghz, cyc_real, (double)h[0] / inst_per_wave);
     }
     return 0;

@@ -20,11 +20,13 @@ OUT=gpurun_out/pmc_$TAG
 mkdir -p "$OUT" profiles
 cd /tmp && export TMPDIR=/tmp && cd - >/dev/null
 BENCH="bench.py --no-cpu-baseline --no-verify --steps 3 --warmup 1 $*"
-rocprofv3 --kernel-trace --stats -d "$OUT/trace" -- python3 $BENCH > "$OUT/trace.log" 2>&1
-rocprofv3 --pmc FETCH_SIZE -d "$OUT/fetch" -- python3 $BENCH > "$OUT/fetch.log" 2>&1
-rocprofv3 --pmc WRITE_SIZE -d "$OUT/write" -- python3 $BENCH > "$OUT/write.log" 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- python3 $BENCH > "$OUT/trace.log" 2>&1
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/fetch" -- python3 $BENCH > "$OUT/fetch.log" 2>&1
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/write" -- python3 $BENCH > "$OUT/write.log" 2>&1
 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM SQ_WAVES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_VALU \
-    -d "$OUT/sq" -- python3 $BENCH > "$OUT/sq.log" 2>&1
-rocprofv3 --pmc FETCH_SIZE -d "$OUT/calib_fetch" -- python3 variants/pmc_calib.py > "$OUT/calib_fetch.log" 2>&1
-rocprofv3 --pmc WRITE_SIZE -d "$OUT/calib_write" -- python3 variants/pmc_calib.py > "$OUT/calib_write.log" 2>&1
+    --output-format csv -d "$OUT/sq" -- python3 $BENCH > "$OUT/sq.log" 2>&1
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/calib_fetch" -- python3 variants/pmc_calib.py > "$OUT/calib_fetch.log" 2>&1
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/calib_write" -- python3 variants/pmc_calib.py > "$OUT/calib_write.log" 2>&1
 python3 variants/make_counters.py "$OUT" "$TAG" $BENCH
+# (gpurun brings back gpurun_out/ only)
+mkdir -p gpurun_out/profiles && cp profiles/${TAG}_counters.json profiles/${TAG}_kernel_stats.csv profiles/counters.json gpurun_out/profiles/
