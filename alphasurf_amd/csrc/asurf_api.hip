@@ -58,6 +58,9 @@ struct Config {
     int no_split_bwd = 0;  // ASURF_NO_SPLIT_BWD: the one-kernel replay
     int eval_walk = 0;     // ASURF_EVAL=walk: the stepping evaluation renders
     int timeline = 0;      // ASURF_TIMELINE = kernel id (instrumented build)
+    int sweep_block = 0;   // ASURF_SWEEP=block: the block-synchronous form of k_sweep (round 2)
+    int sweep_wpb = 0;     // ASURF_SWEEP_WPB = 1, 2, 4: waves per block of k_sweep_wave (measurement)
+    int sweep_rpw = 0;     // ASURF_SWEEP_RPW = 2, 4, 8, 16: rays per wave of k_sweep_wave (0: by batch size)
 };
 #ifdef ASURF_INSTRUMENT
 constexpr int kDebugMask = 1 | 2 | 4 | 8 | 16 | 32 | (7 << 8);
@@ -80,6 +83,9 @@ bool config_assign(Config& c, const char* name, const char* value) {
     else if (!strcmp(name, "ASURF_NO_SPLIT_BWD")) c.no_split_bwd = n ? 1 : 0;
     else if (!strcmp(name, "ASURF_EVAL")) c.eval_walk = (value && !strcmp(value, "walk")) ? 1 : 0;
     else if (!strcmp(name, "ASURF_TIMELINE")) c.timeline = n;
+    else if (!strcmp(name, "ASURF_SWEEP")) c.sweep_block = (value && !strcmp(value, "block")) ? 1 : 0;
+    else if (!strcmp(name, "ASURF_SWEEP_WPB")) c.sweep_wpb = (n == 1 || n == 2 || n == 4) ? n : 0;
+    else if (!strcmp(name, "ASURF_SWEEP_RPW")) c.sweep_rpw = (n == 2 || n == 4 || n == 8 || n == 16) ? n : 0;
     else return false;
     return true;
 }
@@ -88,7 +94,7 @@ Config config() {  // a copy: a call works with one consistent set
     std::call_once(g_cfg_once, [] {
         static const char* const names[] = {"ASURF_DEBUG", "ASURF_WALK_SEG", "ASURF_WALK", "ASURF_RPW", "ASURF_NO_PIPELINE",
                                             "ASURF_CUVOL_RPW", "ASURF_NO_REPLAY", "ASURF_NO_SPLIT_BWD", "ASURF_EVAL",
-                                            "ASURF_TIMELINE"};
+                                            "ASURF_TIMELINE", "ASURF_SWEEP", "ASURF_SWEEP_WPB", "ASURF_SWEEP_RPW"};
         std::lock_guard<std::mutex> lock(g_cfg_mu);
         for (const char* nm : names)
             if (const char* v = getenv(nm)) config_assign(g_cfg, nm, v);
@@ -603,6 +609,7 @@ int find_candidates(const Launch& L, const asurf_rays* rays, bool record, PipeBu
         P.band_rays = L.ML.band_rays;
         // (P.counters: zeroed in prepare(), with the occupancy pass of this call)
         const int seg = walk_segments(Q);
+        const Config cfgc = config();
         if (L.sweep) {
             int nbmax = 1;
             for (int k = 0; k < 3; ++k) nbmax = std::max(nbmax, ((L.g.size[k] - 2) >> 3) + 1);
@@ -614,6 +621,7 @@ int find_candidates(const Launch& L, const asurf_rays* rays, bool record, PipeBu
             // 16 rays per block whatever the grid: the block's fixed costs -- barriers, set-up, allocation -- are per
             // block (8 rays at 512^3 and 768^3, as the 512 pairs of round 2's first half allowed: k_sweep 0.62 against
             // 0.51 ms at 512^3, 3.39 against 3.05 at 768^3)
+            if (cfgc.sweep_block) {
             const int rpb = 16;
             const int sweep_threads = std::min(kSweepThreads, std::max(64, rpb << lpr_log2));
             // at least 128 keys per ray: a ray that finds more is handed to the one-kernel path, whose latency
@@ -625,6 +633,24 @@ int find_candidates(const Launch& L, const asurf_rays* rays, bool record, PipeBu
             const dim3 sgrid((unsigned)((Q + rpb - 1) / rpb));
             hipLaunchKernelGGL(k_sweep, sgrid, dim3(sweep_threads), lds, L.stream, L.g, L.o, rays->origins,
                                rays->dirs, Q, P, lpr_log2, rpb, K, record ? 1 : 0, task_cap, nbmax);
+            } else {
+                // the wave-autonomous form: a wave owns 16 rays; its LDS slice holds their set-up, a task list and a
+                // key buffer shared by the rays (asurf_sweep.h)
+                // rays per wave: 16 when the batch fills the chip several times over; fewer below, where the kernel
+                // lasts as long as ONE wave's chain of phases (k_sweep at 5 184 rays, 16 / 8 / 4 / 2 rays a wave: 0.035 / 0.024 / 0.021 / 0.021 ms;
+                // at 65 536 rays 0.052 / 0.054 / 0.064 / 0.091)
+                const int rpw = cfgc.sweep_rpw ? cfgc.sweep_rpw : (Q <= 8192 ? 4 : (Q <= 32768 ? 8 : kSweepWaveRays));
+                const int task_cap = std::min(std::max(rpw * nbmax * 3 / 4, 128), 1536);
+                const int key_cap = std::max((nbmax > 64 ? 2048 : (nbmax > 32 ? 1280 : 768)) * rpw / kSweepWaveRays, 256);
+                const int wave_bytes = (int)((size_t)rpw * sizeof(SweepRay) + (size_t)task_cap * 4 + (size_t)key_cap * 4 +
+                                             sizeof(SweepWaveMisc));
+                const long long waves = (Q + rpw - 1) / rpw;
+                const int wpb = cfgc.sweep_wpb ? cfgc.sweep_wpb : kSweepWavesPerBlock;
+                const dim3 sgrid((unsigned)((waves + wpb - 1) / wpb));
+                hipLaunchKernelGGL(k_sweep_wave, sgrid, dim3(64 * wpb), (size_t)wave_bytes * wpb,
+                                   L.stream, L.g, L.o, rays->origins, rays->dirs, Q, P, nbmax, record ? 1 : 0, task_cap,
+                                   key_cap, wave_bytes, rpw);
+            }
         } else if (seg > 1) {
             const dim3 seg_grid((unsigned)((Q * seg + kBlock - 1) / kBlock));
 #define ASURF_WALK_SEG(S_)                                                                                   \

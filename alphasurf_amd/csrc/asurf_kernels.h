@@ -613,6 +613,12 @@ __device__ __forceinline__ bool walk_cut_before(const KGrid& g, const Ray& r, fl
                                                 const int* v, const float* tc_v) {
     int c[3] = {v[0], v[1], v[2]};
     float tc[3] = {tc_v[0], tc_v[1], tc_v[2]};
+    // The ray's components as plain values.  Selected among by `best` straight out of the struct, the compiler turns
+    // the selects of loads into ONE load at a selected address -- an indexed access that pins the caller's whole Ray
+    // in scratch memory (36 bytes a lane, written for every entry of k_sweep's phase 3 although this function runs
+    // for a handful).  The empty asm makes them values it cannot trace back to memory.
+    float ox = r.o[0], oy = r.o[1], oz = r.o[2], dx = r.d[0], dy = r.d[1], dz = r.d[2];
+    asm volatile("" : "+v"(ox), "+v"(oy), "+v"(oz), "+v"(dx), "+v"(dy), "+v"(dz));
     for (int guard = 0; guard < 4096; ++guard) {
         int best = -1;
         float T = 0.f;
@@ -626,8 +632,8 @@ __device__ __forceinline__ bool walk_cut_before(const KGrid& g, const Ray& r, fl
         if (best < 0) return false;               // reached the start voxel
         if (!(T + step_size > r.tmax)) return false;
         // (indexing r.d / c by `best` would put them in scratch: select instead)
-        const float o_b = best == 0 ? r.o[0] : (best == 1 ? r.o[1] : r.o[2]);
-        const float d_b = best == 0 ? r.d[0] : (best == 1 ? r.d[1] : r.d[2]);
+        const float o_b = best == 0 ? ox : (best == 1 ? oy : oz);
+        const float d_b = best == 0 ? dx : (best == 1 ? dy : dz);
         const int s = (d_b > 0.f) ? 1 : -1;
         const int p0 = c[0] - (best == 0 ? s : 0), p1 = c[1] - (best == 1 ? s : 0), p2 = c[2] - (best == 2 ? s : 0);
         if (!links_present_at(g, p0, p1, p2)) return true;

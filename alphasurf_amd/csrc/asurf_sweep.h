@@ -463,4 +463,486 @@ k_sweep(KGrid g, KOpt o, const float* __restrict__ origins, const float* __restr
     tl.end();
 }
 
+
+// ------------------------------------------------------------------------------------------------------------------
+// k_sweep, wave-autonomous form (round 3).  Same search, same closed forms, same tables as the block form above; what
+// changes is who waits for whom.  The block form strides the (ray, layer) pairs, the tasks and the hits of 16 rays over
+// 256 threads with a barrier between phases: a hundred tasks occupy four waves at 40 % of their lanes, phases 0 and 4
+// run on 16 of 256 threads while the rest wait, and every task and every hit takes a same-address LDS atomic with return.
+// Here a WAVE owns its rays (16 of them) from the first load to the last store: its own slice of LDS, no block barrier
+// anywhere (waves of a block never meet), and every list is built by ordered compaction -- per-lane counts, one DPP
+// prefix scan, each lane writes at its offset:
+//   * a hundred tasks are two full wave iterations instead of four partial ones (phase 2 and 3 halve);
+//   * tasks come out in (ray, layer) order and hits in task order, so a ray's hits are CONTIGUOUS: no per-ray key
+//     buffers (the rays share one buffer), no atomics with return;
+//   * waves drift apart in time, so one wave's set-up or allocation round trip runs under another's bit tests.
+// A wave whose tasks or hits do not fit takes its rays in smaller groups (a quarter, then one at a time); a single ray
+// that does not fit on its own is handed to the one-kernel path.
+// ------------------------------------------------------------------------------------------------------------------
+constexpr int kSweepWaveRays = 16;       // rays per wave, at most (fewer when the batch is small: sweep_wave_rays)
+constexpr int kSweepWavesPerBlock = 1;   // (1 / 2 / 4 waves a block: 0.305 / 0.313 / 0.322 ms at config 2 -- a block's LDS is held until its last
+                                         // wave ends; at 6 waves per SIMD -- 79 registers, 12 bytes of scratch -- 0.311)
+
+struct SweepWaveMisc {
+    int cnt[kSweepWaveRays];        // hits found per ray
+    int start[kSweepWaveRays + 1];  // first hit of the ray in the wave's key buffer
+    int n[kSweepWaveRays];          // hits that pass the exact test (0 when handed back)
+    int spb[kSweepWaveRays];        // spill base
+    int hand[kSweepWaveRays];       // 1: handed back
+    int slot0[64];                  // first list cell of each table slot
+    int pad[3];
+};
+static_assert(sizeof(SweepWaveMisc) % 16 == 0, "the waves' LDS slices stay 16-byte aligned");
+
+// cross-lane hand-over through the wave's own LDS slice: LDS operations of a wave execute in order; the compiler must
+// not move them across this point, and the data must have landed
+__device__ __forceinline__ void sweep_wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
+// inclusive prefix sum over the 64 lanes (all active): DPP row shifts + the two row broadcasts (wave_sum's sequence
+// IS the scan: after the four shifts a lane holds the prefix within its row of 16, the broadcasts add the rows in front)
+__device__ __forceinline__ int wave_incl_scan(int v) {
+#define ASURF_DPP_IADD(ctrl, row_mask) v += __builtin_amdgcn_update_dpp(0, v, ctrl, row_mask, 0xf, false)
+    ASURF_DPP_IADD(0x111, 0xf);
+    ASURF_DPP_IADD(0x112, 0xf);
+    ASURF_DPP_IADD(0x114, 0xf);
+    ASURF_DPP_IADD(0x118, 0xf);
+    ASURF_DPP_IADD(0x142, 0xa);
+    ASURF_DPP_IADD(0x143, 0xc);
+#undef ASURF_DPP_IADD
+    return v;
+}
+
+__device__ __forceinline__ int list_segment_unit(const PipeBuf& P, unsigned unit, int rays_per_unit) {
+    const unsigned nbb = (unsigned)(P.band_rays / rays_per_unit);
+    const unsigned band = unit / nbb, in_band = unit - band * nbb;
+    return (int)(band % kListGroups) * kListShards + (int)((in_band + band / kListGroups) % kListShards);
+}
+
+__global__ void __launch_bounds__(256)
+k_sweep_wave(KGrid g, KOpt o, const float* __restrict__ origins, const float* __restrict__ dirs, long long Q,
+             PipeBuf P, int n_layers, int want_cut, int task_cap, int key_cap, int wave_bytes, int rpw) {
+    extern __shared__ uint4 s_dyn4[];
+    const TlScope tl(2);
+    const int lane = threadIdx.x & 63;
+    const int wib = threadIdx.x >> 6;
+    const unsigned unit = blockIdx.x * (blockDim.x >> 6) + wib;   // this wave's number
+    const long long q0 = (long long)unit * rpw;
+    if (q0 >= Q) return;   // (no barrier anywhere below: a wave may leave on its own)
+    char* const base = reinterpret_cast<char*>(s_dyn4) + (size_t)wib * wave_bytes;
+    SweepRay* const s_ray = reinterpret_cast<SweepRay*>(base);
+    unsigned* const s_task = reinterpret_cast<unsigned*>(s_ray + rpw);   // ray << 21 | layer << 14 | brick b << 7 | brick c
+    unsigned* const s_key = s_task + task_cap;
+    SweepWaveMisc* const M = reinterpret_cast<SweepWaveMisc*>(s_key + key_cap);
+    const float kEps = 1.f / 256.f;
+
+    // ---- phase 0: lane = ray ----
+    if (lane < rpw) {
+        SweepRay R;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            R.o[k] = R.d[k] = 0.f;
+            R.n0[k] = 0;
+        }
+        R.tmin = R.tmax = 0.f;
+        R.pad2 = 0;
+        R.rd[0] = R.rd[1] = R.rd[2] = 0.f;
+        R.fast_div = 0;
+        R.oa = R.ob = R.oc = R.sb = R.sc = 0.f;
+        R.ulo = 1.f;
+        R.uhi = 0.f;
+        R.flags = 0;
+        R.size_a = R.size_b = R.size_c = 2;
+        R.na = 0;
+        R.cs_a = R.cs_b = R.cs_c = R.bs_a = R.bs_b = R.bs_c = 0;
+        R.state = 0;
+        R.pad = 0;
+        const long long q = q0 + lane;
+        if (q < Q) {
+            Ray r;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                r.o[k] = origins[3 * q + k];
+                r.d[k] = dirs[3 * q + k];
+            }
+            setup_ray(g, o, r);
+            const bool hits_grid = !(r.tmin > r.tmax);
+            if (hits_grid && !ray_is_regular(r)) {
+                R.state = 2;
+            } else if (hits_grid) {
+                R.state = 1;
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    R.o[k] = r.o[k];
+                    R.d[k] = r.d[k];
+                }
+                R.tmin = r.tmin;
+                R.tmax = r.tmax;
+                walk_start(g, r, R.n0);
+#pragma unroll
+                for (int k = 0; k < 3; ++k) R.rd[k] = 1.f / r.d[k];
+                R.fast_div = fmaxf(fmaxf(fabsf(R.rd[0]), fabsf(R.rd[1])), fabsf(R.rd[2])) < 1e30f ? 1 : 0;
+                const float ax = fabsf(r.d[0]), ay = fabsf(r.d[1]), az = fabsf(r.d[2]);
+                const int a = (ax >= ay && ax >= az) ? 0 : (ay >= az ? 1 : 2);
+                // cyclic order: (a, b, c) = (0,1,2), (1,2,0), (2,0,1)
+                const float da = a == 0 ? r.d[0] : (a == 1 ? r.d[1] : r.d[2]);
+                const float db = a == 0 ? r.d[1] : (a == 1 ? r.d[2] : r.d[0]);
+                const float dc = a == 0 ? r.d[2] : (a == 1 ? r.d[0] : r.d[1]);
+                R.oa = a == 0 ? r.o[0] : (a == 1 ? r.o[1] : r.o[2]);
+                R.ob = a == 0 ? r.o[1] : (a == 1 ? r.o[2] : r.o[0]);
+                R.oc = a == 0 ? r.o[2] : (a == 1 ? r.o[0] : r.o[1]);
+                R.sb = db / da;
+                R.sc = dc / da;
+                const float u0 = fmaf(r.tmin, da, R.oa), u1 = fmaf(r.tmax, da, R.oa);
+                R.ulo = fminf(u0, u1) - 2.f * kEps;
+                R.uhi = fmaxf(u0, u1) + 2.f * kEps;
+                R.flags = a | (da < 0.f ? 4 : 0) | (db < 0.f ? 8 : 0) | (dc < 0.f ? 16 : 0) | 32;
+                const int sx = g.size[0], sy = g.size[1], sz = g.size[2];
+                R.size_a = a == 0 ? sx : (a == 1 ? sy : sz);
+                R.size_b = a == 0 ? sy : (a == 1 ? sz : sx);
+                R.size_c = a == 0 ? sz : (a == 1 ? sx : sy);
+                R.na = ((R.size_a - 2) >> 3) + 1;
+                // coarse bitmap: bit index = (bx * nb1 + by) * (nwz * 32) + bz
+                const int cX = g.nb[1] * g.nwz * 32, cY = g.nwz * 32, cZ = 1;
+                R.cs_a = a == 0 ? cX : (a == 1 ? cY : cZ);
+                R.cs_b = a == 0 ? cY : (a == 1 ? cZ : cX);
+                R.cs_c = a == 0 ? cZ : (a == 1 ? cX : cY);
+                const int bX = g.nb[1] * g.nb[2], bY = g.nb[2], bZ = 1;
+                R.bs_a = a == 0 ? bX : (a == 1 ? bY : bZ);
+                R.bs_b = a == 0 ? bY : (a == 1 ? bZ : bX);
+                R.bs_c = a == 0 ? bZ : (a == 1 ? bX : bY);
+            }
+        }
+        s_ray[lane] = R;
+        M->hand[lane] = (q < Q && R.state == 2) ? 1 : 0;
+    }
+    sweep_wave_sync();
+
+    const float inv_layers = 1.f / (float)n_layers;
+    int group = rpw;   // rays taken together; shrinks when the wave's lists overflow
+    for (int r_lo = 0; r_lo < rpw;) {
+        const int r_hi = min(r_lo + group, rpw);
+        // ---- phase 1: lane = (ray, brick layer) -> tasks, in (ray, layer) order ----
+        int ntask = 0;   // (wave-uniform)
+        const int pair_lo = r_lo * n_layers, pair_hi = r_hi * n_layers;
+        for (int lt0 = pair_lo; lt0 < pair_hi; lt0 += 64) {
+            const int lt = lt0 + lane;
+            const int rl = min((int)(((float)lt + 0.5f) * inv_layers), rpw - 1), A = lt - rl * n_layers;
+            unsigned m9 = 0u;   // which of the <= 3 x 3 bricks of the footprint hold a flagged voxel
+            int bl = 0, cl = 0;
+            if (lt < pair_hi) {
+                const SweepRay& R = s_ray[rl];
+                if (R.state == 1 && M->hand[rl] == 0 && A < R.na) {
+                    const float ulo = R.ulo, uhi = R.uhi, oa = R.oa;
+                    float L = (A == 0) ? -1e30f : (float)(8 * A) - kEps;
+                    float U = (A == R.na - 1) ? 1e30f : (float)(8 * A + 8) + kEps;
+                    L = fmaxf(L, ulo);
+                    U = fminf(U, uhi);
+                    if (L <= U) {
+                        const float sb = R.sb, sc = R.sc, ob = R.ob, oc = R.oc;
+                        const int size_b = R.size_b, size_c = R.size_c;
+                        const float bL = fmaf(L - oa, sb, ob), bU = fmaf(U - oa, sb, ob);
+                        const float cL = fmaf(L - oa, sc, oc), cU = fmaf(U - oa, sc, oc);
+                        bl = sweep_clampi((int)floorf(fminf(bL, bU) - kEps), 0, size_b - 2) >> 3;
+                        const int bh = sweep_clampi((int)floorf(fmaxf(bL, bU) + kEps), 0, size_b - 2) >> 3;
+                        cl = sweep_clampi((int)floorf(fminf(cL, cU) - kEps), 0, size_c - 2) >> 3;
+                        const int ch = sweep_clampi((int)floorf(fmaxf(cL, cU) + kEps), 0, size_c - 2) >> 3;
+                        const int cs_b = R.cs_b, cs_c = R.cs_c;
+                        const int lin0 = __mul24(A, R.cs_a) + __mul24(bl, cs_b) + __mul24(cl, cs_c);
+                        // 0 .. 2: the footprint of one layer is at most 8 slabs + the box's half voxel + the margins long
+                        // and the slopes are <= 1, so it spans less than two bricks' lengths
+                        const int nb_ = min(bh - bl, 2), nc_ = min(ch - cl, 2);
+                        // the 2 x 2 corner first, its four bits asked for together; a third row or column is rare
+                        const int l00 = lin0, l01 = lin0 + cs_c, l10 = lin0 + cs_b, l11 = lin0 + cs_b + cs_c;
+                        const unsigned w00 = g.coarse[l00 >> 5];
+                        const unsigned w01 = nc_ >= 1 ? g.coarse[l01 >> 5] : 0u;
+                        const unsigned w10 = nb_ >= 1 ? g.coarse[l10 >> 5] : 0u;
+                        const unsigned w11 = (nb_ >= 1 && nc_ >= 1) ? g.coarse[l11 >> 5] : 0u;
+                        m9 = ((w00 >> (l00 & 31)) & 1u) | (((w01 >> (l01 & 31)) & 1u) << 1) |
+                             (((w10 >> (l10 & 31)) & 1u) << 3) | (((w11 >> (l11 & 31)) & 1u) << 4);
+                        if (nb_ == 2 || nc_ == 2) {
+                            for (int ib = 0; ib <= nb_; ++ib)
+                                for (int ic = 0; ic <= nc_; ++ic) {
+                                    if (ib < 2 && ic < 2) continue;
+                                    const int lin = lin0 + __mul24(ib, cs_b) + __mul24(ic, cs_c);
+                                    m9 |= ((g.coarse[lin >> 5] >> (lin & 31)) & 1u) << (3 * ib + ic);
+                                }
+                        }
+                    }
+                }
+            }
+            const int cnt = __popc(m9);
+            const int incl = wave_incl_scan(cnt);
+            const int total = bcast_i(incl, 63);
+            if (total == 0) continue;   // (wave-uniform)
+            int at = ntask + incl - cnt;
+            if (ntask + total <= task_cap) {
+                unsigned m = m9;
+                while (m) {
+                    const int bit = __ffs((int)m) - 1;
+                    m &= m - 1u;
+                    const int ib = bit / 3, ic = bit - 3 * ib;
+                    s_task[at++] = ((unsigned)rl << 21) | ((unsigned)A << 14) | ((unsigned)(bl + ib) << 7) | (unsigned)(cl + ic);
+                }
+            }
+            ntask += total;
+        }
+        if (ntask > task_cap) {   // (wave-uniform)
+            if (group > 1) {
+                group = max(1, group >> 2);
+                continue;
+            }
+            if (lane == 0) M->hand[r_lo] = 1;   // one ray alone does not fit: the one-kernel path takes it
+            sweep_wave_sync();
+            ntask = 0;
+        }
+        sweep_wave_sync();
+
+        // ---- phase 2: lane = task.  The brick's 8 words; per slab the rectangle mask of the cells between the ray's
+        // positions at the slab's two planes; the hits of all tasks in task order (= ray order) ----
+        if (lane < rpw) M->cnt[lane] = 0;
+        sweep_wave_sync();
+        int nkey = 0;   // (wave-uniform)
+        bool key_overflow = false;
+        for (int t0 = 0; t0 < ntask; t0 += 64) {
+            const int ti = t0 + lane;
+            unsigned long long h[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) h[k] = 0ull;
+            int rl = 0, A = 0, Bb = 0, Bc = 0;
+            int fl = 0;
+            if (ti < ntask) {
+                const unsigned task = s_task[ti];
+                rl = (int)(task >> 21);
+                A = (int)((task >> 14) & 127);
+                Bb = (int)((task >> 7) & 127);
+                Bc = (int)(task & 127);
+                const SweepRay& R = s_ray[rl];
+                fl = R.flags;
+                const int a = fl & 3;
+                const unsigned long long* plane = a == 0 ? g.fine : (a == 1 ? g.fine_y : g.fine_z);
+                const int brick = __mul24(A, R.bs_a) + __mul24(Bb, R.bs_b) + __mul24(Bc, R.bs_c);
+                const ulonglong2* wp = reinterpret_cast<const ulonglong2*>(plane + (size_t)brick * 8);
+                const ulonglong2 w01 = wp[0], w23 = wp[1], w45 = wp[2], w67 = wp[3];
+                const unsigned long long words[8] = {w01.x, w01.y, w23.x, w23.y, w45.x, w45.y, w67.x, w67.y};
+                const float ulo = R.ulo, uhi = R.uhi, oa = R.oa, sb = R.sb, sc = R.sc;
+                const int i0 = 8 * A, last = R.size_a - 2;
+                // brick-local coordinates; the lattice's clamp [0, size - 2] in them
+                const float bo = R.ob - (float)(8 * Bb), co = R.oc - (float)(8 * Bc);
+                const int bmin = -8 * Bb, bmax = R.size_b - 2 - 8 * Bb, cmin = -8 * Bc, cmax = R.size_c - 2 - 8 * Bc;
+                const float kEps2 = 2.f * kEps;  // kEps on the plane's position along a (slopes <= 1) + kEps on b / c
+                // plane 0 (the lattice's first slab reaches back to the ray's start, its last one on to the ray's end)
+                float praw = (i0 == 0) ? -1e30f : (float)i0;
+                float pu = fminf(fmaxf(praw, ulo), uhi);
+                float pb = fmaf(pu - oa, sb, bo), pc = fmaf(pu - oa, sc, co);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const int i = i0 + k;
+                    const float qraw = (i >= last) ? 1e30f : (float)(i + 1);
+                    const float qu = fminf(fmaxf(qraw, ulo), uhi);
+                    const float qb = fmaf(qu - oa, sb, bo), qc = fmaf(qu - oa, sc, co);
+                    const bool live = (i <= last) && (words[k] != 0ull) && (praw <= uhi) && (qraw >= ulo);
+                    const int lb0 = max(sweep_clampi((int)floorf(fminf(pb, qb) - kEps2), bmin, bmax), 0);
+                    const int lb1 = min(sweep_clampi((int)floorf(fmaxf(pb, qb) + kEps2), bmin, bmax), 7);
+                    const int lc0 = max(sweep_clampi((int)floorf(fminf(pc, qc) - kEps2), cmin, cmax), 0);
+                    const int lc1 = min(sweep_clampi((int)floorf(fmaxf(pc, qc) + kEps2), cmin, cmax), 7);
+                    praw = qraw;
+                    pb = qb;
+                    pc = qc;
+                    if (live && lb0 <= lb1 && lc0 <= lc1) {
+                        const unsigned long long rows = (2ull << (8 * lb1 + 7)) - (1ull << (8 * lb0));
+                        const unsigned pat = ((2u << lc1) - (1u << lc0)) & 0xffu;
+                        const unsigned rep = pat * 0x01010101u;
+                        h[k] = words[k] & rows & (((unsigned long long)rep << 32) | rep);
+                    }
+                }
+            }
+            int cnt = 0;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) cnt += __popcll(h[k]);
+            const int incl = wave_incl_scan(cnt);
+            const int total = bcast_i(incl, 63);
+            if (total == 0) continue;   // (wave-uniform)
+            if (nkey + total > key_cap) {
+                key_overflow = true;
+                break;
+            }
+            if (cnt > 0) {
+                atomicAdd(&M->cnt[rl], cnt);   // (no return value: ds_add_u32)
+                int at = nkey + incl - cnt;
+                const int rka = (fl & 4) ? 1023 : 0, rkb = (fl & 8) ? 1023 : 0, rkc = (fl & 16) ? 1023 : 0;
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    unsigned long long hk = h[k];
+                    const int i = 8 * A + k;
+                    while (hk) {
+                        const int bit = __ffsll((long long)hk) - 1;
+                        hk &= hk - 1ull;
+                        const int ib = 8 * Bb + (bit >> 3), ic = 8 * Bc + (bit & 7);
+                        s_key[at++] = ((unsigned)(rka ^ i) << 20) | ((unsigned)(rkb ^ ib) << 10) | (unsigned)(rkc ^ ic);
+                    }
+                }
+            }
+            nkey += total;
+        }
+        if (key_overflow) {   // (wave-uniform)
+            if (group > 1) {
+                group = max(1, group >> 2);
+                continue;
+            }
+            if (lane == 0) M->hand[r_lo] = 1;
+            nkey = 0;
+            if (lane < rpw) M->cnt[lane] = 0;
+        }
+        sweep_wave_sync();
+
+        // ---- the rays' slices of the key buffer ----
+        {
+            const int c = (lane < rpw) ? M->cnt[lane] : 0;
+            const int incl = wave_incl_scan(c);
+            if (lane < rpw) {
+                M->start[lane] = incl - c;
+                M->n[lane] = 0;
+            }
+            if (lane == rpw - 1) M->start[rpw] = incl;
+        }
+        sweep_wave_sync();
+
+        // ---- phase 3: exact membership, lane = hit ----
+        for (int t0 = 0; t0 < nkey; t0 += 64) {
+            const int t = t0 + lane;
+            if (t < nkey) {
+                int rl = r_lo;  // the ray whose slice holds t
+#pragma unroll
+                for (int step = kSweepWaveRays / 2; step >= 1; step >>= 1)
+                    if (rl + step < r_hi && M->start[rl + step] <= t) rl += step;
+                unsigned key = s_key[t];
+                const SweepRay& R = s_ray[rl];
+                const int f = R.flags, a = f & 3;
+                const int ra = (int)(key >> 20), rb = (int)((key >> 10) & 1023), rc = (int)(key & 1023);
+                const int ia = (f & 4) ? 1023 - ra : ra, ib = (f & 8) ? 1023 - rb : rb, ic = (f & 16) ? 1023 - rc : rc;
+                // (a, b, c) -> (x, y, z)
+                const int vv[3] = {a == 0 ? ia : (a == 1 ? ic : ib), a == 0 ? ib : (a == 1 ? ia : ic),
+                                   a == 0 ? ic : (a == 1 ? ib : ia)};
+                Ray r;
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    r.o[k] = R.o[k];
+                    r.d[k] = R.d[k];
+                }
+                r.tmin = R.tmin;
+                r.tmax = R.tmax;
+                const int n0[3] = {R.n0[0], R.n0[1], R.n0[2]};
+                float tc[3], tf[3], t_entry;
+                if (R.fast_div) {  // the IEEE quotients, three instructions each (quotient(), asurf_kernels.h)
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) {
+                        const int up = r.d[k] > 0.f ? 1 : 0;
+                        const float rdk = R.rd[k];
+                        tc[k] = quotient((float)(vv[k] + 1 - up) - r.o[k], r.d[k], rdk);
+                        tf[k] = quotient((float)(vv[k] + up) - r.o[k], r.d[k], rdk);
+                    }
+                } else {
+                    voxel_times(r, vv[0], vv[1], vv[2], tc, tf);
+                }
+                if (walk_visits(r, n0, vv, tc, tf, &t_entry)) {
+                    atomicAdd(&M->n[rl], 1);
+                    if (want_cut && (t_entry + o.step_size > r.tmax) &&
+                        walk_cut_before(g, r, o.step_size, n0, vv, tc))
+                        key |= kSweepCutBit;
+                } else {
+                    key = kSweepDropped;
+                }
+                s_key[t] = key;
+            }
+        }
+        sweep_wave_sync();
+
+        // ---- phase 4: per ray, counts and allocations ----
+        if (lane >= r_lo && lane < r_hi) {
+            const long long q = q0 + lane;
+            int n = 0, spb = 0;
+            if (q < Q) {
+                bool handback = M->hand[lane] != 0;
+                n = handback ? 0 : M->n[lane];
+                if (n > P.C1) {
+                    const int extra = n - P.C1;
+                    spb = atomicAdd(&P.counters[1], extra);
+                    if (spb + extra > P.sp_cap) {  // spill list exhausted
+                        for (int e = spb; e < min(spb + extra, P.sp_cap); ++e) P.sp_ray[e] = -1;
+                        handback = true;
+                        n = 0;
+                    }
+                }
+                if (handback) P.flagged[atomicAdd(&P.counters[0], 1)] = (int)q;
+                P.n_items[q] = handback ? -1 : n;
+                P.cut[q] = 0x7fffffff;
+                P.sp_base[q] = spb;
+                P.cand_mask[q] = 0ull;
+            }
+            M->n[lane] = n;
+            M->spb[lane] = spb;
+        }
+        sweep_wave_sync();
+        // the group's cells of the dense list are laid out SLOT-major -- all rays' slot 0, then slot 1, ... -- so that
+        // neighbouring lanes of k_geom hold neighbouring rays at the same depth (slot0[s]: first cell of slot s)
+        int lbase;
+        {
+            int c = 0;  // rays that fill slot `lane`
+            if (lane < P.C1)
+                for (int r2 = r_lo; r2 < r_hi; ++r2) c += (M->n[r2] > lane) ? 1 : 0;
+            const int ci = wave_incl_scan(c);
+            M->slot0[lane] = ci - c;
+            const int cells = bcast_i(ci, 63);
+            int lb = 0;
+            const int shard = list_segment_unit(P, unit, rpw);
+            if (lane == 0 && cells > 0) lb = atomicAdd(&P.counters[kCtrListShard0 + shard * kCtrShardStride], cells);
+            lbase = shard * P.list_cap + bcast_i(lb, 0);
+        }
+        // (P.cut was stored by other lanes of this wave than the ones that lower it below: the stores must have left)
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        sweep_wave_sync();
+
+        // ---- phase 5: per surviving entry, its rank among the ray's keys is its slot ----
+        for (int t0 = 0; t0 < nkey; t0 += 64) {
+            const int t = t0 + lane;
+            if (t >= nkey) continue;
+            int rl = r_lo;
+#pragma unroll
+            for (int step = kSweepWaveRays / 2; step >= 1; step >>= 1)
+                if (rl + step < r_hi && M->start[rl + step] <= t) rl += step;
+            const unsigned key = s_key[t];
+            if (key == kSweepDropped || M->n[rl] == 0) continue;  // n == 0: ray handed back
+            const unsigned kk = key & ~kSweepCutBit;
+            const int k_lo = M->start[rl], k_hi = M->start[rl + 1];
+            int ord = 0;  // (a dropped key has bit 31 set: larger than every kept one)
+            for (int j = k_lo; j < k_hi; ++j) ord += ((s_key[j] & ~kSweepCutBit) < kk) ? 1 : 0;
+            const int f = s_ray[rl].flags, a = f & 3;
+            const int ra = (int)((kk >> 20) & 1023), rb = (int)((kk >> 10) & 1023), rc = (int)(kk & 1023);
+            const int ia = (f & 4) ? 1023 - ra : ra, ib = (f & 8) ? 1023 - rb : rb, ic = (f & 16) ? 1023 - rc : rc;
+            const int vx = a == 0 ? ia : (a == 1 ? ic : ib);
+            const int vy = a == 0 ? ib : (a == 1 ? ia : ic);
+            const int vz = a == 0 ? ic : (a == 1 ? ib : ia);
+            const int voxel = pack_voxel(vx, vy, vz);
+            const long long q = q0 + rl;
+            if (key & kSweepCutBit) atomicMin(&P.cut[q], ord);  // rare
+            if (ord < P.C1) {
+                int before = 0;  // rays in front of this one that fill slot `ord` too
+                for (int r2 = r_lo; r2 < rl; ++r2) before += (M->n[r2] > ord) ? 1 : 0;
+                P.items[(size_t)ord * Q + q] = voxel;
+                P.list[lbase + M->slot0[ord] + before] = ((unsigned)ord << kListRayBits) | (unsigned)q;
+            } else {
+                const int at = M->spb[rl] + ord - P.C1;
+                P.sp_items[at] = voxel;
+                P.sp_ray[at] = (int)q;
+            }
+        }
+        sweep_wave_sync();
+        r_lo = r_hi;
+    }
+    tl.end();
+}
+
 }  // namespace asurf
