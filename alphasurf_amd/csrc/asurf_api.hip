@@ -19,6 +19,7 @@
 #include "asurf_optim.h"
 #include "asurf_pipeline.h"
 #include "asurf_sweep.h"
+#include "asurf_masks2.h"
 #include "asurf_bwd_pipeline.h"
 #include "asurf_legacy.h"
 #include "asurf_reg.h"
@@ -58,6 +59,7 @@ struct Config {
     int no_split_bwd = 0;  // ASURF_NO_SPLIT_BWD: the one-kernel replay
     int eval_walk = 0;     // ASURF_EVAL=walk: the stepping evaluation renders
     int timeline = 0;      // ASURF_TIMELINE = kernel id (instrumented build)
+    int masks_row = 0;     // ASURF_MASKS=row: the one-pass occupancy kernel (k_build_masks) instead of the two stages
     int sweep_block = 0;   // ASURF_SWEEP=block: the block-synchronous form of k_sweep (round 2)
     int sweep_wpb = 0;     // ASURF_SWEEP_WPB = 1, 2, 4: waves per block of k_sweep_wave (measurement)
     int sweep_rpw = 0;     // ASURF_SWEEP_RPW = 2, 4, 8, 16: rays per wave of k_sweep_wave (0: by batch size)
@@ -83,6 +85,7 @@ bool config_assign(Config& c, const char* name, const char* value) {
     else if (!strcmp(name, "ASURF_NO_SPLIT_BWD")) c.no_split_bwd = n ? 1 : 0;
     else if (!strcmp(name, "ASURF_EVAL")) c.eval_walk = (value && !strcmp(value, "walk")) ? 1 : 0;
     else if (!strcmp(name, "ASURF_TIMELINE")) c.timeline = n;
+    else if (!strcmp(name, "ASURF_MASKS")) c.masks_row = (value && !strcmp(value, "row")) ? 1 : 0;
     else if (!strcmp(name, "ASURF_SWEEP")) c.sweep_block = (value && !strcmp(value, "block")) ? 1 : 0;
     else if (!strcmp(name, "ASURF_SWEEP_WPB")) c.sweep_wpb = (n == 1 || n == 2 || n == 4) ? n : 0;
     else if (!strcmp(name, "ASURF_SWEEP_RPW")) c.sweep_rpw = (n == 2 || n == 4 || n == 8 || n == 16) ? n : 0;
@@ -94,7 +97,7 @@ Config config() {  // a copy: a call works with one consistent set
     std::call_once(g_cfg_once, [] {
         static const char* const names[] = {"ASURF_DEBUG", "ASURF_WALK_SEG", "ASURF_WALK", "ASURF_RPW", "ASURF_NO_PIPELINE",
                                             "ASURF_CUVOL_RPW", "ASURF_NO_REPLAY", "ASURF_NO_SPLIT_BWD", "ASURF_EVAL",
-                                            "ASURF_TIMELINE", "ASURF_SWEEP", "ASURF_SWEEP_WPB", "ASURF_SWEEP_RPW"};
+                                            "ASURF_TIMELINE", "ASURF_SWEEP", "ASURF_SWEEP_WPB", "ASURF_SWEEP_RPW", "ASURF_MASKS"};
         std::lock_guard<std::mutex> lock(g_cfg_mu);
         for (const char* nm : names)
             if (const char* v = getenv(nm)) config_assign(g_cfg, nm, v);
@@ -521,30 +524,51 @@ int prepare(const asurf_grid* grid, const asurf_rays* rays, const asurf_render_o
     int cached = mask_cache_lookup(workspace, epoch, grid, L.ML.n_rows, &live_blocks, capturing);
     // building the list allocates pinned memory and reads a counter back: not while a graph is being captured
     if (cached == 0 && capturing) cached = -1;
+    // From vertex bit planes (asurf_masks2.h) for the surf_trav planes with a short level-set list; the per-voxel kernel
+    // for the cuvol plane, longer lists and ASURF_MASKS=row
+    const bool fast = !cuvol && !(need_surf && grid->level_set_num > kMaskFastSets) && !config().masks_row;
+    const int n_sets = need_surf ? grid->level_set_num : 0;
     if (cached == 1) {
         // (a header that is not what the host table says -- a captured full pass of another grid replayed over this
-        // workspace since -- makes the kernel take every row)
-        hipLaunchKernelGGL(k_build_masks_live, dim3((unsigned)live_blocks), dim3(512), 0, L.stream, L.g, opt->sigma_thresh,
-                           mode, fw, fl, cw, cl, L.sweep ? fy : nullptr, L.sweep ? fz : nullptr, use_live ? 1 : 0, nzg, hdr,
-                           live_rows, epoch, L.ML.n_rows, zero_ptr, zero_n);
+        // workspace since -- makes the kernels take every row)
+        if (fast) {
+            const MaskRows R{hdr, live_rows, epoch, L.ML.n_rows, 1};
+            hipLaunchKernelGGL(k_build_masks2, dim3((unsigned)live_blocks), dim3(512), 0, L.stream, L.g, opt->sigma_thresh,
+                               need_surf ? 1 : 0, n_sets, fw, fl, cw, cl, L.sweep ? fy : nullptr, L.sweep ? fz : nullptr,
+                               use_live ? 1 : 0, nzg, R, static_cast<MaskHdr*>(nullptr), static_cast<int*>(nullptr), zero_ptr,
+                               zero_n);
+        } else {
+            hipLaunchKernelGGL(k_build_masks_live, dim3((unsigned)live_blocks), dim3(512), 0, L.stream, L.g, opt->sigma_thresh,
+                               mode, fw, fl, cw, cl, L.sweep ? fy : nullptr, L.sweep ? fz : nullptr, use_live ? 1 : 0, nzg, hdr,
+                               live_rows, epoch, L.ML.n_rows, zero_ptr, zero_n);
+        }
     } else {
         // a full pass rewrites every plane: whatever the header said is void from here on, on this call and on every
         // replay of a graph this call is captured into (the memset is a node of that graph)
         if (hipMemsetAsync(hdr, 0, hdr_and_counters, L.stream) != hipSuccess)
             return fail(ASURF_E_LAUNCH, "hipMemsetAsync(mask header, pipeline counters) failed");
-        if (cached == 0 && epoch != 0ull) {
-            // first call with this value: the full pass, leaving the list (and zeros in EVERY plane of the empty rows)
-            hipLaunchKernelGGL(k_build_masks, dim3((unsigned)L.ML.n_rows), dim3(512), 0, L.stream, L.g, opt->sigma_thresh,
-                               mode, fw, fl, cw, cl, fy, fz, use_live ? 1 : 0, nzg, hdr, live_rows);
-            hipLaunchKernelGGL(k_mask_seal, dim3(1), dim3(1), 0, L.stream, hdr, epoch);
-            mask_cache_store(workspace, epoch, grid, &hdr->n_live, L.stream);
+        // first call with this value: the full pass leaves the list (and zeros in EVERY plane of the empty rows: the
+        // y / z cuts are written whatever this call needs, the list outlives it)
+        const bool leave_list = cached == 0 && epoch != 0ull;
+        unsigned long long* fy_w = (leave_list || L.sweep) ? fy : nullptr;
+        unsigned long long* fz_w = (leave_list || L.sweep) ? fz : nullptr;
+        MaskHdr* hdr_w = leave_list ? hdr : nullptr;
+        int* rows_w = leave_list ? live_rows : nullptr;
+        if (fast) {
+            const MaskRows R{hdr, live_rows, epoch, L.ML.n_rows, 0};
+            hipLaunchKernelGGL(k_build_masks2, dim3((unsigned)L.ML.n_rows), dim3(512), 0, L.stream, L.g, opt->sigma_thresh,
+                               need_surf ? 1 : 0, n_sets, fw, fl, cw, cl, fy_w, fz_w, use_live ? 1 : 0, nzg, R, hdr_w, rows_w,
+                               static_cast<int*>(nullptr), 0);
         } else {
             hipLaunchKernelGGL(k_build_masks, dim3((unsigned)L.ML.n_rows), dim3(512), 0, L.stream, L.g, opt->sigma_thresh,
-                               mode, fw, fl, cw, cl, L.sweep ? fy : nullptr, L.sweep ? fz : nullptr, use_live ? 1 : 0, nzg,
-                               static_cast<MaskHdr*>(nullptr), static_cast<int*>(nullptr));
+                               mode, fw, fl, cw, cl, fy_w, fz_w, use_live ? 1 : 0, nzg, hdr_w, rows_w);
+        }
+        if (leave_list) {
+            hipLaunchKernelGGL(k_mask_seal, dim3(1), dim3(1), 0, L.stream, hdr, epoch);
+            mask_cache_store(workspace, epoch, grid, &hdr->n_live, L.stream);
         }
     }
-    prof_after(cached == 1 ? "k_build_masks_live" : "k_build_masks", 0, L.stream);
+    prof_after(fast ? "k_build_masks2" : (cached == 1 ? "k_build_masks_live" : "k_build_masks"), 0, L.stream);
     return launch_error("k_build_masks");
 }
 

@@ -1,0 +1,268 @@
+// asurf_masks2.h -- the occupancy pyramid from vertex bit planes (round 3).
+//
+// k_build_masks (asurf_kernels.h) decides every voxel from scratch: 8 links, then 8 densities, then 8 surface values,
+// one x-slab after the other -- a wave that holds anything is a chain of 24 dependent round trips, and every vertex
+// value is fetched by the eight voxels around it.  The pass took 0.067 ms at 256^3 in every variant that kept that
+// structure, a third of a call at the training script's batch size.
+// Here the decision is split where the data dependence is:
+//   per VERTEX, what the voxel tests need of it, as bits over runs of 64 vertices along z (a __ballot each): E "the
+//     vertex exists" (link >= 0), B "its density is below sigma_thresh", and per level set G "its surface value is
+//     above the level" and H "... below the level".  A block takes one row of 8 bricks along z -- 8 x 8 vertex columns
+//     of 64 -- plus the halo its voxels reach into: the ninth column along x and y and the next vertex along z.  Every
+//     wave asks for the links of its eleven runs together, then for the values of the vertices that exist, together: two
+//     round trips, whatever the wave holds;
+//   per VOXEL, bit arithmetic.  With P' = P & (P moved by one along z) and all4(P) = the AND of P' over the four (x, y)
+//     neighbours:
+//         live = all4(E) & ~all4(B)                  8 links >= 0, not all 8 densities below (surf_trav.cu:230-239)
+//         work = live & OR_i (~all4(G_i) & ~all4(H_i))     level i neither below the minimum nor above the maximum
+//                                                    of the 8 surface values (:265-277)
+//     lane = (x, y) column, word = the 64 voxels along z; then the three cuts of the brick words and the coarse bytes,
+//     exactly the layout k_build_masks leaves.
+// (A first form kept the vertex planes in memory between two kernels, 0.036 + 0.021 ms at 256^3; recomputing the halo
+// -- 27 % more vertices -- in one kernel costs less than the second launch and the planes' round trip.)
+// NaN: a NaN density is "not below" in both forms.  A NaN surface value is neither above nor below a level here, so a
+// voxel that holds one stays a work voxel (k_geom then applies the reference's own arithmetic to it); the reference's
+// fminf / fmaxf skip the NaN instead -- the two differ only in which voxels are LOOKED AT, not in what is rendered.
+// Serves the surf_trav planes with at most kMaskFastSets level sets; the cuvol plane and longer level-set lists keep
+// k_build_masks.
+#pragma once
+#include "asurf_kernels.h"
+
+namespace asurf {
+
+constexpr int kMaskFastSets = 3;
+constexpr int kMaskPlanes = 2 + 2 * kMaskFastSets;
+
+// rows of the pass: all of them (blockIdx), or the listed ones (stride over the list the header vouches for; a header
+// that is not what the host table says -- asurf_api.hip, mask_cache_lookup -- makes the pass take every row)
+struct MaskRows {
+    const MaskHdr* hdr;
+    const int* live_rows;
+    unsigned long long epoch;
+    int n_rows;
+    int use_list;
+};
+
+struct MaskTables2 {
+    unsigned long long comb[kMaskPlanes][9][9];   // P' of the 9 x 9 vertex columns of the row and its halo
+    unsigned long long w[64], l[64];              // work / live of the 8 x 8 voxel columns ([lx * 8 + ly])
+    int alive;
+};
+
+__global__ void __launch_bounds__(512)
+k_build_masks2(KGrid g, float sigma_thresh, int need_surf, int n_sets, unsigned long long* fine_work,
+               unsigned long long* fine_live, unsigned int* coarse_work, unsigned int* coarse_live,
+               unsigned long long* fine_y, unsigned long long* fine_z, int orient_live, int nzg, MaskRows R,
+               MaskHdr* hdr_out, int* live_rows_out, int* zero_ptr, int zero_n) {
+    const TlScope tl(1);
+    __shared__ MaskTables2 S;
+    // (the pipeline's counters, zeroed here when no memset runs in front of the pass: asurf_api.hip, prepare())
+    if (blockIdx.x == 0 && zero_ptr != nullptr)
+        for (int i = threadIdx.x; i < zero_n; i += blockDim.x) zero_ptr[i] = 0;
+    const bool listed = R.use_list && R.hdr->magic == kMaskMagic && R.hdr->epoch == R.epoch;
+    const int n = listed ? min(R.hdr->n_live, R.n_rows) : R.n_rows;
+    const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
+    for (int i = blockIdx.x; i < n; i += gridDim.x) {
+        const int row = listed ? R.live_rows[i] : i;
+        if (row < 0 || row >= R.n_rows) continue;   // (block-uniform)
+        const int zg = row % nzg, bxy = row / nzg;
+        const int by = bxy % g.nb[1], bx = bxy / g.nb[1];
+        // The wave's runs, r = 0 .. 10, as vertex columns (xi, yi) of the 9 x 9 patch: its own x-slab with the 9 y's,
+        // its share of the halo slab xi = 8 (column yi = w; wave 0 also takes the corner yi = 8).  Lane l holds vertex
+        // z = 64 zg + l of every run; lane r < 11 also holds the vertex z = 64 (zg + 1) of run r (the halo along z).
+        const int z = zg * 64 + l, zn = zg * 64 + 64;
+        int32_t lk[11];
+        if (!listed) {
+            // The pass over the whole volume: most rows of a sparse grid are empty space, and a row none of whose own
+            // vertices exists holds no voxel whatever its halo holds -- its words are zeros, nothing more is read.  (A
+            // listed row is known to hold vertices: no such test, and one round trip less.)  (Reading the row's links as
+            // 16-byte pieces for this test -- a lane 4 consecutive z, a wave 4 runs an instruction -- changes nothing:
+            // 0.066 against 0.063 ms at 256^3, 0.345 against 0.329 at 512^3.)
+            bool any = false;
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                const int x = bx * 8 + w, y = by * 8 + r;
+                lk[r] = (x < g.size[0] && y < g.size[1] && z < g.size[2]) ? g.links[(size_t)x * g.offx + (size_t)y * g.offy + z] : -1;
+                any = any || (lk[r] >= 0);
+            }
+            if (threadIdx.x == 0) S.alive = 0;
+            __syncthreads();
+            if (__ballot(any) != 0ull && l == 0) S.alive = 1;
+            __syncthreads();
+            if (!S.alive) {   // (block-uniform)
+                const size_t brick0 = ((size_t)bx * g.nb[1] + by) * g.nb[2] + (size_t)zg * 8;
+                const int nbr = min(8, g.nb[2] - zg * 8);
+                const int j = l >> 3, k = l & 7;
+                if (j < nbr) {
+                    if (w == 0) {
+                        fine_work[(brick0 + j) * 8 + k] = 0ull;
+                        fine_live[(brick0 + j) * 8 + k] = 0ull;
+                    } else if (w == 1 && fine_y != nullptr) {
+                        fine_y[(brick0 + j) * 8 + k] = 0ull;
+                        fine_z[(brick0 + j) * 8 + k] = 0ull;
+                    }
+                }
+                if (threadIdx.x == 128) {
+                    reinterpret_cast<unsigned char*>(coarse_work)[(size_t)bxy * g.nwz * 4 + zg] = 0;
+                    reinterpret_cast<unsigned char*>(coarse_live)[(size_t)bxy * g.nwz * 4 + zg] = 0;
+                }
+                continue;
+            }
+        }
+        if (listed) {
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {   // the row's own vertices
+                const int x = bx * 8 + w, y = by * 8 + r;
+                lk[r] = (x < g.size[0] && y < g.size[1] && z < g.size[2]) ? g.links[(size_t)x * g.offx + (size_t)y * g.offy + z] : -1;
+            }
+        }
+#pragma unroll
+        for (int r = 8; r < 11; ++r) {   // the halo: the ninth column along y, the wave's share of the ninth slab along x
+            const int xi = r < 9 ? w : 8, yi = r < 9 ? r : (r == 9 ? w : 8);
+            const int x = bx * 8 + xi, y = by * 8 + yi;
+            const bool have = (r < 10 || w == 0) && x < g.size[0] && y < g.size[1] && z < g.size[2];
+            lk[r] = have ? g.links[(size_t)x * g.offx + (size_t)y * g.offy + z] : -1;
+        }
+        int32_t lkn = -1;
+        {
+            const int xi = l < 9 ? w : 8, yi = l < 9 ? l : (l == 9 ? w : 8);
+            const int x = bx * 8 + xi, y = by * 8 + yi;
+            if ((l < 10 || (l == 10 && w == 0)) && x < g.size[0] && y < g.size[1] && zn < g.size[2])
+                lkn = g.links[(size_t)x * g.offx + (size_t)y * g.offy + zn];
+        }
+        float dv[11], sv[11];
+#pragma unroll
+        for (int r = 0; r < 11; ++r) {
+            dv[r] = lk[r] >= 0 ? g.density[lk[r]] : 0.f;
+            sv[r] = (need_surf && lk[r] >= 0) ? g.surface[lk[r]] : 0.f;
+        }
+        const float dvn = lkn >= 0 ? g.density[lkn] : 0.f;
+        const float svn = (need_surf && lkn >= 0) ? g.surface[lkn] : 0.f;
+        float lv[kMaskFastSets];
+#pragma unroll
+        for (int s = 0; s < kMaskFastSets; ++s) lv[s] = (need_surf && s < n_sets) ? g.level_set[s] : 0.f;
+        // bits of the halo vertices along z: bit r = run r's next vertex
+        const bool exn = lkn >= 0;
+        const unsigned long long nE = __ballot(exn), nB = __ballot(exn && dvn < sigma_thresh);
+        unsigned long long nG[kMaskFastSets], nH[kMaskFastSets];
+#pragma unroll
+        for (int s = 0; s < kMaskFastSets; ++s) {
+            nG[s] = __ballot(exn && svn > lv[s]);
+            nH[s] = __ballot(exn && svn < lv[s]);
+        }
+        // P' = P & (P moved by one along z) of each run; lane r keeps run r's words
+        unsigned long long cE = 0ull, cB = 0ull, cG[kMaskFastSets], cH[kMaskFastSets];
+#pragma unroll
+        for (int s = 0; s < kMaskFastSets; ++s) cG[s] = cH[s] = 0ull;
+        bool own_alive = false;   // some vertex of the row itself exists (a function of `links` alone)
+#pragma unroll
+        for (int r = 0; r < 11; ++r) {
+            const bool ex = lk[r] >= 0;
+            const unsigned long long bE = __ballot(ex);
+            if (r < 8 && w < 8) own_alive = own_alive || (bE != 0ull);
+            if (bE == 0ull) continue;   // (wave-uniform) nothing exists in this run: its words stay 0
+            const unsigned long long bB = __ballot(ex && dv[r] < sigma_thresh);
+            const unsigned long long pE = bE & ((bE >> 1) | (((nE >> r) & 1ull) << 63));
+            const unsigned long long pB = bB & ((bB >> 1) | (((nB >> r) & 1ull) << 63));
+            cE = (l == r) ? pE : cE;
+            cB = (l == r) ? pB : cB;
+            if (need_surf) {
+#pragma unroll
+                for (int s = 0; s < kMaskFastSets; ++s) {
+                    if (s < n_sets) {
+                        const unsigned long long bG = __ballot(ex && sv[r] > lv[s]), bH = __ballot(ex && sv[r] < lv[s]);
+                        const unsigned long long pG = bG & ((bG >> 1) | (((nG[s] >> r) & 1ull) << 63));
+                        const unsigned long long pH = bH & ((bH >> 1) | (((nH[s] >> r) & 1ull) << 63));
+                        cG[s] = (l == r) ? pG : cG[s];
+                        cH[s] = (l == r) ? pH : cH[s];
+                    }
+                }
+            }
+        }
+        if (threadIdx.x == 0) S.alive = 0;
+        __syncthreads();   // (the tables of the row before are no longer read)
+        if (l < 11 && (l < 10 || w == 0)) {
+            const int xi = l < 9 ? w : 8, yi = l < 9 ? l : (l == 9 ? w : 8);
+            S.comb[0][xi][yi] = cE;
+            S.comb[1][xi][yi] = cB;
+#pragma unroll
+            for (int s = 0; s < kMaskFastSets; ++s) {
+                if (s < n_sets) {
+                    S.comb[2 + 2 * s][xi][yi] = cG[s];
+                    S.comb[3 + 2 * s][xi][yi] = cH[s];
+                }
+            }
+        }
+        if (own_alive && l == 0) S.alive = 1;
+        __syncthreads();
+        if (w < 3) {
+            // ---- voxel stage: lane = (lx, ly) column; computed by three waves alike, each leaves one kind of output ----
+            const int lx = l >> 3, ly = l & 7;
+#define ASURF_ALL4(q) (S.comb[q][lx][ly] & S.comb[q][lx][ly + 1] & S.comb[q][lx + 1][ly] & S.comb[q][lx + 1][ly + 1])
+            const unsigned long long live = ASURF_ALL4(0) & ~ASURF_ALL4(1);
+            unsigned long long work = live;
+            if (need_surf) {
+                unsigned long long any = 0ull;
+#pragma unroll
+                for (int s = 0; s < kMaskFastSets; ++s)
+                    if (s < n_sets) any |= ~ASURF_ALL4(2 + 2 * s) & ~ASURF_ALL4(3 + 2 * s);
+                work = live & any;
+            }
+#undef ASURF_ALL4
+            const size_t brick0 = ((size_t)bx * g.nb[1] + by) * g.nb[2] + (size_t)zg * 8;
+            const int nbr = min(8, g.nb[2] - zg * 8);  // bricks of the row that exist
+            const int j = l >> 3, k = l & 7;            // output lane: brick j of the row, word k of the brick
+            const unsigned long long sel = orient_live ? live : work;
+            if (w == 0) {
+                // x cut (word = x-slab k, bit = 8 ly + lz) and y cut (word = y index k, bit = 8 lz + lx) through LDS
+                S.w[l] = work;
+                S.l[l] = live;
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                unsigned long long xw = 0ull, xl = 0ull, yw = 0ull;
+                const unsigned long long* s_sel = orient_live ? S.l : S.w;
+#pragma unroll
+                for (int t = 0; t < 8; ++t) {
+                    xw |= ((S.w[k * 8 + t] >> (8 * j)) & 0xffull) << (8 * t);
+                    xl |= ((S.l[k * 8 + t] >> (8 * j)) & 0xffull) << (8 * t);
+                    yw |= spread_bits_to_bytes((unsigned)((s_sel[t * 8 + k] >> (8 * j)) & 0xffull)) << t;
+                }
+                if (j < nbr) {
+                    fine_work[(brick0 + j) * 8 + k] = xw;
+                    fine_live[(brick0 + j) * 8 + k] = xl;
+                    if (fine_y != nullptr) fine_y[(brick0 + j) * 8 + k] = yw;
+                }
+            } else if (w == 1) {
+                // z cut: word = z index lz, bit = 8 lx + ly = the lane number: a ballot per (brick, lz)
+                if (fine_z != nullptr) {
+                    unsigned long long zw = 0ull;
+#pragma unroll
+                    for (int jj = 0; jj < 8; ++jj) {
+#pragma unroll
+                        for (int lz = 0; lz < 8; ++lz) {
+                            const unsigned long long m = __ballot((sel >> (8 * jj + lz)) & 1ull);
+                            zw = (l == jj * 8 + lz) ? m : zw;
+                        }
+                    }
+                    if (j < nbr) fine_z[(brick0 + j) * 8 + k] = zw;
+                }
+            } else {
+                // coarse bytes (bit j = brick j of the row holds a flagged voxel) and the list of rows that hold vertices
+                unsigned cw = 0u, cl = 0u;
+#pragma unroll
+                for (int jj = 0; jj < 8; ++jj) {
+                    cw |= (__ballot(((work >> (8 * jj)) & 0xffull) != 0ull) != 0ull ? 1u : 0u) << jj;
+                    cl |= (__ballot(((live >> (8 * jj)) & 0xffull) != 0ull) != 0ull ? 1u : 0u) << jj;
+                }
+                if (l == 0) {
+                    reinterpret_cast<unsigned char*>(coarse_work)[(size_t)bxy * g.nwz * 4 + zg] = (unsigned char)cw;
+                    reinterpret_cast<unsigned char*>(coarse_live)[(size_t)bxy * g.nwz * 4 + zg] = (unsigned char)cl;
+                    if (hdr_out != nullptr && S.alive) live_rows_out[atomicAdd(&hdr_out->n_live, 1)] = row;
+                }
+            }
+        }
+    }
+    tl.end();
+}
+
+}  // namespace asurf

@@ -499,6 +499,38 @@ def test_random_option_fuzz(hip, oracle):
         assert (g["mask"].astype(bool) == go["mask"].astype(bool)).all(), tag
 
 
+@pytest.mark.parametrize("optname", ["syn_yaml", "density_gate", "fake_limited", "fake_all", "sigmoid_stop"])
+def test_vertex_plane_occupancy_pass_equals_per_voxel_pass(hip, optname):
+    """The occupancy pyramid built in bit arithmetic on vertex bit planes (asurf_masks2.h) against the
+    per-voxel kernel (ASURF_MASKS=row): the same planes, so the same picture, gradients and masks bit for bit -- one and
+    three level sets, a non-cubic crop whose sizes are no multiples of 8 or 64, the `live` plane (fake_all), the
+    density gate."""
+    from alphasurf_amd import synth
+    for lv, crop in (((0.0,), None), ((-0.3, 0.0, 0.4), None), ((0.0,), (45, 61, 70))):
+        sc = synth.make_sparse_scene(72, 4, seed=9, level_set=lv, trunc_a=3.0, fake_sample_std=0.8)
+        if crop is not None:
+            links = np.ascontiguousarray(sc["links"][:crop[0], :crop[1], :crop[2]])
+            sc = dict(sc, links=links, offset=np.asarray(crop, np.float32) * 0.5, scaling=np.asarray(crop, np.float32) * 0.5)
+        o, d = synth.random_rays(1500, 77)
+        gt = np.random.RandomState(3).rand(o.shape[0], 3).astype(np.float32)
+        fused = dict(lambda_l2=1.0, lambda_l_entropy=1e-4)
+        res = []
+        for form in (None, "row"):
+            _asurf_lib.config_set("ASURF_MASKS", form)
+            res.append(hip.render_fused(sc, o, d, OPTION_SETS[optname], gt, fused))
+        _asurf_lib.config_set("ASURF_MASKS", None)
+        (rgb_a, g_a), (rgb_b, g_b) = res
+        if optname == "fake_all":
+            # every voxel of the shell is a work voxel here: rays overflow their tables, and WHICH rays the spill list
+            # turns away (to the one-kernel path, which sums a ray's colours in another order) depends on timing
+            assert np.abs(rgb_a - rgb_b).max() <= 2.5e-7, (optname, lv, crop)
+        else:
+            assert np.array_equal(rgb_a, rgb_b), (optname, lv, crop)
+        assert (g_a["mask"] == g_b["mask"]).all()
+        for k in ("sh", "density", "surface"):
+            grad_close(g_a[k], g_b[k], 1e-5, f"{optname} {lv} {crop} grad_{k}")
+
+
 INTERNAL_FORMS = (("default", {}), ("no filter", {"ASURF_DEBUG": "32"}), ("one-kernel replay", {"ASURF_NO_SPLIT_BWD": "1"}),
                   ("walking backward", {"ASURF_NO_REPLAY": "1"}), ("one-kernel forward", {"ASURF_NO_PIPELINE": "1"}),
                   ("k_walk", {"ASURF_WALK": "step"}))
