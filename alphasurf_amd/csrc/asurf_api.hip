@@ -26,6 +26,7 @@
 #include "asurf_eval.h"
 #include "asurf_misc.h"
 #include "asurf_cuvol.h"
+#include "asurf_order.h"
 
 namespace {
 
@@ -119,6 +120,9 @@ struct MaskLayout {
     size_t off_p_items, off_p_citem, off_p_nitems, off_p_cut, off_p_flagged, off_p_counters, off_p_pool;
     size_t off_p_cand;  // cand_mask [Q]
     size_t off_p_spbase, off_p_spill, off_p_list, off_rec_list;
+    // ray ordering inside the fused call (batches of kOrderMinRays rays and more): permutation, the rays / targets /
+    // colours in the new order, sort scratch, the coherence probe's two counts
+    size_t off_ord_perm, off_ord_o, off_ord_d, off_ord_gt, off_ord_rgb, off_ord_tmp, off_ord_probe, ord_tmp_bytes;
     int pool_shard_cap, sp_cap, list_cap, band_rays, rec_list_cap;
     size_t total;
 };
@@ -133,6 +137,10 @@ static int walk_segments(long long n_rays) {
     if (n_rays <= 262144) return 4;
     return 1;
 }
+
+// Batches this large are put in a coherent order inside the fused call when they arrive shuffled
+// (asurf_fused_params::order_rays): below, the ordering's fixed costs exceed what it returns
+constexpr long long kOrderMinRays = 65536;
 
 // per-ray capacity of the sample records the fused forward leaves for the replaying
 // backward; rays with more samples fall back to the walking backward kernel
@@ -228,6 +236,22 @@ MaskLayout layout_for(const int32_t size[3], int64_t n_rays, int32_t M) {
     L.pool_shard_cap = (int)((8 * nr + kPoolShards - 1) / kPoolShards) + 256;  // (a wave of k_geom may ask for 3 x 64 at once)
     L.off_p_pool = off;
     off = align_up(off + (size_t)L.pool_shard_cap * kPoolShards * sizeof(CandRec), 256);
+    const size_t onr = (n_rays >= kOrderMinRays) ? nr : 0;
+    L.off_ord_perm = off;
+    off = align_up(off + onr * 4, 256);
+    L.off_ord_o = off;
+    off = align_up(off + onr * 12, 256);
+    L.off_ord_d = off;
+    off = align_up(off + onr * 12, 256);
+    L.off_ord_gt = off;
+    off = align_up(off + onr * 12, 256);
+    L.off_ord_rgb = off;
+    off = align_up(off + onr * 12, 256);
+    L.ord_tmp_bytes = onr ? asurf_order::tmp_bytes32((long long)onr) : 0;
+    L.off_ord_tmp = off;
+    off = align_up(off + L.ord_tmp_bytes, 256);
+    L.off_ord_probe = off;
+    off = align_up(off + (onr ? 256 : 0), 256);
     L.total = off;
     return L;
 }
@@ -472,6 +496,68 @@ void mask_cache_store(void* ws, unsigned long long epoch, const asurf_grid* grid
     if (hipMemcpyAsync(slot->h_count, d_count, sizeof(int), hipMemcpyDeviceToHost, stream) == hipSuccess &&
         hipEventRecord(slot->ev, stream) == hipSuccess)
         slot->pending = true;
+}
+
+// --- asurf_fused_params::order_rays = 0 (auto): was the last batch rendered through this workspace coherent? ---
+// Every fused call over kOrderMinRays rays leaves the answer of a probe (asurf_order.h: a sample of consecutive ray
+// pairs) in pinned memory, asynchronously; the next call reads it if it has arrived.  Unknown means "as given".
+struct OrderState {
+    void* ws = nullptr;
+    int* h_probe = nullptr;   // pinned: coherent pairs, pairs looked at
+    hipEvent_t ev = nullptr;
+    bool pending = false;
+    int coherent = -1;        // -1 unknown, 0 shuffled, 1 coherent
+    unsigned long long used = 0;
+};
+constexpr int kOrderStates = 8;
+std::mutex g_order_mu;
+OrderState g_order[kOrderStates];
+unsigned long long g_order_clock = 0;
+
+// returns what is known about the batches of `ws` (-1 / 0 / 1) and, unless a graph is being captured, queues the probe of
+// THIS batch for the next call
+int order_probe(void* ws, const float* origins, const float* dirs, long long n, int* d_probe, hipStream_t stream,
+                bool capturing) {
+    std::lock_guard<std::mutex> lock(g_order_mu);
+    OrderState* slot = nullptr;
+    for (OrderState& e : g_order)
+        if (e.ws == ws) slot = &e;
+    if (!slot) {
+        slot = &g_order[0];
+        for (OrderState& e : g_order)
+            if (e.ws == nullptr || e.used < slot->used) {
+                slot = &e;
+                if (e.ws == nullptr) break;
+            }
+        if (slot->pending && slot->ev) (void)hipEventSynchronize(slot->ev);
+        slot->ws = ws;
+        slot->pending = false;
+        slot->coherent = -1;
+    }
+    slot->used = ++g_order_clock;
+    if (capturing) return slot->coherent;
+    if (slot->pending) {
+        if (hipEventQuery(slot->ev) == hipSuccess) {
+            slot->pending = false;
+            if (slot->h_probe[1] > 0) slot->coherent = (2 * slot->h_probe[0] >= slot->h_probe[1]) ? 1 : 0;
+        } else {
+            (void)hipGetLastError();  // "not ready" is no error of this call
+            return slot->coherent;    // (one probe in flight at a time)
+        }
+    }
+    if (!slot->h_probe && hipHostMalloc(reinterpret_cast<void**>(&slot->h_probe), 2 * sizeof(int)) != hipSuccess) {
+        slot->h_probe = nullptr;
+        return slot->coherent;
+    }
+    if (!slot->ev && hipEventCreateWithFlags(&slot->ev, hipEventDisableTiming) != hipSuccess) {
+        slot->ev = nullptr;
+        return slot->coherent;
+    }
+    asurf_order::probe(origins, dirs, n, d_probe, stream);
+    if (hipMemcpyAsync(slot->h_probe, d_probe, 2 * sizeof(int), hipMemcpyDeviceToHost, stream) == hipSuccess &&
+        hipEventRecord(slot->ev, stream) == hipSuccess)
+        slot->pending = true;
+    return slot->coherent;
 }
 
 // Common prologue: validation, workspace carve-up and the occupancy-pyramid pass.
@@ -1110,6 +1196,40 @@ int asurf_volume_render_surf_trav_fused(const asurf_grid* grid, const asurf_rays
     loss.norm_l1 = 1.f / (3 * (int)Qn);
     const KGrads G = make_grads(grads);
     int rc = 0;
+    // ---- rays in a coherent order (an extension; results are those of the given order, colours land where the
+    // caller's rays are): order_rays 2 = always, 1 = never, 0 = when the last batch through this workspace arrived
+    // shuffled.  Everything below works on the ordered copies; the permutation never leaves the workspace. ----
+    asurf_rays rays_ord = *rays;
+    const float* rgb_gt_use = fused->rgb_gt;
+    float* rgb_use = rgb_out;
+    const unsigned* perm = nullptr;
+    if (rays->n_rays >= kOrderMinRays && fused->order_rays != 1) {
+        hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+        const bool capturing = hipStreamIsCapturing(L.stream, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone;
+        int* d_probe = reinterpret_cast<int*>(L.ws + L.ML.off_ord_probe);
+        bool order = fused->order_rays == 2;
+        if (fused->order_rays == 0) {
+            order = order_probe(workspace, rays->origins, rays->dirs, rays->n_rays, d_probe, L.stream, capturing) == 0;
+            prof_after("ray_probe", 1, L.stream);
+        }
+        if (order) {
+            unsigned* pm = reinterpret_cast<unsigned*>(L.ws + L.ML.off_ord_perm);
+            float* o_s = reinterpret_cast<float*>(L.ws + L.ML.off_ord_o);
+            float* d_s = reinterpret_cast<float*>(L.ws + L.ML.off_ord_d);
+            float* gt_s = reinterpret_cast<float*>(L.ws + L.ML.off_ord_gt);
+            if (asurf_order::order32(rays->origins, rays->dirs, rays->n_rays, pm, L.ws + L.ML.off_ord_tmp, L.ML.ord_tmp_bytes,
+                                     L.stream) != 0)
+                return fail(ASURF_E_LAUNCH, "ray ordering failed");
+            asurf_order::gather(rays->origins, rays->dirs, fused->rgb_gt, pm, rays->n_rays, o_s, d_s, gt_s, L.stream);
+            prof_after("ray_order", 1, L.stream);
+            rays_ord.origins = o_s;
+            rays_ord.dirs = d_s;
+            rgb_gt_use = gt_s;
+            rgb_use = reinterpret_cast<float*>(L.ws + L.ML.off_ord_rgb);
+            perm = pm;
+        }
+    }
+    rays = &rays_ord;
     // Replay instead of re-walking when the backward provably visits the forward's samples:
     // not with 0 < stop_thresh < 2e-8 (the two passes clamp log(1-alpha) differently,
     // surf_trav.cu:397 vs :2099) and not with more level sets than the record encodes.
@@ -1117,16 +1237,22 @@ int asurf_volume_render_surf_trav_fused(const asurf_grid* grid, const asurf_rays
     const bool replay = !cfg.no_replay && grid->level_set_num <= 32 &&
                         (opt->stop_thresh <= 0.f || opt->stop_thresh >= 2e-8f);
     const bool pipe = use_pipeline(grid, rays, opt, counters);
-    ASURF_DISPATCH_B(grid->basis_dim, run_forward<B_>(L, rays, rgb_out, M, true, replay, counters, pipe));
+    ASURF_DISPATCH_B(grid->basis_dim, run_forward<B_>(L, rays, rgb_use, M, true, replay, counters, pipe));
     if (rc) return rc;
     if (replay) {
         const int replay_mode = (cfg.no_split_bwd || rays->n_rays >= (1ll << kListRayBits)) ? 1 : 3;
         ASURF_DISPATCH_B(grid->basis_dim,
-                         run_backward<B_>(L, rays, loss, G, fused->rgb_gt, rgb_out, M, true, replay_mode, pipe));
+                         run_backward<B_>(L, rays, loss, G, rgb_gt_use, rgb_use, M, true, replay_mode, pipe));
         if (rc) return rc;
-        ASURF_DISPATCH_B(grid->basis_dim, run_backward<B_>(L, rays, loss, G, fused->rgb_gt, rgb_out, M, true, 2));
+        ASURF_DISPATCH_B(grid->basis_dim, run_backward<B_>(L, rays, loss, G, rgb_gt_use, rgb_use, M, true, 2));
     } else {
-        ASURF_DISPATCH_B(grid->basis_dim, run_backward<B_>(L, rays, loss, G, fused->rgb_gt, rgb_out, M, true, 0));
+        ASURF_DISPATCH_B(grid->basis_dim, run_backward<B_>(L, rays, loss, G, rgb_gt_use, rgb_use, M, true, 0));
+    }
+    if (rc) return rc;
+    if (perm != nullptr) {
+        asurf_order::scatter_rgb(rgb_use, perm, rays->n_rays, rgb_out, L.stream);
+        prof_after("ray_order_scatter", 2, L.stream);
+        return launch_error("ray order scatter");
     }
     return rc;
 }

@@ -43,6 +43,116 @@ k_order_keys(const float* __restrict__ origins, const float* __restrict__ dirs, 
     ids[i] = (unsigned)i;
 }
 
+// ---- the same ordering inside the fused call (asurf_api.hip, asurf_fused_params::order_rays) ----
+// 32-bit keys: 6 bits of the origin's hash, then 26 bits of the direction in the octahedral map of the sphere -- four
+// radix passes instead of seven and half the key bytes of the 50-bit form.  (With 9 bits per direction component the
+// cells were four pixels wide and the rays inside a cell stayed shuffled: k_bwd_sh 0.29 ms against 0.17 in image order.)
+__device__ __forceinline__ unsigned spread2(unsigned x) {  // one zero bit between the low 13 bits
+    x &= 0x1FFFu;
+    x = (x | (x << 8)) & 0x00FF00FFu;
+    x = (x | (x << 4)) & 0x0F0F0F0Fu;
+    x = (x | (x << 2)) & 0x33333333u;
+    x = (x | (x << 1)) & 0x55555555u;
+    return x;
+}
+
+__global__ void __launch_bounds__(256)
+k_order_keys32(const float* __restrict__ origins, const float* __restrict__ dirs, long long n,
+               unsigned* __restrict__ keys, unsigned* __restrict__ ids) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float dx = dirs[3 * i], dy = dirs[3 * i + 1], dz = dirs[3 * i + 2];
+    const float rn = 1.f / fmaxf(fabsf(dx) + fabsf(dy) + fabsf(dz), 1e-30f);
+    float u = dx * rn, v = dy * rn;
+    if (dz < 0.f) {   // the lower hemisphere folds over the corners of the square
+        const float fu = (1.f - fabsf(v)) * (u >= 0.f ? 1.f : -1.f), fv = (1.f - fabsf(u)) * (v >= 0.f ? 1.f : -1.f);
+        u = fu;
+        v = fv;
+    }
+    // strips: v in 12 bits (a strip about a pixel wide), u in 14 bits along the strip -- scan-line order.  The kernels
+    // that merge the samples of consecutive rays (k_bwd_sh, k_bwd_geo) want neighbours ALONG a line: a Z curve over
+    // the pixels (13 + 13 bits interleaved) cost them 0.243 / 0.144 ms against 0.169 / 0.110 in image order.
+    const unsigned qu = (unsigned)fminf(fmaxf((u + 1.f) * 8191.75f, 0.f), 16383.f);
+    const unsigned qv = (unsigned)fminf(fmaxf((v + 1.f) * 2047.75f, 0.f), 4095.f);
+    const unsigned morton = (qv << 14) | qu;
+    unsigned h = __float_as_uint(origins[3 * i]) * 0x9E3779B1u;
+    h = (h ^ __float_as_uint(origins[3 * i + 1])) * 0x85EBCA77u;
+    h = (h ^ __float_as_uint(origins[3 * i + 2])) * 0xC2B2AE3Du;
+    h ^= h >> 15;
+    keys[i] = ((h & 63u) << 26) | morton;
+    ids[i] = (unsigned)i;
+}
+
+// rays and targets in the new order: a lane per ray, 12-byte pieces (the reads are the scattered side: three a ray)
+struct F3 {
+    float x, y, z;
+};
+__global__ void __launch_bounds__(256)
+k_order_gather(const float* __restrict__ origins, const float* __restrict__ dirs, const float* __restrict__ gt,
+               const unsigned* __restrict__ perm, long long n, float* __restrict__ o_s, float* __restrict__ d_s,
+               float* __restrict__ gt_s) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const size_t src = perm[i];
+    reinterpret_cast<F3*>(o_s)[i] = reinterpret_cast<const F3*>(origins)[src];
+    reinterpret_cast<F3*>(d_s)[i] = reinterpret_cast<const F3*>(dirs)[src];
+    if (gt != nullptr) reinterpret_cast<F3*>(gt_s)[i] = reinterpret_cast<const F3*>(gt)[src];
+}
+
+__global__ void __launch_bounds__(256)
+k_order_scatter(const float* __restrict__ rgb_s, const unsigned* __restrict__ perm, long long n, float* __restrict__ rgb) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    reinterpret_cast<F3*>(rgb)[perm[i]] = reinterpret_cast<const F3*>(rgb_s)[i];
+}
+
+// How coherent is the batch as it stands?  Of a sample of consecutive pairs (q, q + 1), those that share an origin and
+// point within a few pixels of each other: out[0] = such pairs, out[1] = pairs looked at.  One block, no atomics, no
+// buffer to clear.
+__global__ void __launch_bounds__(1024)
+k_order_probe(const float* __restrict__ origins, const float* __restrict__ dirs, long long n, long long stride,
+              int per_thread, int* __restrict__ out) {
+    __shared__ int s_ok[16], s_seen[16];
+    int ok = 0, seen = 0;
+    for (int j = 0; j < per_thread; ++j) {
+        const long long i = ((long long)j * blockDim.x + threadIdx.x) * stride;
+        if (i + 1 < n) {
+            ++seen;
+            bool same = true;
+            float dot = 0.f, na = 0.f, nb = 0.f;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                same = same && (origins[3 * i + k] == origins[3 * (i + 1) + k]);
+                const float a = dirs[3 * i + k], b = dirs[3 * (i + 1) + k];
+                dot += a * b;
+                na += a * a;
+                nb += b * b;
+            }
+            // within 0.6 degrees (8 pixels of an 800-pixel, 40-degree view): cos^2 > 0.99989
+            ok += (same && dot > 0.f && dot * dot > 0.99989f * na * nb) ? 1 : 0;
+        }
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        ok += __shfl_xor(ok, d);
+        seen += __shfl_xor(seen, d);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        s_ok[threadIdx.x >> 6] = ok;
+        s_seen[threadIdx.x >> 6] = seen;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int a = 0, b2 = 0;
+        for (int w = 0; w < (int)(blockDim.x >> 6); ++w) {
+            a += s_ok[w];
+            b2 += s_seen[w];
+        }
+        out[0] = a;
+        out[1] = b2;
+    }
+}
+
 struct Plan {
     size_t off_keys_in, off_keys_out, off_ids_in, off_sort, total;
     size_t sort_bytes;
@@ -70,6 +180,55 @@ Plan plan_for(long long n) {
 }
 
 }  // namespace
+
+// ---- internal interface for asurf_api.hip (asurf_order.h) ----
+namespace asurf_order {
+
+size_t tmp_bytes32(long long n) {
+    const size_t nn = (size_t)(n > 0 ? n : 1);
+    size_t sb = 0;
+    (void)rocprim::radix_sort_pairs(nullptr, sb, (const unsigned*)nullptr, (unsigned*)nullptr, (const unsigned*)nullptr,
+                                    (unsigned*)nullptr, nn, 0u, 32u);
+    auto up = [](size_t x) { return (x + 255) / 256 * 256; };
+    return up(nn * 4) * 3 + up(sb);   // keys in, keys out, ids in, sort scratch
+}
+
+int order32(const float* origins, const float* dirs, long long n, unsigned* perm, void* tmp, size_t tmp_bytes,
+            hipStream_t s) {
+    auto up = [](size_t x) { return (x + 255) / 256 * 256; };
+    if (n <= 0) return 0;
+    if (tmp_bytes < tmp_bytes32(n)) return -1;
+    char* base = static_cast<char*>(tmp);
+    const size_t plane = up((size_t)n * 4);
+    auto* keys_in = reinterpret_cast<unsigned*>(base);
+    auto* keys_out = reinterpret_cast<unsigned*>(base + plane);
+    auto* ids_in = reinterpret_cast<unsigned*>(base + 2 * plane);
+    hipLaunchKernelGGL(k_order_keys32, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, origins, dirs, n, keys_in, ids_in);
+    size_t sb = tmp_bytes - 3 * plane;
+    const hipError_t e = rocprim::radix_sort_pairs(base + 3 * plane, sb, keys_in, keys_out, ids_in, perm, (size_t)n, 0u, 32u, s);
+    return (e == hipSuccess && hipGetLastError() == hipSuccess) ? 0 : -3;
+}
+
+void gather(const float* origins, const float* dirs, const float* gt, const unsigned* perm, long long n, float* o_s,
+            float* d_s, float* gt_s, hipStream_t s) {
+    if (n <= 0) return;
+    hipLaunchKernelGGL(k_order_gather, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, origins, dirs, gt, perm, n,
+                       o_s, d_s, gt_s);
+}
+
+void scatter_rgb(const float* rgb_s, const unsigned* perm, long long n, float* rgb, hipStream_t s) {
+    if (n <= 0) return;
+    hipLaunchKernelGGL(k_order_scatter, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, rgb_s, perm, n, rgb);
+}
+
+void probe(const float* origins, const float* dirs, long long n, int* out2, hipStream_t s) {
+    if (n < 2) return;
+    const int per_thread = 8;
+    const long long pairs = 1024 * per_thread, stride = (n / pairs) > 1 ? (n / pairs) : 1;
+    hipLaunchKernelGGL(k_order_probe, dim3(1), dim3(1024), 0, s, origins, dirs, n, stride, per_thread, out2);
+}
+
+}  // namespace asurf_order
 
 extern "C" {
 

@@ -318,9 +318,10 @@ def volume_render_surf_trav_fused(grid, rays, opt, rgb_gt, beta_loss, sparsity_l
                                   lambda_l_di, l_di_alpha_thresh, surf_sparse_alpha_thresh,
                                   lambda_inplace_surf_sparse, lambda_inwards_norm_loss,
                                   lambda_conv_mode_samp, l_dist_max_sample, rgb_out, grads,
-                                  global_n_rays=0, counters=None):
+                                  global_n_rays=0, counters=None, order_rays=0):
     """void volume_render_surf_trav_fused(...) -- svox2.cpp:38-40; surf_trav.cu:3802-3942;
-    call site svox2/svox2.py:3594-3621.  `global_n_rays` and `counters` are extensions."""
+    call site svox2/svox2.py:3594-3621.  `global_n_rays`, `counters` and `order_rays` (include/asurf.h,
+    asurf_fused_params) are extensions."""
     g, r, o = _pack_grid(grid), _pack_rays(rays), _pack_opt(opt)
     _check_input(rgb_gt, "rgb_gt", torch.float32)
     _check_input(rgb_out, "rgb_out", torch.float32)
@@ -350,6 +351,7 @@ def volume_render_surf_trav_fused(grid, rays, opt, rgb_gt, beta_loss, sparsity_l
     f.lambda_conv_mode_samp = lambda_conv_mode_samp
     f.l_dist_max_sample = int(l_dist_max_sample)
     f.global_n_rays = int(global_n_rays)
+    f.order_rays = int(order_rays)
     dev = grid.sh_data.device
     with torch.cuda.device(dev):
         nb = _L.workspace_bytes(grid.links.shape, r.n_rays, int(l_dist_max_sample))

@@ -571,13 +571,18 @@ class SparseGrid(nn.Module):
                             l_di_alpha_thresh: float = 0.0, surf_sparse_alpha_thresh: float = 0.0,
                             lambda_inplace_surf_sparse: float = 0.0, lambda_inwards_norm_loss: float = 0.0,
                             lambda_conv_mode_samp: float = 0.0, l_dist_max_sample: int = 64,
-                            no_surface: bool = False, global_n_rays: int = 0, coherent_order: bool = False):
+                            no_surface: bool = False, global_n_rays: int = 0,
+                            coherent_order: Optional[bool] = None):
         """Render + fused loss gradients accumulated into the parameters' .grad (:3477-3638).
-        `global_n_rays` (extension) = ray count of the whole data-parallel batch; `coherent_order` (extension)
-        renders a shuffled batch in the order of _C.ray_order and returns the colours in the caller's order."""
+        `global_n_rays` (extension) = ray count of the whole data-parallel batch; `coherent_order` (extension): True
+        renders a shuffled batch in a coherent order and returns the colours in the caller's order, False renders it as
+        given, None leaves it to the library (asurf_fused_params::order_rays: surf_trav batches of 65 536 rays and
+        more are ordered inside the call when the last batch arrived shuffled)."""
         assert self.sh_data.is_cuda and rays.is_cuda, "the HIP extension is required for fused"
         perm = None
-        if coherent_order and rays.origins.shape[0] > 1:
+        in_library = self._check_backend(no_surface) == "surf_trav" and rays.origins.shape[0] >= 65536
+        order_rays = 0 if coherent_order is None else (2 if coherent_order else 1)
+        if coherent_order and not in_library and rays.origins.shape[0] > 1:
             perm = _C.ray_order(rays.origins.contiguous(), rays.dirs.contiguous()).long()
             rays = Rays(rays.origins[perm].contiguous(), rays.dirs[perm].contiguous())
             rgb_gt = rgb_gt[perm].contiguous()
@@ -622,7 +627,7 @@ class SparseGrid(nn.Module):
             no_norm_weight_l_entropy, lambda_l_dist_a, lambda_l_entropy_a, lambda_l_samp_dist,
             lambda_l_di, l_di_alpha_thresh, surf_sparse_alpha_thresh, lambda_inplace_surf_sparse,
             lambda_inwards_norm_loss, lambda_conv_mode_samp, l_dist_max_sample, rgb_out, holder,
-            global_n_rays=global_n_rays)
+            global_n_rays=global_n_rays, order_rays=order_rays)
         self.sparse_sh_grad_indexer = self.sparse_grad_indexer.clone()
         return finish(rgb_out)
 

@@ -77,6 +77,7 @@ FUSED_FIELDS = [
     ("surf_sparse_alpha_thresh", C.c_float), ("lambda_inplace_surf_sparse", C.c_float),
     ("lambda_inwards_norm_loss", C.c_float), ("lambda_conv_mode_samp", C.c_float),
     ("l_dist_max_sample", C.c_int32), ("global_n_rays", C.c_int64),
+    ("order_rays", C.c_int32), ("reserved_", C.c_int32),
 ]
 
 
@@ -173,7 +174,7 @@ def lib():
         L.asurf_ray_order.argtypes = [vp, vp, C.c_int64, vp, vp, C.c_size_t, vp]
         L.asurf_test_quotient.argtypes = [vp, vp, C.c_int64, vp, vp, vp]
         L.asurf_config_set.argtypes = [C.c_char_p, C.c_char_p]
-        if L.asurf_abi_version() != 2:
+        if L.asurf_abi_version() != 3:
             raise RuntimeError("libasurf_hip.so ABI version mismatch")
         _lib = L
     return _lib

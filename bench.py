@@ -36,6 +36,9 @@ def parse():
     ap.add_argument("--shuffle", action="store_true", help="training-order (shuffled) rays")
     ap.add_argument("--sort", action="store_true",
                     help="order the batch for coherence inside the timed step (asurf_ray_order), scatter rgb back")
+    ap.add_argument("--order-rays", type=int, default=0, choices=[0, 1, 2],
+                    help="asurf_fused_params::order_rays: 0 = the library decides (orders a batch of >= 65 536 rays inside "
+                         "the call when the last batch arrived shuffled), 1 = never, 2 = always")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-verify", action="store_true",
                     help="skip the self-check (a strided sample of the timed batch against the CPU oracle; a mismatch "
@@ -306,7 +309,7 @@ def main():
             g, r, opt, gt, 0.0, 0.0, 0.0, True, False, F["lambda_l2"], F["lambda_l1"], 0.0,
             F["lambda_l_entropy"], False, 0.0, 0.0, 0.0, 0.0, F["l_di_alpha_thresh"],
             F["surf_sparse_alpha_thresh"], 0.0, 0.0, F["lambda_conv_mode_samp"], M, rgb, gr,
-            global_n_rays=Q_global, counters=counters)
+            global_n_rays=Q_global, counters=counters, order_rays=args.order_rays)
         if world > 1 and exchange:
             # data-parallel exchange: sum of per-shard gradients == gradient of the global batch.
             # A view touches ~20 % of the rows here, so the dense ring all-reduce is chosen
@@ -369,7 +372,7 @@ def main():
                 g, r, opt, gt, 0.0, 0.0, 0.0, True, False, F["lambda_l2"], F["lambda_l1"], 0.0,
                 F["lambda_l_entropy"], False, 0.0, 0.0, 0.0, 0.0, F["l_di_alpha_thresh"],
                 F["surf_sparse_alpha_thresh"], 0.0, 0.0, F["lambda_conv_mode_samp"], M, rgb, gr,
-                global_n_rays=Q_global)
+                global_n_rays=Q_global, order_rays=args.order_rays)
             a, b, c = _lib.profile_read()
             t_mask.append(a), t_fwd.append(b), t_bwd.append(c)
             for name, ms in _lib.profile_read_spans():

@@ -653,3 +653,36 @@ def test_segmented_walk_with_long_voxel_lists(hip, oracle, monkeypatch):
     assert np.abs(rgb1 - rgb_o).max() <= 2e-5
     for k in ("sh", "density", "surface"):
         grad_close(g1[k], go[k], 2e-4, f"grad_{k} vs oracle")
+
+
+def test_ray_ordering_inside_the_fused_call_is_transparent(hip):
+    """asurf_fused_params::order_rays: a shuffled batch of 70 000 rays rendered as given (1), ordered inside the call
+    (2) and left to the library (0: the first call renders as given, the probe it leaves makes the later ones order):
+    the colours come back where the caller's rays are, gradients and masks are those of the batch."""
+    import torch
+    from alphasurf_amd import csrc_api as _C, synth
+    sc = synth.make_sparse_scene(96, 9, seed=4, trunc_a=4.0)
+    o, d = synth.pinhole_rays(synth.orbit_camera(2), 265, 265)
+    perm = np.random.RandomState(5).permutation(o.shape[0])
+    o, d = o[perm], d[perm]
+    assert o.shape[0] >= 65536
+    gt = np.random.RandomState(6).rand(o.shape[0], 3).astype(np.float32)
+    g, r, op = hip.grid_spec(sc), hip.rays_spec(o, d), hip.opt_spec(OPTION_SETS["syn_yaml"])
+    gt_t = torch.from_numpy(gt).cuda()
+    fused = dict(lambda_l2=1.0, lambda_l_entropy=1e-4, lambda_conv_mode_samp=1e-6)
+    args = [fused.get(k, dflt) for k, dflt in hip.FUSED_ORDER]
+
+    def run(order_rays):
+        gr = hip.zero_grads(g)
+        rgb = torch.zeros_like(gt_t)
+        _C.volume_render_surf_trav_fused(g, r, op, gt_t, *args, rgb, gr, order_rays=order_rays)
+        torch.cuda.synchronize()
+        return rgb.cpu().numpy(), hip.grads_np(gr)
+
+    rgb1, g1 = run(1)
+    for mode in (2, 0, 0, 0):
+        rgb2, g2 = run(mode)
+        assert np.abs(rgb2 - rgb1).max() <= 2.5e-7, mode
+        assert (g2["mask"] == g1["mask"]).all()
+        for k in ("sh", "density", "surface"):
+            grad_close(g2[k], g1[k], 2e-5, f"order_rays {mode} grad_{k}")
