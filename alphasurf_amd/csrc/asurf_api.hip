@@ -27,6 +27,7 @@
 #include "asurf_misc.h"
 #include "asurf_cuvol.h"
 #include "asurf_order.h"
+#include "asurf_exchange.h"
 
 namespace {
 
@@ -1345,6 +1346,55 @@ int asurf_sgd_step_masked(float* data, float* grad, int64_t n_rows, int32_t n_co
                           void* scratch, size_t scratch_bytes, float lr, float lr_last, void* stream) {
     return optim_masked(false, data, nullptr, grad, n_rows, n_cols, mask, scratch, scratch_bytes, 0.f, lr, 0.f, 0.f,
                         lr_last, stream);
+}
+
+// ---- multi-GPU gradient exchange, device side (asurf_exchange.h) ----
+size_t asurf_rows_list_tmp_bytes(int64_t n_rows) {
+    const int64_t nb = n_rows > 0 ? (n_rows + kRowsPerBlock - 1) / kRowsPerBlock : 0;
+    return (size_t)((nb * 4 + 255) / 256 * 256);
+}
+
+int asurf_rows_list(const uint8_t* mask, int64_t n_rows, int32_t* rows_out, int32_t* count_out, void* tmp, size_t tmp_bytes,
+                    void* stream) {
+    if (n_rows < 0 || n_rows >= (1ll << 31)) return fail(ASURF_E_INVALID, "rows_list: n_rows out of range");
+    if (!count_out) return fail(ASURF_E_INVALID, "rows_list: count_out is NULL");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (n_rows == 0) {
+        if (hipMemsetAsync(count_out, 0, sizeof(int32_t), s) != hipSuccess) return fail(ASURF_E_LAUNCH, "hipMemsetAsync failed");
+        return 0;
+    }
+    if (!mask || !rows_out || !tmp || tmp_bytes < asurf_rows_list_tmp_bytes(n_rows))
+        return fail(ASURF_E_INVALID, "rows_list: NULL tensor or scratch too small");
+    const int nb = (int)((n_rows + kRowsPerBlock - 1) / kRowsPerBlock);
+    int* counts = static_cast<int*>(tmp);
+    hipLaunchKernelGGL(k_rows_count, dim3((unsigned)nb), dim3(256), 0, s, mask, (long long)n_rows, counts);
+    hipLaunchKernelGGL(k_rows_scan, dim3(1), dim3(1024), 0, s, counts, nb, count_out);
+    hipLaunchKernelGGL(k_rows_fill, dim3((unsigned)nb), dim3(256), 0, s, mask, (long long)n_rows, counts, rows_out);
+    return launch_error("rows_list");
+}
+
+int asurf_rows_pack(const int32_t* rows, int64_t n_list, int32_t sh_dim, const float* grad_sh, const float* grad_density,
+                    const float* grad_surface, float* packed, void* stream) {
+    if (n_list < 0 || sh_dim <= 0) return fail(ASURF_E_INVALID, "rows_pack: bad shape");
+    if (n_list == 0) return 0;
+    if (!rows || !grad_sh || !grad_density || !packed) return fail(ASURF_E_INVALID, "rows_pack: NULL tensor");
+    const long long total = (long long)n_list * (sh_dim + 2);
+    const unsigned blocks = (unsigned)std::min<long long>((total + 255) / 256, 256 * 32);
+    hipLaunchKernelGGL(k_rows_pack, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(stream), rows, (long long)n_list,
+                       sh_dim, grad_sh, grad_density, grad_surface, packed);
+    return launch_error("rows_pack");
+}
+
+int asurf_rows_unpack(const int32_t* rows, int64_t n_list, int32_t sh_dim, const float* packed, float* grad_sh,
+                      float* grad_density, float* grad_surface, uint8_t* mask, void* stream) {
+    if (n_list < 0 || sh_dim <= 0) return fail(ASURF_E_INVALID, "rows_unpack: bad shape");
+    if (n_list == 0) return 0;
+    if (!rows || !grad_sh || !grad_density || !packed) return fail(ASURF_E_INVALID, "rows_unpack: NULL tensor");
+    const long long total = (long long)n_list * (sh_dim + 2);
+    const unsigned blocks = (unsigned)std::min<long long>((total + 255) / 256, 256 * 32);
+    hipLaunchKernelGGL(k_rows_unpack, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(stream), rows, (long long)n_list,
+                       sh_dim, packed, grad_sh, grad_density, grad_surface, mask);
+    return launch_error("rows_unpack");
 }
 
 int asurf_profile_enable(int on) {

@@ -361,6 +361,38 @@ def volume_render_surf_trav_fused(grid, rays, opt, rgb_gt, beta_loss, sparsity_l
             nb, _counters_ptr(counters), _stream(dev)))
 
 
+# ---- multi-GPU gradient exchange, device side (include/asurf.h: asurf_rows_*) ----
+def rows_list(mask):
+    """(rows int32[n] -- the first `count` entries are the rows `mask` names, in increasing order --, count int32[1] on
+    the device)."""
+    _check_input(mask, "mask")
+    n = mask.numel()
+    dev = mask.device
+    with torch.cuda.device(dev):
+        rows = torch.empty(max(n, 1), dtype=torch.int32, device=dev)
+        count = torch.empty(1, dtype=torch.int32, device=dev)
+        nb = int(_L.lib().asurf_rows_list_tmp_bytes(n))
+        tmp = torch.empty(max(nb, 1), dtype=torch.uint8, device=dev)
+        m8 = mask.view(torch.uint8) if mask.dtype == torch.bool else mask
+        _L.check(_L.lib().asurf_rows_list(_ptr(m8), n, _ptr(rows), _ptr(count), _ptr(tmp), nb, _stream(dev)))
+    return rows, count
+
+
+def rows_pack(rows, n_list, grad_sh, grad_density, grad_surface, out):
+    dev = grad_sh.device
+    with torch.cuda.device(dev):
+        _L.check(_L.lib().asurf_rows_pack(_ptr(rows), int(n_list), int(grad_sh.shape[1]), _ptr(grad_sh), _ptr(grad_density),
+                                          _ptr(grad_surface), _ptr(out), _stream(dev)))
+
+
+def rows_unpack(rows, n_list, packed, grad_sh, grad_density, grad_surface, mask):
+    dev = grad_sh.device
+    m8 = None if mask is None else (mask.view(torch.uint8) if mask.dtype == torch.bool else mask)
+    with torch.cuda.device(dev):
+        _L.check(_L.lib().asurf_rows_unpack(_ptr(rows), int(n_list), int(grad_sh.shape[1]), _ptr(packed), _ptr(grad_sh),
+                                            _ptr(grad_density), _ptr(grad_surface), _ptr(m8), _stream(dev)))
+
+
 def _pack_ray_vox(rv):
     _check_input(rv.voxel_ls, "voxel_ls", torch.int32)
     _check_input(rv.vox_start_i, "vox_start_i", torch.int32)

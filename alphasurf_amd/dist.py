@@ -28,32 +28,6 @@ def _reduce(t, op, group):
         dist.all_reduce(t, op=op, group=group)
 
 
-def _staged(t, group):
-    return t.is_cuda and dist.get_backend(group) == "gloo"
-
-
-def _all_to_all(out, inp, out_splits, in_splits, group):
-    """all_to_all_single; device tensors go through host memory with the gloo backend."""
-    if _staged(inp, group):
-        h = torch.empty(out.shape, dtype=out.dtype)
-        dist.all_to_all_single(h, inp.cpu(), output_split_sizes=out_splits, input_split_sizes=in_splits,
-                               group=group)
-        out.copy_(h)
-    else:
-        dist.all_to_all_single(out, inp, output_split_sizes=out_splits, input_split_sizes=in_splits, group=group)
-
-
-def _all_gather(outs, inp, group):
-    """all_gather into the list `outs`; device tensors go through host memory with the gloo backend."""
-    if _staged(inp, group):
-        hs = [torch.empty(o.shape, dtype=o.dtype) for o in outs]
-        dist.all_gather(hs, inp.cpu(), group=group)
-        for o, h in zip(outs, hs):
-            o.copy_(h)
-    else:
-        dist.all_gather(outs, inp, group=group)
-
-
 def all_reduce_dense(tensors, mask=None, group=None):
     """Plain sum all-reduce of every gradient buffer + OR of the mask."""
     if _world(group) == 1:
@@ -66,71 +40,70 @@ def all_reduce_dense(tensors, mask=None, group=None):
         _reduce(m8, dist.ReduceOp.MAX, group)
 
 
-def all_reduce_sparse(tensors, mask, group=None):
-    """Sparse sum keyed by the touched-row mask (`mask_out`, render_util.cuh:138-142).
+DENSE_ABOVE = 0.5   # union of touched rows above this fraction of the grid: the dense ring moves fewer bytes per row
 
-    Row ownership is a contiguous range per rank.  Step 1 (all-to-all): every rank sends the
-    touched rows of each range to its owner, which sums them.  Step 2 (all-gather): owners
-    publish their summed rows; every rank writes them back.  Per-rank volume is about
-    2 * touched_rows * row_bytes instead of 2 * all_rows * row_bytes for the dense ring, and
-    the all-to-all uses all xGMI links at once rather than one ring direction.
-    """
-    world = _world(group)
-    if world == 1:
-        return
-    rank = dist.get_rank(group)
-    tensors = [t for t in tensors if t is not None]
-    n = mask.shape[0]
-    dev = mask.device
-    widths = [t.reshape(n, -1).shape[1] for t in tensors]
-    W = sum(widths)
-    # contiguous ownership ranges
-    bounds = torch.linspace(0, n, world + 1, device="cpu").long().tolist()
-    idx = torch.nonzero(mask.view(-1), as_tuple=False).view(-1)
-    rows = torch.cat([t.reshape(n, -1)[idx] for t in tensors], dim=1) if idx.numel() else \
-        torch.zeros((0, W), dtype=tensors[0].dtype, device=dev)
-    owner_cuts = torch.searchsorted(idx, torch.tensor(bounds, device=dev))
-    send_counts = (owner_cuts[1:] - owner_cuts[:-1]).to(torch.int64)
-    recv_counts = torch.empty_like(send_counts)
-    _all_to_all(recv_counts, send_counts, None, None, group)
-    sc, rc = send_counts.tolist(), recv_counts.tolist()
-    recv_idx = torch.empty(sum(rc), dtype=idx.dtype, device=dev)
-    recv_rows = torch.empty((sum(rc), W), dtype=rows.dtype, device=dev)
-    _all_to_all(recv_idx, idx, rc, sc, group)
-    _all_to_all(recv_rows, rows, rc, sc, group)
-    # owner-side reduction over its range
-    lo, hi = bounds[rank], bounds[rank + 1]
-    acc = torch.zeros((hi - lo, W), dtype=rows.dtype, device=dev)
-    acc.index_add_(0, recv_idx - lo, recv_rows)
-    touched = torch.zeros(hi - lo, dtype=torch.bool, device=dev)
-    touched[recv_idx - lo] = True
-    own_idx = torch.nonzero(touched, as_tuple=False).view(-1)
-    own_rows = acc[own_idx]
-    own_idx = own_idx + lo
-    # publish the summed rows
-    cnt = torch.tensor([own_idx.numel()], dtype=torch.int64, device=dev)
-    cnts = [torch.zeros_like(cnt) for _ in range(world)]
-    _all_gather(cnts, cnt, group)
-    cnts = [int(c.item()) for c in cnts]
-    mx = max(max(cnts), 1)
-    pad_idx = torch.zeros(mx, dtype=own_idx.dtype, device=dev)
-    pad_rows = torch.zeros((mx, W), dtype=rows.dtype, device=dev)
-    pad_idx[: own_idx.numel()] = own_idx
-    pad_rows[: own_idx.numel()] = own_rows
-    all_idx = [torch.empty_like(pad_idx) for _ in range(world)]
-    all_rows = [torch.empty_like(pad_rows) for _ in range(world)]
-    _all_gather(all_idx, pad_idx, group)
-    _all_gather(all_rows, pad_rows, group)
-    for r in range(world):
-        k = cnts[r]
-        if k == 0:
-            continue
-        ids, vals = all_idx[r][:k], all_rows[r][:k]
-        c0 = 0
-        for t, w in zip(tensors, widths):
-            t.reshape(n, -1)[ids] = vals[:, c0:c0 + w]
-            c0 += w
-        mask.view(-1)[ids] = True
+
+def _union_rows(mask, group):
+    """The union of the ranks' touched rows: `mask` all-reduced (max) in place, then the ordered list of the rows it
+    names -- identical on every rank -- and its length, the ONE number the host reads per exchange."""
+    m8 = mask.view(torch.uint8) if mask.dtype == torch.bool else mask
+    _reduce(m8, dist.ReduceOp.MAX, group)
+    if mask.is_cuda:
+        from . import csrc_api as _C
+        rows, count = _C.rows_list(mask)
+        return rows, int(count.item())
+    rows = torch.nonzero(mask.view(-1), as_tuple=False).view(-1).to(torch.int32)
+    return rows, int(rows.numel())
+
+
+def all_reduce_sparse(tensors, mask, group=None, extra=None, dense_above=None):
+    """Sum keyed by the UNION of the ranks' touched rows (`mask_out`, render_util.cuh:138-142).
+
+    One small all-reduce (max) of the masks gives every rank the same union mask and therefore the same ordered row
+    list; each rank packs its values of those rows (zeros where it touched nothing) into a dense [U, D + 2] buffer,
+    ONE ring all-reduce sums the buffers, and the sums are written back (asurf_rows_list / _pack / _unpack on the
+    device: include/asurf.h).  Per rank the ring moves 2 (N-1)/N * U * row_bytes instead of ... * all_rows * row_bytes,
+    with one host read (U, the buffer's size) instead of the four of a variable-size all-to-all.
+    `extra`: a tensor of a few floats (grad_fake_sample_std) summed in the same collective.
+    `dense_above`: when the union exceeds this fraction of the rows the buffers are all-reduced as they are.
+    Returns "sparse" or "dense"."""
+    if _world(group) == 1:
+        return "single"
+    grad_sh, grad_density, grad_surface = tensors
+    n, D = grad_sh.shape[0], grad_sh.shape[1]
+    rows, U = _union_rows(mask, group)
+    if dense_above is not None and U > dense_above * n:
+        for t in (grad_sh, grad_density, grad_surface, extra):
+            if t is not None:
+                _reduce(t, dist.ReduceOp.SUM, group)
+        return "dense"
+    W = D + 2
+    n_extra = 0 if extra is None else extra.numel()
+    packed = torch.empty(U * W + n_extra, dtype=grad_sh.dtype, device=grad_sh.device)
+    if grad_sh.is_cuda:
+        from . import csrc_api as _C
+        _C.rows_pack(rows, U, grad_sh, grad_density, grad_surface, packed)
+    elif U:
+        idx = rows[:U].long()
+        body = packed[:U * W].view(U, W)
+        body[:, :D] = grad_sh[idx]
+        body[:, D] = grad_density.view(-1)[idx]
+        body[:, D + 1] = grad_surface.view(-1)[idx] if grad_surface is not None else 0.0
+    if n_extra:
+        packed[U * W:] = extra.view(-1)
+    _reduce(packed, dist.ReduceOp.SUM, group)
+    if grad_sh.is_cuda:
+        _C.rows_unpack(rows, U, packed, grad_sh, grad_density, grad_surface, None)   # (the mask IS the union already)
+    elif U:
+        idx = rows[:U].long()
+        body = packed[:U * W].view(U, W)
+        grad_sh[idx] = body[:, :D]
+        grad_density.view(-1)[idx] = body[:, D]
+        if grad_surface is not None:
+            grad_surface.view(-1)[idx] = body[:, D + 1]
+    if n_extra:
+        extra.view(-1).copy_(packed[U * W:])
+    return "sparse"
 
 
 class GradArena:
@@ -168,36 +141,38 @@ class GradArena:
         self.flat.zero_()
         self.zero_mask()
 
-    def all_reduce(self, group=None):
-        """Sum over the ranks in place; `mask` becomes the union of the ranks' masks."""
+    def all_reduce(self, group=None, mode="dense"):
+        """Sum over the ranks in place; `mask` becomes the union of the ranks' masks.  mode "dense": one ring
+        all-reduce of the whole allocation; "sparse": the rows of the union only (all_reduce_sparse); "auto": sparse
+        unless the union exceeds DENSE_ABOVE of the rows."""
         if _world(group) == 1:
-            return
-        self.touched.copy_(self.mask)
-        _reduce(self.flat, dist.ReduceOp.SUM, group)
-        torch.gt(self.touched, 0, out=self.mask)
+            return "single"
+        if mode == "dense":
+            self.touched.copy_(self.mask)
+            _reduce(self.flat, dist.ReduceOp.SUM, group)
+            torch.gt(self.touched, 0, out=self.mask)
+            return "dense"
+        return all_reduce_sparse([self.grad_sh, self.grad_density, self.grad_surface], self.mask, group=group,
+                                 extra=self.grad_fake_sample_std, dense_above=DENSE_ABOVE if mode == "auto" else None)
 
 
 def all_reduce_grads(grad_sh, grad_density, grad_surface, mask, grad_fake_sample_std=None,
-                     group=None, dense_threshold=0.125, mode="auto"):
+                     group=None, dense_threshold=DENSE_ABOVE, mode="auto"):
     """Sum the sparse gradient buffers of a fused render across ranks.
 
-    mode: "dense", "sparse" or "auto" (sparse when the fraction of touched rows on every rank
-    is below `dense_threshold`, mirroring the reference's own switch between mask and index
-    lists at svox2/svox2.py:6326-6332)."""
+    mode: "dense", "sparse" or "auto" (sparse unless the UNION of the ranks' touched rows exceeds `dense_threshold` of
+    the grid -- known after the masks' all-reduce, at no extra cost; the reference makes the same kind of switch
+    between mask and index lists at svox2/svox2.py:6326-6332)."""
     if _world(group) == 1:
         return "single"
-    if grad_fake_sample_std is not None:
-        _reduce(grad_fake_sample_std, dist.ReduceOp.SUM, group)
     tensors = [grad_sh, grad_density, grad_surface]
-    if mode == "auto":
-        frac = mask.float().mean().reshape(1)
-        _reduce(frac, dist.ReduceOp.MAX, group)
-        mode = "sparse" if float(frac.item()) < dense_threshold else "dense"
-    if mode == "sparse":
-        all_reduce_sparse(tensors, mask, group=group)
-    else:
+    if mode == "dense":
+        if grad_fake_sample_std is not None:
+            _reduce(grad_fake_sample_std, dist.ReduceOp.SUM, group)
         all_reduce_dense(tensors, mask, group=group)
-    return mode
+        return "dense"
+    return all_reduce_sparse(tensors, mask, group=group, extra=grad_fake_sample_std,
+                             dense_above=dense_threshold if mode == "auto" else None)
 
 
 def shard_rays(n_rays, rank, world):

@@ -104,6 +104,7 @@ EXPORTS = [
     "asurf_volume_render_cuvol", "asurf_volume_render_cuvol_backward", "asurf_volume_render_cuvol_fused",
     "asurf_grid_weight_render", "asurf_sparse_grid_weight_render", "asurf_render_eval_cuvol",
     "asurf_ray_order_tmp_bytes", "asurf_ray_order", "asurf_test_quotient",
+    "asurf_rows_list_tmp_bytes", "asurf_rows_list", "asurf_rows_pack", "asurf_rows_unpack",
 ]
 
 _lib = None
@@ -174,6 +175,11 @@ def lib():
         L.asurf_ray_order.argtypes = [vp, vp, C.c_int64, vp, vp, C.c_size_t, vp]
         L.asurf_test_quotient.argtypes = [vp, vp, C.c_int64, vp, vp, vp]
         L.asurf_config_set.argtypes = [C.c_char_p, C.c_char_p]
+        L.asurf_rows_list_tmp_bytes.restype = C.c_size_t
+        L.asurf_rows_list_tmp_bytes.argtypes = [C.c_int64]
+        L.asurf_rows_list.argtypes = [vp, C.c_int64, vp, vp, vp, C.c_size_t, vp]
+        L.asurf_rows_pack.argtypes = [vp, C.c_int64, C.c_int32, vp, vp, vp, vp, vp]
+        L.asurf_rows_unpack.argtypes = [vp, C.c_int64, C.c_int32, vp, vp, vp, vp, vp, vp]
         if L.asurf_abi_version() != 3:
             raise RuntimeError("libasurf_hip.so ABI version mismatch")
         _lib = L

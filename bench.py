@@ -53,7 +53,7 @@ def parse():
     ap.add_argument("--graph", action="store_true",
                     help="capture one step in a HIP graph after the warm-up and replay it in the timed region")
     ap.add_argument("--cpu-rays", type=int, default=40000)
-    ap.add_argument("--exchange", default="dense", choices=["dense", "sparse", "auto"],
+    ap.add_argument("--exchange", default="auto", choices=["dense", "sparse", "auto"],
                     help="gradient exchange for --gpus > 1 (alphasurf_amd/dist.py)")
     return ap.parse_args()
 
@@ -311,14 +311,10 @@ def main():
             F["surf_sparse_alpha_thresh"], 0.0, 0.0, F["lambda_conv_mode_samp"], M, rgb, gr,
             global_n_rays=Q_global, counters=counters, order_rays=args.order_rays)
         if world > 1 and exchange:
-            # data-parallel exchange: sum of per-shard gradients == gradient of the global batch.
-            # A view touches ~20 % of the rows here, so the dense ring all-reduce is chosen
-            # (alphasurf_amd/dist.py switches to the sparse all-to-all below 1/8).
-            if args.exchange == "dense":
-                arena.all_reduce()
-            else:
-                adist.all_reduce_grads(gr.grad_sh_out, gr.grad_density_out, gr.grad_surface_out, gr.mask_out,
-                                       mode=args.exchange)
+            # data-parallel exchange: sum of per-shard gradients == gradient of the global batch (alphasurf_amd/dist.py:
+            # "dense" = one ring all-reduce of the whole arena, "sparse" = the rows of the union of the ranks' masks
+            # only, "auto" = sparse unless the union exceeds half of the rows)
+            arena.all_reduce(mode=args.exchange)
 
     def barrier():
         if world > 1:

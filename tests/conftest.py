@@ -12,6 +12,44 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+_DIST_GPU_JOB = None
+
+
+def pytest_sessionstart(session):
+    """`-m gpu` on a box with a GPU: start the two-rank job of tests/test_dist_gpu.py NOW, as child processes, while this
+    process has not touched the GPU yet (counting devices does not initialise it)."""
+    global _DIST_GPU_JOB
+    expr = (session.config.getoption("-m") or "").strip()
+    if "gpu" not in expr or "not gpu" in expr:
+        return
+    try:
+        import torch
+        if torch.cuda.device_count() < 1:
+            return
+    except Exception:  # noqa: BLE001
+        return
+    import socket
+    import subprocess
+    import tempfile
+    out_dir = tempfile.mkdtemp(prefix="asurf_dist_gpu_")
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    log = os.path.join(out_dir, "job.log")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "tests", "dist_gpu_worker.py"), out_dir]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    proc = subprocess.Popen(cmd, stdout=open(log, "w"), stderr=subprocess.STDOUT, env=env, cwd=ROOT)
+    _DIST_GPU_JOB = (proc, out_dir, log)
+
+
+@pytest.fixture(scope="session")
+def dist_gpu_job():
+    if _DIST_GPU_JOB is None:
+        pytest.skip("the two-rank job was not started (no GPU, or the session was not selected with -m gpu)")
+    return _DIST_GPU_JOB
+
+
 @pytest.fixture(scope="session")
 def oracle():
     """The CPU oracle (test infrastructure): built on demand with g++."""

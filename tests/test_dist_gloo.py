@@ -42,7 +42,7 @@ def _worker(rank, world, port, mode, frac, n, d, out):
         t_sh, t_de, t_su = torch.from_numpy(g_sh), torch.from_numpy(g_de), torch.from_numpy(g_su)
         t_m = torch.from_numpy(mask.copy())
         t_std = torch.tensor([[float(rank + 1)]])
-        if mode == "arena":          # the same buffers as views of one flat allocation, one collective
+        if mode.startswith("arena"):  # the same buffers as views of one flat allocation, one collective
             arena = adist.GradArena(n, d, torch.device("cpu"))
             arena.grad_sh.copy_(t_sh)
             arena.grad_density.copy_(t_de)
@@ -51,10 +51,10 @@ def _worker(rank, world, port, mode, frac, n, d, out):
             arena.mask.copy_(t_m)
             base = arena.flat.data_ptr()
             assert all((v.data_ptr() - base) % 256 == 0 for v in (arena.grad_sh, arena.grad_density, arena.grad_surface))
-            arena.all_reduce()
+            used = arena.all_reduce(mode={"arena": "dense", "arena_sparse": "sparse", "arena_auto": "auto"}[mode])
             t_sh, t_de, t_su, t_m, t_std = (arena.grad_sh, arena.grad_density, arena.grad_surface, arena.mask,
                                             arena.grad_fake_sample_std)
-            used = "arena"
+            used = "arena:" + used
         else:
             used = adist.all_reduce_grads(t_sh, t_de, t_su, t_m, t_std, mode=mode)
         exp = [_shard_grads(r, n, d, frac, 42) for r in range(world)]
@@ -72,7 +72,9 @@ def _worker(rank, world, port, mode, frac, n, d, out):
 
 @pytest.mark.parametrize("mode,frac,expect", [("dense", 0.3, "dense"), ("sparse", 0.05, "sparse"),
                                               ("auto", 0.03, "sparse"), ("auto", 0.5, "dense"),
-                                              ("sparse", 0.0, "sparse"), ("arena", 0.3, "arena")])
+                                              ("sparse", 0.0, "sparse"), ("arena", 0.3, "arena:dense"),
+                                              ("arena_sparse", 0.2, "arena:sparse"), ("arena_auto", 0.1, "arena:sparse"),
+                                              ("arena_auto", 0.6, "arena:dense")])
 def test_gradient_exchange_world2(mode, frac, expect):
     world, n, d = 2, 4001, 27
     ctx = mp.get_context("spawn")
