@@ -145,7 +145,7 @@ constexpr long long kOrderMinRays = 65536;
 
 // per-ray capacity of the sample records the fused forward leaves for the replaying
 // backward; rays with more samples fall back to the walking backward kernel
-constexpr int kRecDepth = 16;
+constexpr int kRecDepth = 32;
 
 size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
@@ -234,7 +234,9 @@ MaskLayout layout_for(const int32_t size[3], int64_t n_rays, int32_t M) {
                              // block b of k_bwd_seq (256 rays, kRecDepth records each at most) fills segment b % 8
     L.rec_list_cap = (int)(((nr + kBlock - 1) / kBlock + kRecShards - 1) / kRecShards) * kBlock * kRecDepth;
     off = align_up(off + (size_t)L.rec_list_cap * kRecShards * 4, 256);
-    L.pool_shard_cap = (int)((8 * nr + kPoolShards - 1) / kPoolShards) + 256;  // (a wave of k_geom may ask for 3 x 64 at once)
+    // 16 candidates a ray on average (the live config yields 0.7; three level sets with fake samples 11: with 8 a fifth of
+    // the rays of such a scene went to the one-kernel path, whose walking backward then took 30 of the step's 39 ms)
+    L.pool_shard_cap = (int)((16 * nr + kPoolShards - 1) / kPoolShards) + 256;  // (a wave of k_geom may ask for 3 x 64 at once)
     L.off_p_pool = off;
     off = align_up(off + (size_t)L.pool_shard_cap * kPoolShards * sizeof(CandRec), 256);
     const size_t onr = (n_rays >= kOrderMinRays) ? nr : 0;

@@ -39,6 +39,10 @@ def parse():
     ap.add_argument("--order-rays", type=int, default=0, choices=[0, 1, 2],
                     help="asurf_fused_params::order_rays: 0 = the library decides (orders a batch of >= 65 536 rays inside "
                          "the call when the last batch arrived shuffled), 1 = never, 2 = always")
+    ap.add_argument("--heavy", nargs="?", const="levels", default=None, choices=["levels", "fake"],
+                    help="a heavier variant of the workload (never the driver's default line).  levels: three level sets "
+                         "(-1, 0, 1 voxel), both crossings of each -- about 4 samples a ray instead of 0.7; fake: three level "
+                         "sets, outward crossings, limited fake samples on -- about 11")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-verify", action="store_true",
                     help="skip the self-check (a strided sample of the timed batch against the CPU oracle; a mismatch "
@@ -237,10 +241,19 @@ def main():
     R, B = args.reso, args.basis_dim
     D = 3 * B
     on_device = R > 256 or args.band != 3.0   # big grids: build the scene with torch on the GPU
+    scene_kw = dict(synth.BENCH_SCENE)
+    render_opts = dict(synth.SYN_OPTS)
+    if args.heavy:
+        scene_kw["level_set"] = (-1.0, 0.0, 1.0)
+        if args.heavy == "levels":
+            render_opts.update(only_outward_intersect=False)
+        else:
+            render_opts.update(only_outward_intersect=True, surf_fake_sample=True, limited_fake_sample=True,
+                               surf_fake_sample_min_vox_len=0.1)
     if on_device:
-        sc = synth.make_sparse_scene_torch(R, B, dev, band=args.band, trunc_a=5.0, **synth.BENCH_SCENE)
+        sc = synth.make_sparse_scene_torch(R, B, dev, band=args.band, trunc_a=5.0, **scene_kw)
     else:
-        sc = synth.make_sparse_scene(R, B, trunc_a=5.0, **synth.BENCH_SCENE)
+        sc = synth.make_sparse_scene(R, B, trunc_a=5.0, **scene_kw)
     o_np, d_np = synth.pinhole_rays(synth.orbit_camera(rank % 8), args.width, args.width)
     if args.shuffle:
         perm = np.random.RandomState(11 + rank).permutation(o_np.shape[0])
@@ -269,7 +282,7 @@ def main():
     r.origins, r.dirs = torch.from_numpy(o_np).to(dev), torch.from_numpy(d_np).to(dev)
     r.masks = torch.ones(Q, dtype=torch.bool, device=dev)
     opt = _C.RenderOptions()
-    for k, v in synth.SYN_OPTS.items():
+    for k, v in render_opts.items():
         setattr(opt, k, v)
     gt = torch.from_numpy(gt_np).to(dev)
     rgb = torch.zeros_like(gt)
@@ -409,7 +422,7 @@ def main():
             # the same entry point, so that their gradients and masks can be compared row by row
             n_v = min(args.verify_rays, Q)
             vidx = np.linspace(0, Q - 1, n_v).astype(np.int64)
-            rgb_o, go, st_o = O.render_fused(osc, o_np[vidx], d_np[vidx], synth.SYN_OPTS, gt_np[vidx], fused)
+            rgb_o, go, st_o = O.render_fused(osc, o_np[vidx], d_np[vidx], render_opts, gt_np[vidx], fused)
             rgb_timed = (rgb_user if args.sort else rgb)[torch.from_numpy(vidx).to(dev)].cpu().numpy()
             e_timed = float(np.abs(rgb_timed - rgb_o).max())
             rv = _C.RaysSpec()
@@ -443,10 +456,10 @@ def main():
             # the oracle on a bounded, strided sample of the same rays
             n_cpu = min(args.cpu_rays, Q)
             idx = np.linspace(0, Q - 1, n_cpu).astype(np.int64)
-            O.render_fused(osc, o_np[idx[:2000]], d_np[idx[:2000]], synth.SYN_OPTS, gt_np[idx[:2000]], fused)
+            O.render_fused(osc, o_np[idx[:2000]], d_np[idx[:2000]], render_opts, gt_np[idx[:2000]], fused)
             reps, tc = 0, time.perf_counter()
             while True:
-                O.render_fused(osc, o_np[idx], d_np[idx], synth.SYN_OPTS, gt_np[idx], fused)
+                O.render_fused(osc, o_np[idx], d_np[idx], render_opts, gt_np[idx], fused)
                 reps += 1
                 if time.perf_counter() - tc > 10.0 or reps >= 50:
                     break
@@ -466,9 +479,14 @@ def main():
                                    f"({'shuffled' if args.shuffle else 'image-order'} rays"
                                    f"{', ordered per step' if args.sort else ''}), "
                                    "volume_render_surf_trav_fused fwd+bwd, surface_cuda_syn.yaml options"
+                                   + ({"levels": " -- HEAVY variant: level sets (-1, 0, 1), both crossings of each",
+                                       "fake": " -- HEAVY variant: level sets (-1, 0, 1), limited fake samples on"}[args.heavy]
+                                      if args.heavy else "")
                                    + ("; links unchanged from step to step (links_epoch)" if args.links_epoch else ""),
                        "rays_per_step_per_gpu": Q, "active_voxels": int(g.density_data.shape[0]),
-                       "avg_per_ray": {"V_t": round(v_t / Q, 2), "V_a": round(v_a / Q, 2), "S": round(s_cnt / Q, 3)},
+                       "avg_per_ray": {"V_t": round(v_t / Q, 2), "V_a": round(v_a / Q, 2), "S": round(s_cnt / Q, 3),
+                                       "rays_with_a_sample": round(float(((rgb_user if args.sort else rgb) != 1.0)
+                                                                         .any(dim=1).float().mean().item()), 4)},
                        "parallelism": f"ray-sharded dp{world}, {args.exchange} RCCL exchange of grads" if world > 1 else "single GPU"},
             "roofline": roofline, "cpu_baseline": cpu, "verify": verify,
         }
