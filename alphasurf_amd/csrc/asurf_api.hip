@@ -61,6 +61,7 @@ struct Config {
     int no_split_bwd = 0;  // ASURF_NO_SPLIT_BWD: the one-kernel replay
     int eval_walk = 0;     // ASURF_EVAL=walk: the stepping evaluation renders
     int timeline = 0;      // ASURF_TIMELINE = kernel id (instrumented build)
+    int side_stream = 0;   // ASURF_SIDE_STREAM: the fused call's fallback kernels on a stream of their own (measured: slower)
     int masks_row = 0;     // ASURF_MASKS=row: the one-pass occupancy kernel (k_build_masks) instead of the two stages
     int sweep_block = 0;   // ASURF_SWEEP=block: the block-synchronous form of k_sweep (round 2)
     int sweep_wpb = 0;     // ASURF_SWEEP_WPB = 1, 2, 4: waves per block of k_sweep_wave (measurement)
@@ -87,6 +88,7 @@ bool config_assign(Config& c, const char* name, const char* value) {
     else if (!strcmp(name, "ASURF_NO_SPLIT_BWD")) c.no_split_bwd = n ? 1 : 0;
     else if (!strcmp(name, "ASURF_EVAL")) c.eval_walk = (value && !strcmp(value, "walk")) ? 1 : 0;
     else if (!strcmp(name, "ASURF_TIMELINE")) c.timeline = n;
+    else if (!strcmp(name, "ASURF_SIDE_STREAM")) c.side_stream = n ? 1 : 0;
     else if (!strcmp(name, "ASURF_MASKS")) c.masks_row = (value && !strcmp(value, "row")) ? 1 : 0;
     else if (!strcmp(name, "ASURF_SWEEP")) c.sweep_block = (value && !strcmp(value, "block")) ? 1 : 0;
     else if (!strcmp(name, "ASURF_SWEEP_WPB")) c.sweep_wpb = (n == 1 || n == 2 || n == 4) ? n : 0;
@@ -99,7 +101,7 @@ Config config() {  // a copy: a call works with one consistent set
     std::call_once(g_cfg_once, [] {
         static const char* const names[] = {"ASURF_DEBUG", "ASURF_WALK_SEG", "ASURF_WALK", "ASURF_RPW", "ASURF_NO_PIPELINE",
                                             "ASURF_CUVOL_RPW", "ASURF_NO_REPLAY", "ASURF_NO_SPLIT_BWD", "ASURF_EVAL",
-                                            "ASURF_TIMELINE", "ASURF_SWEEP", "ASURF_SWEEP_WPB", "ASURF_SWEEP_RPW", "ASURF_MASKS"};
+                                            "ASURF_TIMELINE", "ASURF_SWEEP", "ASURF_SWEEP_WPB", "ASURF_SWEEP_RPW", "ASURF_MASKS", "ASURF_SIDE_STREAM"};
         std::lock_guard<std::mutex> lock(g_cfg_mu);
         for (const char* nm : names)
             if (const char* v = getenv(nm)) config_assign(g_cfg, nm, v);
@@ -793,9 +795,38 @@ int find_candidates(const Launch& L, const asurf_rays* rays, bool record, PipeBu
 
 // The one-kernel forward.  `pipeline` = the three-kernel pipeline runs first and this kernel
 // only renders the rays it handed back (k_forward's ray_filter).
+// A stream of the library's own, per host thread, for work of a call that nothing else in the call waits for (the fused
+// call's one-kernel fallbacks); forked from and joined to the caller's stream with events, so the call stays stream-ordered
+// for its caller and capturable into a graph.
+struct SideStream {
+    hipStream_t stream = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    int device = -1;
+};
+SideStream* side_stream() {
+    thread_local SideStream tl[8];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+    SideStream& s = tl[dev & 7];
+    if (s.stream == nullptr || s.device != dev) {
+        if (hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking) != hipSuccess ||
+            hipEventCreateWithFlags(&s.ev_fork, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&s.ev_join, hipEventDisableTiming) != hipSuccess) {
+            s.stream = nullptr;
+            (void)hipGetLastError();
+            return nullptr;
+        }
+        s.device = dev;
+    }
+    return &s;
+}
+
+// `fb`: where the one-kernel forward of the handed-back rays is launched when the pipeline ran first -- nullptr: on the
+// call's stream, leaving records like the pipeline; else on that launch context's stream (the fused call's side stream)
+// and WITHOUT records, so that nothing on the call's own stream waits for it.
 template <int B>
 int run_forward(const Launch& L, const asurf_rays* rays, float* rgb_out, int M, bool cache,
-                bool record, uint64_t* counters, bool pipeline) {
+                bool record, uint64_t* counters, bool pipeline, const Launch* fb = nullptr, SideStream* side = nullptr) {
     float* ca = reinterpret_cast<float*>(L.ws + L.ML.off_cache_a);
     float* cw = reinterpret_cast<float*>(L.ws + L.ML.off_cache_w);
     float* ct = reinterpret_cast<float*>(L.ws + L.ML.off_cache_t);
@@ -834,9 +865,18 @@ int run_forward(const Launch& L, const asurf_rays* rays, float* rgb_out, int M, 
         ray_list = P.flagged;
         n_list = P.counters;
     }
+    hipStream_t fstream = L.stream;
+    if (pipeline && fb != nullptr && side != nullptr) {
+        // fork: the side stream continues from here (k_comp and everything before it are queued on the call's stream)
+        if (hipEventRecord(side->ev_fork, L.stream) != hipSuccess ||
+            hipStreamWaitEvent(side->stream, side->ev_fork, 0) != hipSuccess)
+            return fail(ASURF_E_LAUNCH, "side stream fork failed");
+        fstream = fb->stream;
+        rv = nullptr;  // (k_forward records iff rec_v != nullptr)
+    }
 #define ASURF_FWD(CACHE, COUNT, CLDS)                                                            \
     hipLaunchKernelGGL((k_forward<B, CACHE, COUNT, CLDS>), L.ray_grid, dim3(kBlock), L.dyn_lds,  \
-                       L.stream, L.g, L.o, rays->origins, rays->dirs, (long long)rays->n_rays,   \
+                       fstream, L.g, L.o, rays->origins, rays->dirs, (long long)rays->n_rays,    \
                        rgb_out, M, ca, cw, ct, cn, rv, rm, rn, kRecDepth, rf, ray_list, n_list, cnt)
 #define ASURF_FWD2(CACHE, COUNT)             \
     do {                                     \
@@ -852,7 +892,7 @@ int run_forward(const Launch& L, const asurf_rays* rays, float* rgb_out, int M, 
     }
 #undef ASURF_FWD2
 #undef ASURF_FWD
-    prof_after(pipeline ? "k_forward_fallback" : "k_forward", 1, L.stream);
+    if (fstream == L.stream) prof_after(pipeline ? "k_forward_fallback" : "k_forward", 1, L.stream);
     return launch_error("k_forward");
 }
 
@@ -1240,14 +1280,33 @@ int asurf_volume_render_surf_trav_fused(const asurf_grid* grid, const asurf_rays
     const bool replay = !cfg.no_replay && grid->level_set_num <= 32 &&
                         (opt->stop_thresh <= 0.f || opt->stop_thresh >= 2e-8f);
     const bool pipe = use_pipeline(grid, rays, opt, counters);
-    ASURF_DISPATCH_B(grid->basis_dim, run_forward<B_>(L, rays, rgb_use, M, true, replay, counters, pipe));
+    const int replay_mode = (cfg.no_split_bwd || rays->n_rays >= (1ll << kListRayBits)) ? 1 : 3;
+    // The rays the pipeline hands to the one-kernel path (tables, pool or records too small: none at all on most calls)
+    // are rendered and differentiated by two kernels of their own -- one-kernel forward, walking backward -- that depend
+    // on k_comp and on nothing after it.  On the call's stream each of them is a dependent launch in the chain (8 us
+    // apiece whether or not a single ray was handed back).  With ASURF_SIDE_STREAM=1 they run on a stream of the
+    // library's own beside k_bwd_seq / k_bwd_sh / k_bwd_geo and the call's stream waits for them at the end -- built,
+    // measured and left OFF: the two event hand-overs cost more than the two launches (5 184 rays: 0.173 against 0.162 ms
+    // per step, 0.143 against 0.131 with links_epoch; 640 k rays: 0.952 against 0.943).  tests/test_hip_parity.py keeps
+    // the form alive.
+    SideStream* side = (pipe && replay && replay_mode == 3 && !g_prof_on && cfg.side_stream) ? side_stream() : nullptr;
+    Launch Lside = L;
+    if (side != nullptr) Lside.stream = side->stream;
+    const Launch* fb = side != nullptr ? &Lside : nullptr;
+    ASURF_DISPATCH_B(grid->basis_dim, run_forward<B_>(L, rays, rgb_use, M, true, replay, counters, pipe, fb, side));
     if (rc) return rc;
     if (replay) {
-        const int replay_mode = (cfg.no_split_bwd || rays->n_rays >= (1ll << kListRayBits)) ? 1 : 3;
         ASURF_DISPATCH_B(grid->basis_dim,
                          run_backward<B_>(L, rays, loss, G, rgb_gt_use, rgb_use, M, true, replay_mode, pipe));
         if (rc) return rc;
-        ASURF_DISPATCH_B(grid->basis_dim, run_backward<B_>(L, rays, loss, G, rgb_gt_use, rgb_use, M, true, 2));
+        ASURF_DISPATCH_B(grid->basis_dim,
+                         run_backward<B_>(side != nullptr ? Lside : L, rays, loss, G, rgb_gt_use, rgb_use, M, true, 2));
+        if (rc) return rc;
+        if (side != nullptr) {   // join
+            if (hipEventRecord(side->ev_join, side->stream) != hipSuccess ||
+                hipStreamWaitEvent(L.stream, side->ev_join, 0) != hipSuccess)
+                return fail(ASURF_E_LAUNCH, "side stream join failed");
+        }
     } else {
         ASURF_DISPATCH_B(grid->basis_dim, run_backward<B_>(L, rays, loss, G, rgb_gt_use, rgb_use, M, true, 0));
     }

@@ -701,6 +701,9 @@ k_comp(KGrid g, KOpt o, const float* __restrict__ dirs, long long Q, PipeBuf P,
         for (int k = 0; k < B; ++k) s_sph[tid * kSphPad + k] = sph[k];
     }
     const bool do_rec = CACHE && (rec_v != nullptr);
+    // a ray handed to the one-kernel path leaves no records: the replaying backward must pass it by whether or not the
+    // one-kernel forward has run yet (in the fused call it runs BESIDE the backward kernels, asurf_api.hip)
+    if (in_range && n < 0 && do_rec) rec_n[q] = -1;
     const int cutv = (valid && do_rec) ? P.cut[q] : 0x7fffffff;
     const int spb = (valid && n > P.C1) ? P.sp_base[q] : 0;
     float outv[3] = {0.f, 0.f, 0.f};

@@ -533,7 +533,8 @@ def test_vertex_plane_occupancy_pass_equals_per_voxel_pass(hip, optname):
 
 INTERNAL_FORMS = (("default", {}), ("no filter", {"ASURF_DEBUG": "32"}), ("one-kernel replay", {"ASURF_NO_SPLIT_BWD": "1"}),
                   ("walking backward", {"ASURF_NO_REPLAY": "1"}), ("one-kernel forward", {"ASURF_NO_PIPELINE": "1"}),
-                  ("k_walk", {"ASURF_WALK": "step"}))
+                  ("k_walk", {"ASURF_WALK": "step"}), ("fallbacks on a side stream", {"ASURF_SIDE_STREAM": "1"}),
+                  ("block-synchronous k_sweep", {"ASURF_SWEEP": "block"}), ("per-voxel occupancy pass", {"ASURF_MASKS": "row"}))
 
 
 def test_fuzz_knife_edge_draw(hip, oracle):
@@ -686,3 +687,27 @@ def test_ray_ordering_inside_the_fused_call_is_transparent(hip):
         assert (g2["mask"] == g1["mask"]).all()
         for k in ("sh", "density", "surface"):
             grad_close(g2[k], g1[k], 2e-5, f"order_rays {mode} grad_{k}")
+
+
+def test_fallback_kernels_beside_the_backward_pipeline(hip, oracle):
+    """A scene that hands many rays to the one-kernel path (dense noisy shell, fake samples in every voxel): the fused
+    call as it is (one stream) against the same call with its fallback kernels on the library's side stream
+    (ASURF_SIDE_STREAM=1), and against the oracle."""
+    from alphasurf_amd import synth
+    sc = synth.make_sparse_scene(40, 4, seed=7, band=3.5, level_set=(-0.4, 0.0, 0.4), trunc_a=4.0, fake_sample_std=0.9)
+    o, d = synth.random_rays(3000, 41)
+    gt = np.random.RandomState(8).rand(o.shape[0], 3).astype(np.float32)
+    opts = OPTION_SETS["fake_all"]
+    fused = dict(lambda_l2=1.0, lambda_l_entropy=1e-3)
+    rgb_a, g_a = hip.render_fused(sc, o, d, opts, gt, fused)
+    _asurf_lib.config_set("ASURF_SIDE_STREAM", "1")
+    rgb_b, g_b = hip.render_fused(sc, o, d, opts, gt, fused)
+    _asurf_lib.config_set("ASURF_SIDE_STREAM", None)
+    assert np.abs(rgb_a - rgb_b).max() <= 2.5e-7
+    assert (g_a["mask"] == g_b["mask"]).all()
+    rgb_o, go, _ = oracle.render_fused(sc, o, d, opts, gt, fused)
+    assert np.abs(rgb_a - rgb_o).max() <= RGB_TOL_ORACLE
+    for k in ("sh", "density", "surface"):
+        grad_close(g_a[k], g_b[k], 2e-5, f"side stream grad_{k}")
+        grad_close(g_a[k], go[k], GRAD_RTOL, f"grad_{k} vs oracle")
+    assert (g_a["mask"].astype(bool) == go["mask"].astype(bool)).all()
