@@ -490,6 +490,7 @@ struct SweepWaveMisc {
     int spb[kSweepWaveRays];        // spill base
     int hand[kSweepWaveRays];       // 1: handed back
     int slot0[64];                  // first list cell of each table slot
+    unsigned fill[64];              // bit r: ray r fills the slot
     int pad[3];
 };
 static_assert(sizeof(SweepWaveMisc) % 16 == 0, "the waves' LDS slices stay 16-byte aligned");
@@ -535,7 +536,8 @@ k_sweep_wave(KGrid g, KOpt o, const float* __restrict__ origins, const float* __
     SweepRay* const s_ray = reinterpret_cast<SweepRay*>(base);
     unsigned* const s_task = reinterpret_cast<unsigned*>(s_ray + rpw);   // ray << 21 | layer << 14 | brick b << 7 | brick c
     unsigned* const s_key = s_task + task_cap;
-    SweepWaveMisc* const M = reinterpret_cast<SweepWaveMisc*>(s_key + key_cap);
+    unsigned char* const s_krl = reinterpret_cast<unsigned char*>(s_key + key_cap);   // the ray a key belongs to
+    SweepWaveMisc* const M = reinterpret_cast<SweepWaveMisc*>(s_krl + key_cap);       // (key_cap: a multiple of 16)
     const float kEps = 1.f / 256.f;
 
     // ---- phase 0: lane = ray ----
@@ -620,6 +622,22 @@ k_sweep_wave(KGrid g, KOpt o, const float* __restrict__ origins, const float* __
     }
     sweep_wave_sync();
 
+#ifdef ASURF_INSTRUMENT
+    // phase timing (instrumented build): ASURF_DEBUG = 256 * n makes every wave leave after phase n - 1, results invalid
+#define ASURF_SWEEP_LEAVE(n_)                                  \
+    if (((o.debug >> 8) & 7) == (n_)) {                        \
+        if (lane < rpw && q0 + lane < Q) {                     \
+            P.n_items[q0 + lane] = 0;                          \
+            P.cut[q0 + lane] = 0x7fffffff;                     \
+            P.sp_base[q0 + lane] = 0;                          \
+            P.cand_mask[q0 + lane] = 0ull;                     \
+        }                                                      \
+        return;                                                \
+    }
+#else
+#define ASURF_SWEEP_LEAVE(n_)
+#endif
+    ASURF_SWEEP_LEAVE(1)
     const float inv_layers = 1.f / (float)n_layers;
     int group = rpw;   // rays taken together; shrinks when the wave's lists overflow
     for (int r_lo = 0; r_lo < rpw;) {
@@ -700,6 +718,61 @@ k_sweep_wave(KGrid g, KOpt o, const float* __restrict__ origins, const float* __
         }
         sweep_wave_sync();
 
+        ASURF_SWEEP_LEAVE(2)
+        // ---- phase 1b: lane = task.  Two tasks in three find nothing: the brick holds flagged voxels, but not where the
+        // ray passes.  One rectangle -- the ray's footprint over ALL of the brick's slabs, a superset of the slabs'
+        // rectangles: the positions are monotone along the ray, so the planes at the brick's two ends bound the ones in
+        // between -- against the brick's projection along a (the OR of its 8 words) removes half of the tasks for a
+        // sixth of what a task costs; the survivors are compacted in place (ordered: ballot + prefix), so that phase 2
+        // spends its 8 slabs per lane on tasks that can yield something. ----
+        {
+            int nkeep = 0;   // (wave-uniform)
+            for (int t0 = 0; t0 < ntask; t0 += 64) {
+                const int ti = t0 + lane;
+                bool keep = false;
+                unsigned task = 0u;
+                if (ti < ntask) {
+                    task = s_task[ti];
+                    const int rl = (int)(task >> 21), A = (int)((task >> 14) & 127), Bb = (int)((task >> 7) & 127),
+                              Bc = (int)(task & 127);
+                    const SweepRay& R = s_ray[rl];
+                    const int a = R.flags & 3;
+                    const unsigned long long* plane = a == 0 ? g.fine : (a == 1 ? g.fine_y : g.fine_z);
+                    const int brick = __mul24(A, R.bs_a) + __mul24(Bb, R.bs_b) + __mul24(Bc, R.bs_c);
+                    const ulonglong2* wp = reinterpret_cast<const ulonglong2*>(plane + (size_t)brick * 8);
+                    const ulonglong2 w01 = wp[0], w23 = wp[1], w45 = wp[2], w67 = wp[3];
+                    const unsigned long long proj = (w01.x | w01.y) | (w23.x | w23.y) | (w45.x | w45.y) | (w67.x | w67.y);
+                    const float ulo = R.ulo, uhi = R.uhi, oa = R.oa;
+                    const int i0 = 8 * A, last = R.size_a - 2;
+                    const float bo = R.ob - (float)(8 * Bb), co = R.oc - (float)(8 * Bc);
+                    const int bmin = -8 * Bb, bmax = R.size_b - 2 - 8 * Bb, cmin = -8 * Bc, cmax = R.size_c - 2 - 8 * Bc;
+                    const float kEps2 = 2.f * kEps;
+                    // the planes at the brick's two ends, exactly as phase 2 forms them for its first and last slab
+                    const float praw = (i0 == 0) ? -1e30f : (float)i0;
+                    const float qraw = (i0 + 7 >= last) ? 1e30f : (float)(i0 + 8);
+                    const float pu = fminf(fmaxf(praw, ulo), uhi), qu = fminf(fmaxf(qraw, ulo), uhi);
+                    const float pb = fmaf(pu - oa, R.sb, bo), pc = fmaf(pu - oa, R.sc, co);
+                    const float qb = fmaf(qu - oa, R.sb, bo), qc = fmaf(qu - oa, R.sc, co);
+                    const int lb0 = max(sweep_clampi((int)floorf(fminf(pb, qb) - kEps2), bmin, bmax), 0);
+                    const int lb1 = min(sweep_clampi((int)floorf(fmaxf(pb, qb) + kEps2), bmin, bmax), 7);
+                    const int lc0 = max(sweep_clampi((int)floorf(fminf(pc, qc) - kEps2), cmin, cmax), 0);
+                    const int lc1 = min(sweep_clampi((int)floorf(fmaxf(pc, qc) + kEps2), cmin, cmax), 7);
+                    if (lb0 <= lb1 && lc0 <= lc1 && (praw <= uhi) && (qraw >= ulo)) {
+                        const unsigned long long rows = (2ull << (8 * lb1 + 7)) - (1ull << (8 * lb0));
+                        const unsigned pat = ((2u << lc1) - (1u << lc0)) & 0xffu;
+                        const unsigned rep = pat * 0x01010101u;
+                        keep = (proj & rows & (((unsigned long long)rep << 32) | rep)) != 0ull;
+                    }
+                }
+                const unsigned long long mk = __ballot(keep);
+                if (keep) s_task[nkeep + __popcll(mk & ((1ull << lane) - 1ull))] = task;
+                nkeep += __popcll(mk);
+            }
+            ntask = nkeep;
+        }
+        sweep_wave_sync();
+
+        ASURF_SWEEP_LEAVE(3)
         // ---- phase 2: lane = task.  The brick's 8 words; per slab the rectangle mask of the cells between the ray's
         // positions at the slab's two planes; the hits of all tasks in task order (= ray order) ----
         if (lane < rpw) M->cnt[lane] = 0;
@@ -781,6 +854,7 @@ k_sweep_wave(KGrid g, KOpt o, const float* __restrict__ origins, const float* __
                         const int bit = __ffsll((long long)hk) - 1;
                         hk &= hk - 1ull;
                         const int ib = 8 * Bb + (bit >> 3), ic = 8 * Bc + (bit & 7);
+                        s_krl[at] = (unsigned char)rl;
                         s_key[at++] = ((unsigned)(rka ^ i) << 20) | ((unsigned)(rkb ^ ib) << 10) | (unsigned)(rkc ^ ic);
                     }
                 }
@@ -798,6 +872,7 @@ k_sweep_wave(KGrid g, KOpt o, const float* __restrict__ origins, const float* __
         }
         sweep_wave_sync();
 
+        ASURF_SWEEP_LEAVE(4)
         // ---- the rays' slices of the key buffer ----
         {
             const int c = (lane < rpw) ? M->cnt[lane] : 0;
@@ -814,10 +889,7 @@ k_sweep_wave(KGrid g, KOpt o, const float* __restrict__ origins, const float* __
         for (int t0 = 0; t0 < nkey; t0 += 64) {
             const int t = t0 + lane;
             if (t < nkey) {
-                int rl = r_lo;  // the ray whose slice holds t
-#pragma unroll
-                for (int step = kSweepWaveRays / 2; step >= 1; step >>= 1)
-                    if (rl + step < r_hi && M->start[rl + step] <= t) rl += step;
+                const int rl = s_krl[t];
                 unsigned key = s_key[t];
                 const SweepRay& R = s_ray[rl];
                 const int f = R.flags, a = f & 3;
@@ -860,6 +932,7 @@ k_sweep_wave(KGrid g, KOpt o, const float* __restrict__ origins, const float* __
         }
         sweep_wave_sync();
 
+        ASURF_SWEEP_LEAVE(5)
         // ---- phase 4: per ray, counts and allocations ----
         if (lane >= r_lo && lane < r_hi) {
             const long long q = q0 + lane;
@@ -890,14 +963,19 @@ k_sweep_wave(KGrid g, KOpt o, const float* __restrict__ origins, const float* __
         // neighbouring lanes of k_geom hold neighbouring rays at the same depth (slot0[s]: first cell of slot s)
         int lbase;
         {
-            int c = 0;  // rays that fill slot `lane`
+            unsigned fm = 0u;  // rays that fill slot `lane`
             if (lane < P.C1)
-                for (int r2 = r_lo; r2 < r_hi; ++r2) c += (M->n[r2] > lane) ? 1 : 0;
+                for (int r2 = r_lo; r2 < r_hi; ++r2) fm |= (M->n[r2] > lane ? 1u : 0u) << r2;
+            const int c = __popc(fm);
             const int ci = wave_incl_scan(c);
             M->slot0[lane] = ci - c;
+            M->fill[lane] = fm;
             const int cells = bcast_i(ci, 63);
             int lb = 0;
             const int shard = list_segment_unit(P, unit, rpw);
+            if (ASURF_AID(o, 1)) {   // (instrumented build: what the allocation's round trip costs -- results invalid)
+                lb = (int)((unit * 640u) % (unsigned)max(P.list_cap - 1024, 1));
+            } else
             if (lane == 0 && cells > 0) lb = atomicAdd(&P.counters[kCtrListShard0 + shard * kCtrShardStride], cells);
             lbase = shard * P.list_cap + bcast_i(lb, 0);
         }
@@ -909,10 +987,7 @@ k_sweep_wave(KGrid g, KOpt o, const float* __restrict__ origins, const float* __
         for (int t0 = 0; t0 < nkey; t0 += 64) {
             const int t = t0 + lane;
             if (t >= nkey) continue;
-            int rl = r_lo;
-#pragma unroll
-            for (int step = kSweepWaveRays / 2; step >= 1; step >>= 1)
-                if (rl + step < r_hi && M->start[rl + step] <= t) rl += step;
+            const int rl = s_krl[t];
             const unsigned key = s_key[t];
             if (key == kSweepDropped || M->n[rl] == 0) continue;  // n == 0: ray handed back
             const unsigned kk = key & ~kSweepCutBit;
@@ -929,8 +1004,7 @@ k_sweep_wave(KGrid g, KOpt o, const float* __restrict__ origins, const float* __
             const long long q = q0 + rl;
             if (key & kSweepCutBit) atomicMin(&P.cut[q], ord);  // rare
             if (ord < P.C1) {
-                int before = 0;  // rays in front of this one that fill slot `ord` too
-                for (int r2 = r_lo; r2 < rl; ++r2) before += (M->n[r2] > ord) ? 1 : 0;
+                const int before = __popc(M->fill[ord] & ((1u << rl) - 1u));  // rays in front that fill slot `ord` too
                 P.items[(size_t)ord * Q + q] = voxel;
                 P.list[lbase + M->slot0[ord] + before] = ((unsigned)ord << kListRayBits) | (unsigned)q;
             } else {
