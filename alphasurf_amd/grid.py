@@ -1052,6 +1052,9 @@ class SparseGrid(nn.Module):
         dev = self.links.device
         if not contiguous:
             return torch.randint(0, n_cells, (count,), dtype=torch.int32, device=dev)
+        if self.__dict__.get("_device_rng"):   # (inside a captured iteration: the start is drawn on the device)
+            first = (torch.rand(1, device=dev) * n_cells).long().clamp_(max=n_cells - 1)
+            return (torch.arange(count, dtype=torch.int64, device=dev) + first).remainder_(n_cells).to(torch.int32)
         first = int(np.random.randint(0, n_cells))
         run = torch.arange(count, dtype=torch.int64, device=dev).add_(first)
         return run.remainder_(n_cells).to(torch.int32)
@@ -1069,6 +1072,10 @@ class SparseGrid(nn.Module):
         else:
             sparse_num = min(int(sparse_frac * grid_size), int(non_empty_num))
         if contiguous:
+            if self.__dict__.get("_device_rng"):   # (inside a captured iteration: the start is drawn on the device)
+                span = non_empty_num - sparse_num + 1
+                start = (torch.rand(1, device=non_empty_ids.device) * span).long().clamp_(max=span - 1)
+                return non_empty_ids.index_select(0, torch.arange(sparse_num, device=non_empty_ids.device) + start)
             start = np.random.randint(0, non_empty_num - sparse_num + 1)
             return non_empty_ids[start:start + sparse_num].clone()
         return non_empty_ids[torch.randint(0, non_empty_num, (sparse_num,), dtype=torch.long,
@@ -1098,6 +1105,42 @@ class SparseGrid(nn.Module):
         counter: an object's id() is reused as soon as the object is freed, so two successive grids of the same
         shape could otherwise present the same epoch (and often the same links pointer and version)."""
         self.__dict__["_links_epoch"] = next(_LINKS_EPOCHS)
+
+    def capture_iteration(self, fn, rays: Rays, rgb_gt: torch.Tensor, warmup: int = 3):
+        """(extension; the reference has no counterpart)  One training iteration -- `fn(rays, rgb_gt)`: the fused render,
+        the regularisers, the optimizer steps, whatever the caller does per batch with THIS grid -- captured into one
+        HIP graph and returned as a callable `step(rays, rgb_gt)` that copies a new batch of the same shape into the
+        captured buffers and replays the graph.  At the training script's batch size the iteration is bound by the
+        host (a few dozen launches and their Python glue: 0.37 ms per iteration against 0.25 ms of kernels); a replay
+        is one call.  Requirements: shapes and `links` stay what they were (re-capture after up-sampling / pruning);
+        nothing in `fn` reads device memory on the host (a trainable `fake_sample_std` does: `.item()`).  The
+        random cell blocks of the sparse regularisers draw their start on the device inside the graph (torch's
+        graph-safe generator) instead of from numpy.  Returns (step, outputs) with `outputs` what `fn` returned for
+        the captured batch (its tensors are rewritten by every replay)."""
+        assert rays.is_cuda and rgb_gt.is_cuda
+        s_rays = Rays(rays.origins.clone(), rays.dirs.clone())
+        s_gt = rgb_gt.clone()
+        stream = torch.cuda.Stream(device=rgb_gt.device)
+        stream.wait_stream(torch.cuda.current_stream(rgb_gt.device))
+        self.__dict__["_device_rng"] = True
+        try:
+            with torch.cuda.stream(stream):
+                for _ in range(max(1, warmup)):
+                    fn(s_rays, s_gt)
+            stream.synchronize()
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph, stream=stream):
+                outputs = fn(s_rays, s_gt)
+        finally:
+            self.__dict__["_device_rng"] = False
+
+        def step(new_rays: Rays, new_gt: torch.Tensor):
+            s_rays.origins.copy_(new_rays.origins, non_blocking=True)
+            s_rays.dirs.copy_(new_rays.dirs, non_blocking=True)
+            s_gt.copy_(new_gt, non_blocking=True)
+            graph.replay()
+            return outputs
+        return step, outputs
 
     def _get_data_to_links(self):
         """:6378-6382"""

@@ -15,12 +15,12 @@ def env():
     return torch, svox2
 
 
-def make_grid(torch, svox2, reso, basis_dim, seed=2):
+def make_grid(torch, svox2, reso, basis_dim, seed=2, trainable_std=True):
     """The reference gradcheck's grid (test/test_render_gradcheck_surface.py:26-77)."""
     grid = svox2.SparseGrid(reso=reso, center=[0.0, 0.0, 0.0], radius=[1.0, 1.0, 1.0], basis_dim=basis_dim,
                             use_z_order=True, device="cuda:0", background_nlayers=0,
                             basis_type=svox2.BASIS_TYPE_SH, surface_type=svox2.SURFACE_TYPE_SDF,
-                            use_sphere_bound=False, trainable_fake_sample_std=True, surface_init="sphere")
+                            use_sphere_bound=False, trainable_fake_sample_std=trainable_std, surface_init="sphere")
     grid.opt.backend = "surf_trav"
     grid.opt.sigma_thresh = -20
     grid.opt.stop_thresh = 0.0
@@ -269,3 +269,57 @@ def test_coherent_order_is_transparent(env):
     step_given = (rays.dirs[1:] - rays.dirs[:-1]).norm(dim=1).mean()
     assert float(step_sorted) < 0.2 * float(step_given)              # neighbours in the order are neighbours in direction
     assert _C.ray_order(rays.origins[:0], rays.dirs[:0]).numel() == 0
+
+
+def test_captured_iteration_equals_eager_iterations(env):
+    """SparseGrid.capture_iteration: a training iteration (fused render, surface TV, normal and eikonal regularisers, the
+    three optimizer steps) captured into one HIP graph and replayed on new batches must leave the parameters where the
+    same iterations leave them when issued call by call (float atomics reorder sums: 1e-4 of the parameter range)."""
+    torch, svox2 = env
+
+    def build():
+        # (a trainable fake_sample_std is read on the host in every call: not capturable)
+        grid = make_grid(torch, svox2, 32, 4, seed=9, trainable_std=False)
+        grid.opt.surf_fake_sample = False
+        grid.requires_grad_(True)
+        return grid
+
+    def iteration(grid):
+        def fn(rays, gt):
+            out = grid.volume_render_fused(rays, gt, lambda_l2=1.0, lambda_l_entropy=1e-4, l_dist_max_sample=64)
+            grid.inplace_tv_surface_grad(grid.surface_data.grad, scaling=1e-3, sparse_frac=1, ignore_edge=True,
+                                         edge_value=-1.0, alpha_dependency=True)
+            grid.inplace_surface_normal_grad(grid.surface_data.grad, scaling=1e-5, sparse_frac=1, connectivity_check=True,
+                                             ignore_empty=False, use_l1=True)
+            grid.inplace_surface_eikonal_grad(grid.surface_data.grad, scaling=1e-4, sparse_frac=1, use_kernel=False)
+            grid.optim_density_step(1e-2, beta=0.95, optim="rmsprop")
+            grid.optim_surface_step(1e-4, beta=0.95, optim="rmsprop")
+            grid.optim_sh_step(1e-3, beta=0.95, optim="rmsprop")
+            return out["rgb"]
+        return fn
+
+    rs = np.random.RandomState(3)
+    batches = []
+    for _ in range(4):
+        o = (rs.randn(600, 3) * 3).astype(np.float32)
+        d = -o + rs.randn(600, 3).astype(np.float32) * 0.3
+        d /= np.linalg.norm(d, axis=-1, keepdims=True)
+        batches.append((svox2.Rays(torch.from_numpy(o).cuda(), torch.from_numpy(d).cuda()),
+                        torch.from_numpy(rs.rand(600, 3).astype(np.float32)).cuda()))
+    eager = build()
+    fn = iteration(eager)
+    for _ in range(4):              # what capture_iteration does before it captures: 3 warm-up runs + the captured one,
+        fn(*batches[0])             # all on the first batch
+    rgb_e = [fn(r, g).clone() for r, g in batches[1:]]
+    graphed = build()
+    step, _ = graphed.capture_iteration(iteration(graphed), *batches[0], warmup=3)
+    step(*batches[0])
+    # (the capture itself does not execute: warm-up 3 + this replay = the eager twin's 4 runs on batch 0)
+    rgb_g = [step(r, g).clone() for r, g in batches[1:]]
+    torch.cuda.synchronize()
+    for a, b in zip(rgb_e, rgb_g):
+        assert float((a - b).abs().max()) <= 1e-4
+    for name in ("density_data", "surface_data", "sh_data"):
+        pe, pg = getattr(eager, name).data, getattr(graphed, name).data
+        scale = float(pe.abs().max())
+        assert float((pe - pg).abs().max()) <= 2e-4 * scale, name

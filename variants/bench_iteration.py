@@ -10,6 +10,7 @@ from alphasurf_amd import synth
 ap = argparse.ArgumentParser()
 ap.add_argument("--rays", type=int, default=0, help="0: the whole 800x800 view in image order; N: N shuffled rays of it")
 ap.add_argument("--iters", type=int, default=30)
+ap.add_argument("--graph", action="store_true", help="capture the iteration into one HIP graph (SparseGrid.capture_iteration)")
 args = ap.parse_args()
 dev = torch.device("cuda:0")
 sc = synth.make_sparse_scene(256, 9, trunc_a=5.0, **synth.BENCH_SCENE)
@@ -38,7 +39,7 @@ grid.requires_grad_(True)
 F = synth.SYN_FUSED
 
 
-def iteration():
+def iteration(rays=rays, gt=gt):
     grid.volume_render_fused(rays, gt, lambda_l2=F["lambda_l2"], lambda_l1=F["lambda_l1"],
                              lambda_l_entropy=F["lambda_l_entropy"], lambda_conv_mode_samp=F["lambda_conv_mode_samp"],
                              l_dist_max_sample=F["l_dist_max_sample"], l_di_alpha_thresh=F["l_di_alpha_thresh"],
@@ -58,15 +59,23 @@ def iteration():
 for _ in range(5):
     iteration()
 torch.cuda.synchronize()
+if args.graph:
+    step, _ = grid.capture_iteration(iteration, rays, gt)
+    run = lambda: step(rays, gt)
+    for _ in range(3):
+        run()
+    torch.cuda.synchronize()
+else:
+    run = iteration
 a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 import time
 t0 = time.perf_counter()
 a.record()
 for _ in range(args.iters):
-    iteration()
+    run()
 b.record()
 torch.cuda.synchronize()
 wall = (time.perf_counter() - t0) / args.iters * 1e3
 ms = a.elapsed_time(b) / args.iters
-print(json.dumps(dict(rays=o.shape[0], ms_per_iteration=round(ms, 3), wall_ms_per_iteration=round(wall, 3),
+print(json.dumps(dict(graph=bool(args.graph), rays=o.shape[0], ms_per_iteration=round(ms, 3), wall_ms_per_iteration=round(wall, 3),
                       iterations_per_s=round(1e3 / wall, 1), Mrays_per_s=round(o.shape[0] / wall / 1e3, 2))))
