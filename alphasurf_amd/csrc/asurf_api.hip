@@ -508,10 +508,11 @@ void mask_cache_store(void* ws, unsigned long long epoch, const asurf_grid* grid
 // pairs) in pinned memory, asynchronously; the next call reads it if it has arrived.  Unknown means "as given".
 struct OrderState {
     void* ws = nullptr;
-    int* h_probe = nullptr;   // pinned: coherent pairs, pairs looked at
+    int* h_probe = nullptr;   // pinned: coherent pairs, pairs looked at, pairs with different origins
     hipEvent_t ev = nullptr;
     bool pending = false;
     int coherent = -1;        // -1 unknown, 0 shuffled, 1 coherent
+    int one_origin = 0;       // 1: no sampled pair of the last batch had two origins (a batch of one camera)
     unsigned long long used = 0;
 };
 constexpr int kOrderStates = 8;
@@ -522,7 +523,7 @@ unsigned long long g_order_clock = 0;
 // returns what is known about the batches of `ws` (-1 / 0 / 1) and, unless a graph is being captured, queues the probe of
 // THIS batch for the next call
 int order_probe(void* ws, const float* origins, const float* dirs, long long n, int* d_probe, hipStream_t stream,
-                bool capturing) {
+                bool capturing, int* one_origin) {
     std::lock_guard<std::mutex> lock(g_order_mu);
     OrderState* slot = nullptr;
     for (OrderState& e : g_order)
@@ -538,30 +539,38 @@ int order_probe(void* ws, const float* origins, const float* dirs, long long n, 
         slot->ws = ws;
         slot->pending = false;
         slot->coherent = -1;
+        slot->one_origin = 0;
     }
     slot->used = ++g_order_clock;
-    if (capturing) return slot->coherent;
-    if (slot->pending) {
+    // (one probe in flight at a time; none while a graph is being captured)
+    bool may_probe = !capturing;
+    if (may_probe && slot->pending) {
         if (hipEventQuery(slot->ev) == hipSuccess) {
             slot->pending = false;
-            if (slot->h_probe[1] > 0) slot->coherent = (2 * slot->h_probe[0] >= slot->h_probe[1]) ? 1 : 0;
+            if (slot->h_probe[1] > 0) {
+                slot->coherent = (2 * slot->h_probe[0] >= slot->h_probe[1]) ? 1 : 0;
+                slot->one_origin = slot->h_probe[2] == 0 ? 1 : 0;
+            }
         } else {
             (void)hipGetLastError();  // "not ready" is no error of this call
-            return slot->coherent;    // (one probe in flight at a time)
+            may_probe = false;
         }
     }
-    if (!slot->h_probe && hipHostMalloc(reinterpret_cast<void**>(&slot->h_probe), 2 * sizeof(int)) != hipSuccess) {
+    if (may_probe && !slot->h_probe && hipHostMalloc(reinterpret_cast<void**>(&slot->h_probe), 3 * sizeof(int)) != hipSuccess) {
         slot->h_probe = nullptr;
-        return slot->coherent;
+        may_probe = false;
     }
-    if (!slot->ev && hipEventCreateWithFlags(&slot->ev, hipEventDisableTiming) != hipSuccess) {
+    if (may_probe && !slot->ev && hipEventCreateWithFlags(&slot->ev, hipEventDisableTiming) != hipSuccess) {
         slot->ev = nullptr;
-        return slot->coherent;
+        may_probe = false;
     }
-    asurf_order::probe(origins, dirs, n, d_probe, stream);
-    if (hipMemcpyAsync(slot->h_probe, d_probe, 2 * sizeof(int), hipMemcpyDeviceToHost, stream) == hipSuccess &&
-        hipEventRecord(slot->ev, stream) == hipSuccess)
-        slot->pending = true;
+    if (may_probe) {
+        asurf_order::probe(origins, dirs, n, d_probe, stream);
+        if (hipMemcpyAsync(slot->h_probe, d_probe, 3 * sizeof(int), hipMemcpyDeviceToHost, stream) == hipSuccess &&
+            hipEventRecord(slot->ev, stream) == hipSuccess)
+            slot->pending = true;
+    }
+    *one_origin = slot->one_origin;
     return slot->coherent;
 }
 
@@ -1251,8 +1260,10 @@ int asurf_volume_render_surf_trav_fused(const asurf_grid* grid, const asurf_rays
         const bool capturing = hipStreamIsCapturing(L.stream, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone;
         int* d_probe = reinterpret_cast<int*>(L.ws + L.ML.off_ord_probe);
         bool order = fused->order_rays == 2;
+        int one_origin = 0;
         if (fused->order_rays == 0) {
-            order = order_probe(workspace, rays->origins, rays->dirs, rays->n_rays, d_probe, L.stream, capturing) == 0;
+            order = order_probe(workspace, rays->origins, rays->dirs, rays->n_rays, d_probe, L.stream, capturing,
+                                &one_origin) == 0;
             prof_after("ray_probe", 1, L.stream);
         }
         if (order) {
@@ -1260,8 +1271,9 @@ int asurf_volume_render_surf_trav_fused(const asurf_grid* grid, const asurf_rays
             float* o_s = reinterpret_cast<float*>(L.ws + L.ML.off_ord_o);
             float* d_s = reinterpret_cast<float*>(L.ws + L.ML.off_ord_d);
             float* gt_s = reinterpret_cast<float*>(L.ws + L.ML.off_ord_gt);
+            // (a batch of one camera sorts on the direction's 24 bits: three radix passes instead of four)
             if (asurf_order::order32(rays->origins, rays->dirs, rays->n_rays, pm, L.ws + L.ML.off_ord_tmp, L.ML.ord_tmp_bytes,
-                                     L.stream) != 0)
+                                     L.stream, one_origin ? 24 : 30) != 0)
                 return fail(ASURF_E_LAUNCH, "ray ordering failed");
             asurf_order::gather(rays->origins, rays->dirs, fused->rgb_gt, pm, rays->n_rays, o_s, d_s, gt_s, L.stream);
             prof_after("ray_order", 1, L.stream);

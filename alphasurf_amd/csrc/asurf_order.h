@@ -7,11 +7,13 @@ namespace asurf_order {
 size_t tmp_bytes32(long long n);
 // perm[i] = the caller's index of the ray that comes i-th (rays of one origin together, along a Morton curve of the
 // direction); tmp: tmp_bytes32(n) bytes of device scratch
+// key_bits: 30 (origin hash + direction) or 24 (direction only: every ray of the batch has the same origin)
 int order32(const float* origins, const float* dirs, long long n, unsigned* perm, void* tmp, size_t tmp_bytes,
-            hipStream_t s);
+            hipStream_t s, int key_bits);
 void gather(const float* origins, const float* dirs, const float* gt, const unsigned* perm, long long n, float* o_s,
             float* d_s, float* gt_s, hipStream_t s);
 void scatter_rgb(const float* rgb_s, const unsigned* perm, long long n, float* rgb, hipStream_t s);
-// out2[0] = coherent pairs, out2[1] = pairs looked at (a sample of 8192 consecutive pairs)
+// out3[0] = coherent pairs, out3[1] = pairs looked at, out3[2] = pairs with different origins (a sample of 8192
+// consecutive pairs)
 void probe(const float* origins, const float* dirs, long long n, int* out2, hipStream_t s);
 }  // namespace asurf_order

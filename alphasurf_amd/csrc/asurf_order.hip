@@ -44,8 +44,8 @@ k_order_keys(const float* __restrict__ origins, const float* __restrict__ dirs, 
 }
 
 // ---- the same ordering inside the fused call (asurf_api.hip, asurf_fused_params::order_rays) ----
-// 32-bit keys: 6 bits of the origin's hash, then 26 bits of the direction in the octahedral map of the sphere -- four
-// radix passes instead of seven and half the key bytes of the 50-bit form.  (With 9 bits per direction component the
+// 30-bit keys: 6 bits of the origin's hash, then 24 bits of the direction in the octahedral map of the sphere -- three
+// or four radix passes instead of seven and half the key bytes of the 50-bit form.  (With 9 bits per direction component the
 // cells were four pixels wide and the rays inside a cell stayed shuffled: k_bwd_sh 0.29 ms against 0.17 in image order.)
 __device__ __forceinline__ unsigned spread2(unsigned x) {  // one zero bit between the low 13 bits
     x &= 0x1FFFu;
@@ -69,17 +69,18 @@ k_order_keys32(const float* __restrict__ origins, const float* __restrict__ dirs
         u = fu;
         v = fv;
     }
-    // strips: v in 12 bits (a strip about a pixel wide), u in 14 bits along the strip -- scan-line order.  The kernels
+    // strips: v in 12 bits (a strip about a pixel wide), u in 12 bits along the strip -- scan-line order; the origin's
+    // hash above them, so that a batch of one camera sorts on 24 bits (three radix passes: order32's key_bits).  The kernels
     // that merge the samples of consecutive rays (k_bwd_sh, k_bwd_geo) want neighbours ALONG a line: a Z curve over
     // the pixels (13 + 13 bits interleaved) cost them 0.243 / 0.144 ms against 0.169 / 0.110 in image order.
-    const unsigned qu = (unsigned)fminf(fmaxf((u + 1.f) * 8191.75f, 0.f), 16383.f);
+    const unsigned qu = (unsigned)fminf(fmaxf((u + 1.f) * 2047.75f, 0.f), 4095.f);
     const unsigned qv = (unsigned)fminf(fmaxf((v + 1.f) * 2047.75f, 0.f), 4095.f);
-    const unsigned morton = (qv << 14) | qu;
+    const unsigned morton = (qv << 12) | qu;
     unsigned h = __float_as_uint(origins[3 * i]) * 0x9E3779B1u;
     h = (h ^ __float_as_uint(origins[3 * i + 1])) * 0x85EBCA77u;
     h = (h ^ __float_as_uint(origins[3 * i + 2])) * 0xC2B2AE3Du;
     h ^= h >> 15;
-    keys[i] = ((h & 63u) << 26) | morton;
+    keys[i] = ((h & 63u) << 24) | morton;
     ids[i] = (unsigned)i;
 }
 
@@ -107,13 +108,14 @@ k_order_scatter(const float* __restrict__ rgb_s, const unsigned* __restrict__ pe
 }
 
 // How coherent is the batch as it stands?  Of a sample of consecutive pairs (q, q + 1), those that share an origin and
-// point within a few pixels of each other: out[0] = such pairs, out[1] = pairs looked at.  One block, no atomics, no
+// point within a few pixels of each other: out[0] = such pairs, out[1] = pairs looked at, out[2] = pairs whose origins
+// differ.  One block, no atomics, no
 // buffer to clear.
 __global__ void __launch_bounds__(1024)
 k_order_probe(const float* __restrict__ origins, const float* __restrict__ dirs, long long n, long long stride,
               int per_thread, int* __restrict__ out) {
-    __shared__ int s_ok[16], s_seen[16];
-    int ok = 0, seen = 0;
+    __shared__ int s_ok[16], s_seen[16], s_diff[16];
+    int ok = 0, seen = 0, diff = 0;
     for (int j = 0; j < per_thread; ++j) {
         const long long i = ((long long)j * blockDim.x + threadIdx.x) * stride;
         if (i + 1 < n) {
@@ -130,26 +132,31 @@ k_order_probe(const float* __restrict__ origins, const float* __restrict__ dirs,
             }
             // within 0.6 degrees (8 pixels of an 800-pixel, 40-degree view): cos^2 > 0.99989
             ok += (same && dot > 0.f && dot * dot > 0.99989f * na * nb) ? 1 : 0;
+            diff += same ? 0 : 1;
         }
     }
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) {
         ok += __shfl_xor(ok, d);
         seen += __shfl_xor(seen, d);
+        diff += __shfl_xor(diff, d);
     }
     if ((threadIdx.x & 63) == 0) {
         s_ok[threadIdx.x >> 6] = ok;
         s_seen[threadIdx.x >> 6] = seen;
+        s_diff[threadIdx.x >> 6] = diff;
     }
     __syncthreads();
     if (threadIdx.x == 0) {
-        int a = 0, b2 = 0;
+        int a = 0, b2 = 0, c2 = 0;
         for (int w = 0; w < (int)(blockDim.x >> 6); ++w) {
             a += s_ok[w];
             b2 += s_seen[w];
+            c2 += s_diff[w];
         }
         out[0] = a;
         out[1] = b2;
+        out[2] = c2;
     }
 }
 
@@ -194,7 +201,7 @@ size_t tmp_bytes32(long long n) {
 }
 
 int order32(const float* origins, const float* dirs, long long n, unsigned* perm, void* tmp, size_t tmp_bytes,
-            hipStream_t s) {
+            hipStream_t s, int key_bits) {
     auto up = [](size_t x) { return (x + 255) / 256 * 256; };
     if (n <= 0) return 0;
     if (tmp_bytes < tmp_bytes32(n)) return -1;
@@ -205,7 +212,8 @@ int order32(const float* origins, const float* dirs, long long n, unsigned* perm
     auto* ids_in = reinterpret_cast<unsigned*>(base + 2 * plane);
     hipLaunchKernelGGL(k_order_keys32, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, origins, dirs, n, keys_in, ids_in);
     size_t sb = tmp_bytes - 3 * plane;
-    const hipError_t e = rocprim::radix_sort_pairs(base + 3 * plane, sb, keys_in, keys_out, ids_in, perm, (size_t)n, 0u, 32u, s);
+    const hipError_t e = rocprim::radix_sort_pairs(base + 3 * plane, sb, keys_in, keys_out, ids_in, perm, (size_t)n, 0u,
+                                                   (unsigned)key_bits, s);
     return (e == hipSuccess && hipGetLastError() == hipSuccess) ? 0 : -3;
 }
 
