@@ -522,8 +522,10 @@ unsigned long long g_order_clock = 0;
 
 // returns what is known about the batches of `ws` (-1 / 0 / 1) and, unless a graph is being captured, queues the probe of
 // THIS batch for the next call
+// launch = false: what is known (called before the render); true: queue the probe of this batch (called after the
+// render's last kernel, so that neither the probe nor its copy to the host stands in front of anything)
 int order_probe(void* ws, const float* origins, const float* dirs, long long n, int* d_probe, hipStream_t stream,
-                bool capturing, int* one_origin) {
+                bool capturing, int* one_origin, bool launch) {
     std::lock_guard<std::mutex> lock(g_order_mu);
     OrderState* slot = nullptr;
     for (OrderState& e : g_order)
@@ -544,6 +546,7 @@ int order_probe(void* ws, const float* origins, const float* dirs, long long n, 
     slot->used = ++g_order_clock;
     // (one probe in flight at a time; none while a graph is being captured)
     bool may_probe = !capturing;
+    if (!launch && !(may_probe && slot->pending)) may_probe = false;   // (before the render: only collect an answer)
     if (may_probe && slot->pending) {
         if (hipEventQuery(slot->ev) == hipSuccess) {
             slot->pending = false;
@@ -564,7 +567,7 @@ int order_probe(void* ws, const float* origins, const float* dirs, long long n, 
         slot->ev = nullptr;
         may_probe = false;
     }
-    if (may_probe) {
+    if (may_probe && launch) {
         asurf_order::probe(origins, dirs, n, d_probe, stream);
         if (hipMemcpyAsync(slot->h_probe, d_probe, 3 * sizeof(int), hipMemcpyDeviceToHost, stream) == hipSuccess &&
             hipEventRecord(slot->ev, stream) == hipSuccess)
@@ -1255,6 +1258,8 @@ int asurf_volume_render_surf_trav_fused(const asurf_grid* grid, const asurf_rays
     const float* rgb_gt_use = fused->rgb_gt;
     float* rgb_use = rgb_out;
     const unsigned* perm = nullptr;
+    bool probe_after = false;
+    const asurf_rays* rays_given = rays;
     if (rays->n_rays >= kOrderMinRays && fused->order_rays != 1) {
         hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
         const bool capturing = hipStreamIsCapturing(L.stream, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone;
@@ -1263,8 +1268,8 @@ int asurf_volume_render_surf_trav_fused(const asurf_grid* grid, const asurf_rays
         int one_origin = 0;
         if (fused->order_rays == 0) {
             order = order_probe(workspace, rays->origins, rays->dirs, rays->n_rays, d_probe, L.stream, capturing,
-                                &one_origin) == 0;
-            prof_after("ray_probe", 1, L.stream);
+                                &one_origin, false) == 0;
+            probe_after = !capturing;
         }
         if (order) {
             unsigned* pm = reinterpret_cast<unsigned*>(L.ws + L.ML.off_ord_perm);
@@ -1326,9 +1331,13 @@ int asurf_volume_render_surf_trav_fused(const asurf_grid* grid, const asurf_rays
     if (perm != nullptr) {
         asurf_order::scatter_rgb(rgb_use, perm, rays->n_rays, rgb_out, L.stream);
         prof_after("ray_order_scatter", 2, L.stream);
-        return launch_error("ray order scatter");
     }
-    return rc;
+    if (probe_after) {   // how coherent was THIS batch as it came?  (read by the next call through this workspace)
+        int one_origin = 0;
+        (void)order_probe(workspace, rays_given->origins, rays_given->dirs, rays_given->n_rays,
+                          reinterpret_cast<int*>(L.ws + L.ML.off_ord_probe), L.stream, false, &one_origin, true);
+    }
+    return launch_error("fused call epilogue");
 }
 
 static int optim_launch(bool rms_mode, float* data, float* rms, float* grad, int64_t n_rows,

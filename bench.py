@@ -164,8 +164,8 @@ def build_roofline(spans, shares, dom_name, call_ms, model_bytes, cfg_key, count
         per_kernel_GBps={k: round(shares.get(k, 0.0) / (v * 1e-3) / 1e9, 1) for k, v in spans.items() if v > 0},
         whole_call=dict(algorithmic_bytes=model_bytes, achieved=round(model_bytes / (call_ms * 1e-3) / 1e9, 1),
                         frac=round(model_bytes / (call_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)))
-    if counters is None:
-        # no counters for this configuration: nothing measured to price a ceiling with
+    if counters is None or dom["bound"] is None:
+        # no counters for this configuration (or none for its dominant kernel): nothing measured to price a ceiling with
         return dict(bound="hbm", kernel=dom_name, achieved=None, peak=HBM_PEAK_GBPS, unit="GB/s", frac=None, traffic=None,
                     avg_launch_ms=round(dom_ms, 4), per_kernel_ms={k: round(v, 4) for k, v in spans.items()},
                     note="no PMC counters on file for this configuration (variants/pmc_profile.sh collects them)",
@@ -396,7 +396,8 @@ def main():
         dom_name = max(spans, key=spans.get)
         call_ms = t_mask + t_fwd + t_bwd
         cfg_key = dict(reso=R, basis_dim=B, width=args.width, band=args.band, shuffle=bool(args.shuffle),
-                       sort=bool(args.sort), links_epoch=bool(args.links_epoch), rays=Q)
+                       sort=bool(args.sort), links_epoch=bool(args.links_epoch), rays=Q, heavy=args.heavy,
+                       order_rays=args.order_rays)
         roofline = build_roofline(spans, shares, dom_name, call_ms, b_f + b_b, cfg_key,
                                   args.counters or os.path.join(ROOT, "profiles", "counters.json"))
         roofline["groups_ms"] = dict(k_build_masks=round(t_mask, 4), forward=round(t_fwd, 4), backward=round(t_bwd, 4))

@@ -1,3 +1,6 @@
-import json,sys
-d=json.load(sys.stdin); r=d["roofline"]
-print(sys.argv[1], d["value"], d["ms_per_step"], r["kernel"], r["frac"], r["whole_call"], r["per_kernel_ms"])
+"""One line per bench run (stdin: bench.py's JSON line): value, ms/step, dominant kernel and its ceiling, per-kernel ms."""
+import json, sys
+d = json.load(sys.stdin)
+r = d["roofline"]
+print(d["value"], d["ms_per_step"], r["kernel"], r.get("bound"), r.get("frac"), (d.get("verify") or {}).get("ok"),
+      r["per_kernel_ms"])

@@ -7,7 +7,7 @@ write_bytes, and the SQ counters (chip-wide sums per dispatch)."""
 import csv, glob, json, os, re, shutil, sys
 
 root, tag, cmd = sys.argv[1], sys.argv[2], sys.argv[3:]
-RENAME = {"k_forward": "k_forward_fallback", "k_backward": "k_backward_fallback"}
+RENAME = {"k_forward": "k_forward_fallback", "k_backward": "k_backward_fallback", "k_sweep_wave": "k_sweep"}   # (bench.py's span names)
 
 
 def short(name):
@@ -48,7 +48,7 @@ import bench  # noqa: E402
 a = bench.parse()
 Q = a.width * a.width
 cfg = dict(reso=a.reso, basis_dim=a.basis_dim, width=a.width, band=a.band, shuffle=bool(a.shuffle), sort=bool(a.sort),
-           links_epoch=bool(a.links_epoch), rays=Q)
+           links_epoch=bool(a.links_epoch), rays=Q, heavy=a.heavy, order_rays=a.order_rays)
 
 kernels = {}
 names = sorted({k for k, _ in list(fetch) + list(write) + list(sq) if k.startswith("k_")})
