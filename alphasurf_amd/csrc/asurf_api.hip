@@ -62,6 +62,7 @@ struct Config {
     int eval_walk = 0;     // ASURF_EVAL=walk: the stepping evaluation renders
     int timeline = 0;      // ASURF_TIMELINE = kernel id (instrumented build)
     int side_stream = 0;   // ASURF_SIDE_STREAM: the fused call's fallback kernels on a stream of their own (measured: slower)
+    int order_radix = 0;   // ASURF_ORDER=radix: the ray ordering through rocPRIM's radix sort instead of the strip sort
     int masks_row = 0;     // ASURF_MASKS=row: the one-pass occupancy kernel (k_build_masks) instead of the two stages
     int sweep_block = 0;   // ASURF_SWEEP=block: the block-synchronous form of k_sweep (round 2)
     int sweep_wpb = 0;     // ASURF_SWEEP_WPB = 1, 2, 4: waves per block of k_sweep_wave (measurement)
@@ -89,6 +90,7 @@ bool config_assign(Config& c, const char* name, const char* value) {
     else if (!strcmp(name, "ASURF_EVAL")) c.eval_walk = (value && !strcmp(value, "walk")) ? 1 : 0;
     else if (!strcmp(name, "ASURF_TIMELINE")) c.timeline = n;
     else if (!strcmp(name, "ASURF_SIDE_STREAM")) c.side_stream = n ? 1 : 0;
+    else if (!strcmp(name, "ASURF_ORDER")) c.order_radix = (value && !strcmp(value, "radix")) ? 1 : 0;
     else if (!strcmp(name, "ASURF_MASKS")) c.masks_row = (value && !strcmp(value, "row")) ? 1 : 0;
     else if (!strcmp(name, "ASURF_SWEEP")) c.sweep_block = (value && !strcmp(value, "block")) ? 1 : 0;
     else if (!strcmp(name, "ASURF_SWEEP_WPB")) c.sweep_wpb = (n == 1 || n == 2 || n == 4) ? n : 0;
@@ -101,7 +103,7 @@ Config config() {  // a copy: a call works with one consistent set
     std::call_once(g_cfg_once, [] {
         static const char* const names[] = {"ASURF_DEBUG", "ASURF_WALK_SEG", "ASURF_WALK", "ASURF_RPW", "ASURF_NO_PIPELINE",
                                             "ASURF_CUVOL_RPW", "ASURF_NO_REPLAY", "ASURF_NO_SPLIT_BWD", "ASURF_EVAL",
-                                            "ASURF_TIMELINE", "ASURF_SWEEP", "ASURF_SWEEP_WPB", "ASURF_SWEEP_RPW", "ASURF_MASKS", "ASURF_SIDE_STREAM"};
+                                            "ASURF_TIMELINE", "ASURF_SWEEP", "ASURF_SWEEP_WPB", "ASURF_SWEEP_RPW", "ASURF_MASKS", "ASURF_SIDE_STREAM", "ASURF_ORDER"};
         std::lock_guard<std::mutex> lock(g_cfg_mu);
         for (const char* nm : names)
             if (const char* v = getenv(nm)) config_assign(g_cfg, nm, v);
@@ -252,7 +254,7 @@ MaskLayout layout_for(const int32_t size[3], int64_t n_rays, int32_t M) {
     off = align_up(off + onr * 12, 256);
     L.off_ord_rgb = off;
     off = align_up(off + onr * 12, 256);
-    L.ord_tmp_bytes = onr ? asurf_order::tmp_bytes32((long long)onr) : 0;
+    L.ord_tmp_bytes = onr ? std::max(asurf_order::tmp_bytes32((long long)onr), asurf_order::tmp_bytes_strips((long long)onr)) : 0;
     L.off_ord_tmp = off;
     off = align_up(off + L.ord_tmp_bytes, 256);
     L.off_ord_probe = off;
@@ -1276,11 +1278,15 @@ int asurf_volume_render_surf_trav_fused(const asurf_grid* grid, const asurf_rays
             float* o_s = reinterpret_cast<float*>(L.ws + L.ML.off_ord_o);
             float* d_s = reinterpret_cast<float*>(L.ws + L.ML.off_ord_d);
             float* gt_s = reinterpret_cast<float*>(L.ws + L.ML.off_ord_gt);
-            // (a batch of one camera sorts on the direction's 24 bits: three radix passes instead of four)
-            if (asurf_order::order32(rays->origins, rays->dirs, rays->n_rays, pm, L.ws + L.ML.off_ord_tmp, L.ML.ord_tmp_bytes,
-                                     L.stream, one_origin ? 24 : 30) != 0)
+            if (config().order_radix) {   // rocPRIM's radix sort + a gather (ASURF_ORDER=radix: the form the strip sort is tested against)
+                if (asurf_order::order32(rays->origins, rays->dirs, rays->n_rays, pm, L.ws + L.ML.off_ord_tmp,
+                                         L.ML.ord_tmp_bytes, L.stream, one_origin ? 24 : 30) != 0)
+                    return fail(ASURF_E_LAUNCH, "ray ordering failed");
+                asurf_order::gather(rays->origins, rays->dirs, fused->rgb_gt, pm, rays->n_rays, o_s, d_s, gt_s, L.stream);
+            } else if (asurf_order::order_strips(rays->origins, rays->dirs, fused->rgb_gt, rays->n_rays, pm, o_s, d_s, gt_s,
+                                                 L.ws + L.ML.off_ord_tmp, L.ML.ord_tmp_bytes, L.stream) != 0) {
                 return fail(ASURF_E_LAUNCH, "ray ordering failed");
-            asurf_order::gather(rays->origins, rays->dirs, fused->rgb_gt, pm, rays->n_rays, o_s, d_s, gt_s, L.stream);
+            }
             prof_after("ray_order", 1, L.stream);
             rays_ord.origins = o_s;
             rays_ord.dirs = d_s;

@@ -795,7 +795,10 @@ __device__ __forceinline__ bool voxel_may_hold_root(const KGrid& g, const Ray& r
         if (lvf < smin || lvf > smax) continue;
         const float c0 = p_a - lvf;
         const float b1 = fmaf(c1, 1.f / 3.f, c0), b2 = fmaf(2.f * c1 + c2, 1.f / 3.f, c0), b3 = c0 + c1 + c2 + c3;
-        const float margin = 1e-4f * (smag + fabsf(lvf)) + 1e-30f;
+        // relative to the field's magnitude (the float evaluation above), with an absolute floor: where the solver takes
+        // its quadratic / linear form (|f3| or |f2| below 1e-10) it drops a term worth up to 1e-9 over the interval,
+        // whatever the field's scale -- a field of tiny values must not be filtered on a margin smaller than that
+        const float margin = 1e-4f * (smag + fabsf(lvf)) + 1e-8f;
         const float mn = fminf(fminf(c0, b1), fminf(b2, b3)), mx = fmaxf(fmaxf(c0, b1), fmaxf(b2, b3));
         if (!(mn > margin || mx < -margin)) maybe = true;
     }

@@ -10,6 +10,11 @@ size_t tmp_bytes32(long long n);
 // key_bits: 30 (origin hash + direction) or 24 (direction only: every ray of the batch has the same origin)
 int order32(const float* origins, const float* dirs, long long n, unsigned* perm, void* tmp, size_t tmp_bytes,
             hipStream_t s, int key_bits);
+// The same ordering as a sort of its own (count per strip, scan, scatter, strip-local bitonic sort that also gathers):
+// perm AND the rays / targets in the new order; tmp: tmp_bytes_strips(n) bytes
+size_t tmp_bytes_strips(long long n);
+int order_strips(const float* origins, const float* dirs, const float* gt, long long n, unsigned* perm, float* o_s,
+                 float* d_s, float* gt_s, void* tmp, size_t tmp_bytes, hipStream_t s);
 void gather(const float* origins, const float* dirs, const float* gt, const unsigned* perm, long long n, float* o_s,
             float* d_s, float* gt_s, hipStream_t s);
 void scatter_rgb(const float* rgb_s, const unsigned* perm, long long n, float* rgb, hipStream_t s);

@@ -188,6 +188,183 @@ Plan plan_for(long long n) {
 
 }  // namespace
 
+// ---- the ordering as a two-level sort of its own (order_strips) ----
+// rocPRIM's radix sort is 21 launches for 640 k keys (143 us of the 197 us the ordering took).  The keys have structure:
+// the high 18 bits name a strip (origin hash, v), a batch lights up a few hundred to a few thousand of the 262 144
+// strips, and a strip holds a few hundred rays.  So: count the rays per strip (one atomic a ray; its return value is
+// the ray's place in the strip), scan the counts (one block; it also lists the strips that hold anything), scatter
+// (u, ray) pairs to their strips, and sort every strip by u in LDS (bitonic, ties by ray number: the result does not depend
+// on the order of the atomics) -- that kernel writes the permutation AND the gathered rays / targets.  A memset and five
+// launches.  (First form: one counter a strip and one block scanning 2^18 counters -- 0.11 and 0.34 ms: the counters
+// were hit 700 times each by atomics that return a value, and the scan's loads did not coalesce.)
+constexpr int kStripBits = 16;    // strips: 4 bits of the origin's hash, 12 bits of v
+constexpr int kSubBits = 4;       // counters per strip: a strip's rays are counted in 16 cells (by the ray's number), because
+                                  // atomics on ONE address that return a value retire at about 150 ns apiece -- 700 rays on one
+                                  // counter were 0.11 ms
+constexpr int kCells = 1 << (kStripBits + kSubBits);
+constexpr int kScanBlocks = kCells / 1024;
+constexpr int kStripMax = 2048;   // rays of one strip sorted together (a longer strip is sorted in pieces of this size)
+
+__device__ __forceinline__ unsigned strip_key(const float* __restrict__ origins, const float* __restrict__ dirs, long long i) {
+    const float dx = dirs[3 * i], dy = dirs[3 * i + 1], dz = dirs[3 * i + 2];
+    const float rn = 1.f / fmaxf(fabsf(dx) + fabsf(dy) + fabsf(dz), 1e-30f);
+    float u = dx * rn, v = dy * rn;
+    if (dz < 0.f) {
+        const float fu = (1.f - fabsf(v)) * (u >= 0.f ? 1.f : -1.f), fv = (1.f - fabsf(u)) * (v >= 0.f ? 1.f : -1.f);
+        u = fu;
+        v = fv;
+    }
+    const unsigned qu = (unsigned)fminf(fmaxf((u + 1.f) * 2047.75f, 0.f), 4095.f);
+    const unsigned qv = (unsigned)fminf(fmaxf((v + 1.f) * 2047.75f, 0.f), 4095.f);
+    unsigned h = __float_as_uint(origins[3 * i]) * 0x9E3779B1u;
+    h = (h ^ __float_as_uint(origins[3 * i + 1])) * 0x85EBCA77u;
+    h = (h ^ __float_as_uint(origins[3 * i + 2])) * 0xC2B2AE3Du;
+    h ^= h >> 15;
+    return ((h & 15u) << 24) | (qv << 12) | qu;   // strip = key >> 12, u = key & 4095
+}
+
+__global__ void __launch_bounds__(256)
+k_strip_count(const float* __restrict__ origins, const float* __restrict__ dirs, long long n, unsigned* __restrict__ keys,
+              unsigned* __restrict__ rank, unsigned* __restrict__ counts) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const unsigned key = strip_key(origins, dirs, i);
+    keys[i] = key;
+    rank[i] = atomicAdd(&counts[((key >> 12) << kSubBits) | ((unsigned)i & ((1u << kSubBits) - 1u))], 1u);
+}
+
+// 1024 cells a block: the cells' exclusive prefix within the block (in place), the block's total, and the strips of the
+// block (64 of them, 16 cells each) that hold rays, in order, with their number
+__global__ void __launch_bounds__(1024)
+k_strip_scan_local(unsigned* __restrict__ counts, unsigned* __restrict__ block_tot, unsigned* __restrict__ strips,
+                   unsigned* __restrict__ block_nz) {
+    __shared__ unsigned s_w[16], s_z[16];
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+    const unsigned g = blockIdx.x * 1024u + t;
+    const unsigned c = counts[g];
+    unsigned incl = c;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const unsigned v = __shfl_up(incl, d);
+        if (lane >= d) incl += v;
+    }
+    // the strip's total in its first lane
+    unsigned st = c;
+#pragma unroll
+    for (int d = 1; d < 16; d <<= 1) st += __shfl_xor(st, d);
+    const bool head = (lane & 15) == 0 && st > 0;
+    const unsigned long long mh = __ballot(head);
+    if (lane == 63) s_w[w] = incl;
+    if (lane == 0) s_z[w] = (unsigned)__popcll(mh);
+    __syncthreads();
+    unsigned base = 0, zbase = 0;
+    for (int k = 0; k < w; ++k) {
+        base += s_w[k];
+        zbase += s_z[k];
+    }
+    counts[g] = base + incl - c;
+    if (head) strips[blockIdx.x * 64u + zbase + (unsigned)__popcll(mh & ((1ull << lane) - 1ull))] = g >> kSubBits;
+    if (t == 1023) {
+        block_tot[blockIdx.x] = base + incl;
+        block_nz[blockIdx.x] = zbase + (unsigned)__popcll(mh);
+    }
+}
+
+// exclusive scans of the blocks' totals and strip counts in place (kScanBlocks = 1024 values each); [kScanBlocks] = totals
+__global__ void __launch_bounds__(1024)
+k_strip_scan_base(unsigned* __restrict__ block_tot, unsigned* __restrict__ block_nz) {
+    __shared__ unsigned s_a[1024], s_b[1024];
+    const int t = threadIdx.x;
+    const unsigned a = block_tot[t], b = block_nz[t];
+    s_a[t] = a;
+    s_b[t] = b;
+    __syncthreads();
+    for (int d = 1; d < 1024; d <<= 1) {
+        const unsigned x = t >= d ? s_a[t - d] : 0u, y = t >= d ? s_b[t - d] : 0u;
+        __syncthreads();
+        s_a[t] += x;
+        s_b[t] += y;
+        __syncthreads();
+    }
+    block_tot[t] = s_a[t] - a;
+    block_nz[t] = s_b[t] - b;
+    if (t == 1023) {
+        block_tot[1024] = s_a[t];
+        block_nz[1024] = s_b[t];
+    }
+}
+
+__device__ __forceinline__ unsigned cell_offset(const unsigned* __restrict__ counts, const unsigned* __restrict__ block_tot,
+                                                unsigned cell) {
+    return cell < (unsigned)kCells ? counts[cell] + block_tot[cell >> 10] : block_tot[1024];
+}
+
+__global__ void __launch_bounds__(256)
+k_strip_scatter(const unsigned* __restrict__ keys, const unsigned* __restrict__ rank, const unsigned* __restrict__ counts,
+                const unsigned* __restrict__ block_tot, long long n, unsigned long long* __restrict__ pairs) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const unsigned key = keys[i];
+    const unsigned cell = ((key >> 12) << kSubBits) | ((unsigned)i & ((1u << kSubBits) - 1u));
+    pairs[cell_offset(counts, block_tot, cell) + rank[i]] = ((unsigned long long)(key & 4095u) << 32) | (unsigned)i;
+}
+
+// one strip a block at a time: its (u, ray) pairs sorted in LDS, then the permutation and the rays in the new order
+__global__ void __launch_bounds__(256)
+k_strip_sort_gather(const unsigned* __restrict__ counts, const unsigned* __restrict__ block_tot,
+                    const unsigned* __restrict__ strips, const unsigned* __restrict__ block_nz,
+                    const unsigned long long* __restrict__ pairs, const float* __restrict__ origins,
+                    const float* __restrict__ dirs, const float* __restrict__ gt, unsigned* __restrict__ perm,
+                    float* __restrict__ o_s, float* __restrict__ d_s, float* __restrict__ gt_s) {
+    __shared__ unsigned long long s_p[kStripMax];
+    __shared__ unsigned s_nz[kScanBlocks + 1];
+    const int t = threadIdx.x;
+    for (int i = t; i <= kScanBlocks; i += 256) s_nz[i] = block_nz[i];
+    __syncthreads();
+    const unsigned ns = s_nz[kScanBlocks];
+    for (unsigned si = blockIdx.x; si < ns; si += gridDim.x) {
+        // the si-th strip that holds rays: which scan block listed it (s_nz: exclusive prefix), and where
+        int b = 0;
+        for (int step = kScanBlocks / 2; step >= 1; step >>= 1)
+            if (s_nz[b + step] <= si) b += step;
+        const unsigned strip = strips[(unsigned)b * 64u + (si - s_nz[b])];
+        const unsigned begin = cell_offset(counts, block_tot, strip << kSubBits);
+        const unsigned end = cell_offset(counts, block_tot, (strip + 1u) << kSubBits);
+        for (unsigned p0 = begin; p0 < end; p0 += kStripMax) {
+            const int m = (int)min((unsigned)kStripMax, end - p0);
+            int cap = 64;   // power of two >= m
+            while (cap < m) cap <<= 1;
+            for (int i = t; i < cap; i += 256) s_p[i] = i < m ? pairs[p0 + i] : ~0ull;
+            __syncthreads();
+            for (int k = 2; k <= cap; k <<= 1) {
+                for (int j = k >> 1; j > 0; j >>= 1) {
+                    for (int i = t; i < cap; i += 256) {
+                        const int l = i ^ j;
+                        if (l > i) {
+                            const unsigned long long a = s_p[i], b2 = s_p[l];
+                            const bool up = (i & k) == 0;
+                            if ((a > b2) == up) {
+                                s_p[i] = b2;
+                                s_p[l] = a;
+                            }
+                        }
+                    }
+                    __syncthreads();
+                }
+            }
+            for (int i = t; i < m; i += 256) {
+                const unsigned src = (unsigned)(s_p[i] & 0xffffffffull);
+                const size_t dst = (size_t)p0 + i;
+                perm[dst] = src;
+                reinterpret_cast<F3*>(o_s)[dst] = reinterpret_cast<const F3*>(origins)[src];
+                reinterpret_cast<F3*>(d_s)[dst] = reinterpret_cast<const F3*>(dirs)[src];
+                if (gt != nullptr) reinterpret_cast<F3*>(gt_s)[dst] = reinterpret_cast<const F3*>(gt)[src];
+            }
+            __syncthreads();
+        }
+    }
+}
+
 // ---- internal interface for asurf_api.hip (asurf_order.h) ----
 namespace asurf_order {
 
@@ -215,6 +392,38 @@ int order32(const float* origins, const float* dirs, long long n, unsigned* perm
     const hipError_t e = rocprim::radix_sort_pairs(base + 3 * plane, sb, keys_in, keys_out, ids_in, perm, (size_t)n, 0u,
                                                    (unsigned)key_bits, s);
     return (e == hipSuccess && hipGetLastError() == hipSuccess) ? 0 : -3;
+}
+
+size_t tmp_bytes_strips(long long n) {
+    const size_t nn = (size_t)(n > 0 ? n : 1);
+    auto up = [](size_t x) { return (x + 255) / 256 * 256; };
+    // keys, ranks | cell counts / offsets | the blocks' totals and strip counts (+1) | the strips listed per block | pairs
+    return up(nn * 4) * 2 + up((size_t)kCells * 4) + 2 * up((kScanBlocks + 1) * 4) + up((size_t)kScanBlocks * 64 * 4) + up(nn * 8);
+}
+
+int order_strips(const float* origins, const float* dirs, const float* gt, long long n, unsigned* perm, float* o_s,
+                 float* d_s, float* gt_s, void* tmp, size_t tmp_bytes, hipStream_t s) {
+    auto up = [](size_t x) { return (x + 255) / 256 * 256; };
+    if (n <= 0) return 0;
+    if (tmp_bytes < tmp_bytes_strips(n)) return -1;
+    char* base = static_cast<char*>(tmp);
+    const size_t plane = up((size_t)n * 4), cells = up((size_t)kCells * 4), small = up((kScanBlocks + 1) * 4);
+    auto* keys = reinterpret_cast<unsigned*>(base);
+    auto* rank = reinterpret_cast<unsigned*>(base + plane);
+    auto* counts = reinterpret_cast<unsigned*>(base + 2 * plane);
+    auto* block_tot = reinterpret_cast<unsigned*>(base + 2 * plane + cells);
+    auto* block_nz = reinterpret_cast<unsigned*>(base + 2 * plane + cells + small);
+    auto* strips = reinterpret_cast<unsigned*>(base + 2 * plane + cells + 2 * small);
+    auto* pairs = reinterpret_cast<unsigned long long*>(base + 2 * plane + cells + 2 * small + up((size_t)kScanBlocks * 64 * 4));
+    if (hipMemsetAsync(counts, 0, (size_t)kCells * 4, s) != hipSuccess) return -3;
+    const unsigned nb = (unsigned)((n + 255) / 256);
+    hipLaunchKernelGGL(k_strip_count, dim3(nb), dim3(256), 0, s, origins, dirs, n, keys, rank, counts);
+    hipLaunchKernelGGL(k_strip_scan_local, dim3(kScanBlocks), dim3(1024), 0, s, counts, block_tot, strips, block_nz);
+    hipLaunchKernelGGL(k_strip_scan_base, dim3(1), dim3(1024), 0, s, block_tot, block_nz);
+    hipLaunchKernelGGL(k_strip_scatter, dim3(nb), dim3(256), 0, s, keys, rank, counts, block_tot, n, pairs);
+    hipLaunchKernelGGL(k_strip_sort_gather, dim3(2048), dim3(256), 0, s, counts, block_tot, strips, block_nz, pairs, origins,
+                       dirs, gt, perm, o_s, d_s, gt_s);
+    return hipGetLastError() == hipSuccess ? 0 : -3;
 }
 
 void gather(const float* origins, const float* dirs, const float* gt, const unsigned* perm, long long n, float* o_s,
