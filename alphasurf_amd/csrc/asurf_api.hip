@@ -1404,6 +1404,82 @@ int asurf_sgd_step(float* data, float* grad, int64_t n_rows, int32_t n_cols, con
 size_t asurf_optim_scratch_bytes(int64_t n_rows) { return (size_t)(n_rows > 0 ? n_rows : 0) * 8 + 256; }
 
 // mask -> row list on the device, then the index-list step over it (its length stays on the device)
+// The masked steps build the row list on the device (k_compact_rows) so that a sparse mask costs its rows only; a mask
+// that names a quarter of the rows or more is walked itself, and then the list was built for nothing (a memset and a
+// kernel, 17 us a step, three steps an iteration -- and with the shipped configuration's regularisers touching every
+// non-empty cell, the masks of a training iteration are full).  What the last list of a mask held is therefore
+// remembered (read back asynchronously): after a dense one the next 15 steps on the same mask go straight to the mask
+// form, the 16th builds the list again to see whether that is still so.  Only speed depends on it: the mask form is
+// correct for every mask.
+struct MaskDensity {
+    const void* mask = nullptr;
+    long long n_rows = 0;
+    int* h_count = nullptr;   // pinned
+    hipEvent_t ev = nullptr;
+    bool pending = false;
+    int dense_streak = 0;     // > 0: steps left that skip the list
+    unsigned long long used = 0;
+};
+constexpr int kMaskDensityEntries = 8;
+std::mutex g_mask_density_mu;
+MaskDensity g_mask_density[kMaskDensityEntries];
+unsigned long long g_mask_density_clock = 0;
+
+// true: skip the list this time
+bool mask_density_skip(const void* mask, long long n_rows, hipStream_t s, MaskDensity** slot_out) {
+    *slot_out = nullptr;
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(s, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) return false;
+    std::lock_guard<std::mutex> lock(g_mask_density_mu);
+    MaskDensity* slot = nullptr;
+    for (MaskDensity& e : g_mask_density)
+        if (e.mask == mask && e.n_rows == n_rows) slot = &e;
+    if (!slot) {
+        slot = &g_mask_density[0];
+        for (MaskDensity& e : g_mask_density)
+            if (e.mask == nullptr || e.used < slot->used) {
+                slot = &e;
+                if (e.mask == nullptr) break;
+            }
+        if (slot->pending && slot->ev) (void)hipEventSynchronize(slot->ev);
+        slot->mask = mask;
+        slot->n_rows = n_rows;
+        slot->pending = false;
+        slot->dense_streak = 0;
+    }
+    slot->used = ++g_mask_density_clock;
+    if (slot->pending) {
+        if (hipEventQuery(slot->ev) == hipSuccess) {
+            slot->pending = false;
+            if (4ll * (*slot->h_count) >= n_rows) slot->dense_streak = 15;
+        } else {
+            (void)hipGetLastError();
+        }
+    }
+    if (slot->dense_streak > 0) {
+        --slot->dense_streak;
+        return true;
+    }
+    if (!slot->pending) *slot_out = slot;   // the caller reads the new list's length back into it
+    return false;
+}
+
+void mask_density_record(MaskDensity* slot, const int* d_count, hipStream_t s) {
+    if (!slot) return;
+    std::lock_guard<std::mutex> lock(g_mask_density_mu);
+    if (!slot->h_count && hipHostMalloc(reinterpret_cast<void**>(&slot->h_count), sizeof(int)) != hipSuccess) {
+        slot->h_count = nullptr;
+        return;
+    }
+    if (!slot->ev && hipEventCreateWithFlags(&slot->ev, hipEventDisableTiming) != hipSuccess) {
+        slot->ev = nullptr;
+        return;
+    }
+    if (hipMemcpyAsync(slot->h_count, d_count, sizeof(int), hipMemcpyDeviceToHost, s) == hipSuccess &&
+        hipEventRecord(slot->ev, s) == hipSuccess)
+        slot->pending = true;
+}
+
 static int optim_masked(bool rms_mode, float* data, float* rms, float* grad, int64_t n_rows, int32_t n_cols,
                         const uint8_t* mask, void* scratch, size_t scratch_bytes, float beta, float lr, float epsilon,
                         float minval, float lr_last, void* stream) {
@@ -1414,13 +1490,19 @@ static int optim_masked(bool rms_mode, float* data, float* rms, float* grad, int
     int* count = static_cast<int*>(scratch);
     long long* rows = reinterpret_cast<long long*>(static_cast<char*>(scratch) + 256);
     hipStream_t s = static_cast<hipStream_t>(stream);
+    MaskDensity* slot = nullptr;
+    if (mask_density_skip(mask, n_rows, s, &slot))   // the mask itself (dense the last time it was listed)
+        return optim_launch(rms_mode, data, rms, grad, n_rows, n_cols, mask, nullptr, 0, beta, lr, epsilon, minval, lr_last,
+                            stream);
     if (hipMemsetAsync(count, 0, sizeof(int), s) != hipSuccess) return fail(ASURF_E_LAUNCH, "hipMemsetAsync failed");
     hipLaunchKernelGGL(k_compact_rows, dim3((unsigned)((n_rows + kCompactRowsPerBlock - 1) / kCompactRowsPerBlock)),
                        dim3(256), 0, s, mask, (long long)n_rows, rows, count);
     if (int e = launch_error("k_compact_rows")) return e;
     // (the step kernel reads the count: a list that names a quarter of the rows or more is not walked, the mask is)
-    return optim_launch(rms_mode, data, rms, grad, n_rows, n_cols, mask, reinterpret_cast<const int64_t*>(rows), 0,
-                        beta, lr, epsilon, minval, lr_last, stream, count);
+    const int rc = optim_launch(rms_mode, data, rms, grad, n_rows, n_cols, mask, reinterpret_cast<const int64_t*>(rows), 0,
+                                beta, lr, epsilon, minval, lr_last, stream, count);
+    mask_density_record(slot, count, s);
+    return rc;
 }
 
 int asurf_rmsprop_step_masked(float* data, float* rms, float* grad, int64_t n_rows, int32_t n_cols,

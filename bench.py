@@ -488,7 +488,9 @@ def main():
                        "avg_per_ray": {"V_t": round(v_t / Q, 2), "V_a": round(v_a / Q, 2), "S": round(s_cnt / Q, 3),
                                        "rays_with_a_sample": round(float(((rgb_user if args.sort else rgb) != 1.0)
                                                                          .any(dim=1).float().mean().item()), 4)},
-                       "parallelism": f"ray-sharded dp{world}, {args.exchange} RCCL exchange of grads" if world > 1 else "single GPU"},
+                       "parallelism": (f"ray-sharded dp{world}, {args.exchange} exchange of grads over "
+                                       f"{'RCCL' if os.environ.get('ASURF_DIST_BACKEND', 'nccl') == 'nccl' else 'gloo (rehearsal: ranks share devices)'}")
+                       if world > 1 else "single GPU"},
             "roofline": roofline, "cpu_baseline": cpu, "verify": verify,
         }
     if world > 1:
