@@ -59,7 +59,7 @@ def oracle():
 
 
 _SWITCHES = ("ASURF_DEBUG", "ASURF_WALK_SEG", "ASURF_WALK", "ASURF_RPW", "ASURF_NO_PIPELINE", "ASURF_CUVOL_RPW",
-             "ASURF_NO_REPLAY", "ASURF_NO_SPLIT_BWD", "ASURF_EVAL", "ASURF_MASKS", "ASURF_SWEEP", "ASURF_SIDE_STREAM")
+             "ASURF_NO_REPLAY", "ASURF_NO_SPLIT_BWD", "ASURF_EVAL", "ASURF_MASKS", "ASURF_SWEEP", "ASURF_SIDE_STREAM", "ASURF_ORDER")
 
 
 @pytest.fixture(autouse=True)

@@ -711,3 +711,46 @@ def test_fallback_kernels_beside_the_backward_pipeline(hip, oracle):
         grad_close(g_a[k], g_b[k], 2e-5, f"side stream grad_{k}")
         grad_close(g_a[k], go[k], GRAD_RTOL, f"grad_{k} vs oracle")
     assert (g_a["mask"].astype(bool) == go["mask"].astype(bool)).all()
+
+
+def test_ray_ordering_handles_many_origins_and_crowded_strips(hip):
+    """The ordering's two sort paths on batches that are not one camera's pixels: rays with an origin each (every ray its
+    own hash, strips of a ray or two), eight cameras mixed and shuffled, and 6 000 copies of one ray (one strip far beyond
+    the 2 048 rays a block sorts at once: sorted in pieces).  Strip sort and rocPRIM's radix sort (ASURF_ORDER=radix) against
+    the batch as given."""
+    import torch
+    from alphasurf_amd import csrc_api as _C, synth
+    sc = synth.make_sparse_scene(64, 4, seed=11, trunc_a=4.0)
+    rs = np.random.RandomState(12)
+    o_r, d_r = synth.random_rays(30000, 13)                         # an origin each
+    cams = [synth.pinhole_rays(synth.orbit_camera(k), 70, 70) for k in range(8)]
+    o_c = np.concatenate([c[0] for c in cams])
+    d_c = np.concatenate([c[1] for c in cams])
+    o_d = np.repeat(cams[3][0][2477:2478], 6000, axis=0)            # one ray, 6 000 times
+    d_d = np.repeat(cams[3][1][2477:2478], 6000, axis=0)
+    o = np.concatenate([o_r, o_c, o_d]).astype(np.float32)
+    d = np.concatenate([d_r, d_c, d_d]).astype(np.float32)
+    perm = rs.permutation(o.shape[0])
+    o, d = np.ascontiguousarray(o[perm]), np.ascontiguousarray(d[perm])
+    assert o.shape[0] >= 65536
+    gt = rs.rand(o.shape[0], 3).astype(np.float32)
+    g, r, op = hip.grid_spec(sc), hip.rays_spec(o, d), hip.opt_spec(OPTION_SETS["syn_yaml"])
+    gt_t = torch.from_numpy(gt).cuda()
+    args = [dict(lambda_l2=1.0, lambda_l_entropy=1e-4).get(k, dflt) for k, dflt in hip.FUSED_ORDER]
+
+    def run(order_rays):
+        gr = hip.zero_grads(g)
+        rgb = torch.zeros_like(gt_t)
+        _C.volume_render_surf_trav_fused(g, r, op, gt_t, *args, rgb, gr, order_rays=order_rays)
+        torch.cuda.synchronize()
+        return rgb.cpu().numpy(), hip.grads_np(gr)
+
+    rgb1, g1 = run(1)
+    for form in (None, "radix"):
+        _asurf_lib.config_set("ASURF_ORDER", form)
+        rgb2, g2 = run(2)
+        _asurf_lib.config_set("ASURF_ORDER", None)
+        assert np.abs(rgb2 - rgb1).max() <= 2.5e-7, form
+        assert (g2["mask"] == g1["mask"]).all()
+        for k in ("sh", "density", "surface"):
+            grad_close(g2[k], g1[k], 5e-5, f"{form} grad_{k}")
