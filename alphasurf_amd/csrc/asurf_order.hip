@@ -193,8 +193,8 @@ Plan plan_for(long long n) {
 // the high 18 bits name a strip (origin hash, v), a batch lights up a few hundred to a few thousand of the 262 144
 // strips, and a strip holds a few hundred rays.  So: count the rays per strip (one atomic a ray; its return value is
 // the ray's place in the strip), scan the counts (one block; it also lists the strips that hold anything), scatter
-// (u, ray) pairs to their strips, and sort every strip by u in LDS (bitonic, ties by ray number: the result does not depend
-// on the order of the atomics) -- that kernel writes the permutation AND the gathered rays / targets.  A memset and five
+// (u, ray) pairs to their strips, and sort every strip by u in LDS (a counting sort over its 4096 u cells) -- that kernel
+// writes the permutation AND the gathered rays / targets.  A memset and five
 // launches.  (First form: one counter a strip and one block scanning 2^18 counters -- 0.11 and 0.34 ms: the counters
 // were hit 700 times each by atomics that return a value, and the scan's loads did not coalesce.)
 constexpr int kStripBits = 16;    // strips: 4 bits of the origin's hash, 12 bits of v
@@ -205,21 +205,51 @@ constexpr int kCells = 1 << (kStripBits + kSubBits);
 constexpr int kScanBlocks = kCells / 1024;
 constexpr int kStripMax = 2048;   // rays of one strip sorted together (a longer strip is sorted in pieces of this size)
 
+// The key of the strip sort.  Where the ray's direction is given in the frame of a camera at the ray's origin that looks at
+// the scene's centre with the world's z as its up vector -- n = -o / |o|, e1 = n x z, e2 = n x e1 --, as the gnomonic
+// coordinates (d.e1 / d.n, d.e2 / d.n): image rows of such a camera (the orbit cameras of NeRF-synthetic, of bench.py) are
+// lines of constant second coordinate, so a strip IS a pixel row (or two), and the ordered batch is the image-order
+// batch; rows of any other camera are still straight lines of the chart, cut by the strips at an angle.  (The octahedral
+// map of the first form bends the rows: the kernels that merge neighbouring rays' samples ran 0.207 / 0.128 ms on its
+// strips against 0.166 / 0.110 on pixel rows.)  Rays that point away from the centre, or start at it, keep the
+// octahedral map.
 __device__ __forceinline__ unsigned strip_key(const float* __restrict__ origins, const float* __restrict__ dirs, long long i) {
+    const float ox = origins[3 * i], oy = origins[3 * i + 1], oz = origins[3 * i + 2];
     const float dx = dirs[3 * i], dy = dirs[3 * i + 1], dz = dirs[3 * i + 2];
-    const float rn = 1.f / fmaxf(fabsf(dx) + fabsf(dy) + fabsf(dz), 1e-30f);
-    float u = dx * rn, v = dy * rn;
-    if (dz < 0.f) {
-        const float fu = (1.f - fabsf(v)) * (u >= 0.f ? 1.f : -1.f), fv = (1.f - fabsf(u)) * (v >= 0.f ? 1.f : -1.f);
-        u = fu;
-        v = fv;
-    }
-    const unsigned qu = (unsigned)fminf(fmaxf((u + 1.f) * 2047.75f, 0.f), 4095.f);
-    const unsigned qv = (unsigned)fminf(fmaxf((v + 1.f) * 2047.75f, 0.f), 4095.f);
-    unsigned h = __float_as_uint(origins[3 * i]) * 0x9E3779B1u;
-    h = (h ^ __float_as_uint(origins[3 * i + 1])) * 0x85EBCA77u;
-    h = (h ^ __float_as_uint(origins[3 * i + 2])) * 0xC2B2AE3Du;
+    unsigned h = __float_as_uint(ox) * 0x9E3779B1u;
+    h = (h ^ __float_as_uint(oy)) * 0x85EBCA77u;
+    h = (h ^ __float_as_uint(oz)) * 0xC2B2AE3Du;
     h ^= h >> 15;
+    float u, v;   // both mapped to [0, 4096)
+    const float on = sqrtf(ox * ox + oy * oy + oz * oz);
+    const float nx = -ox / fmaxf(on, 1e-30f), ny = -oy / fmaxf(on, 1e-30f), nz = -oz / fmaxf(on, 1e-30f);
+    // e1 = n x up, up = z (x where n is nearly vertical)
+    const bool vertical = fabsf(nz) > 0.999f;
+    float e1x = vertical ? 0.f : ny, e1y = vertical ? nz : -nx, e1z = vertical ? -ny : 0.f;
+    const float e1n = rsqrtf(fmaxf(e1x * e1x + e1y * e1y + e1z * e1z, 1e-30f));
+    e1x *= e1n;
+    e1y *= e1n;
+    e1z *= e1n;
+    const float e2x = ny * e1z - nz * e1y, e2y = nz * e1x - nx * e1z, e2z = nx * e1y - ny * e1x;
+    const float dn = dx * nx + dy * ny + dz * nz;
+    const float dl = sqrtf(dx * dx + dy * dy + dz * dz);
+    if (on > 1e-6f && dn > 0.2f * dl) {
+        const float inv = 1.f / dn;
+        u = ((dx * e1x + dy * e1y + dz * e1z) * inv + 2.f) * 1023.9f;
+        v = ((dx * e2x + dy * e2y + dz * e2z) * inv + 2.f) * 1023.9f;
+    } else {
+        const float rn = 1.f / fmaxf(fabsf(dx) + fabsf(dy) + fabsf(dz), 1e-30f);
+        float a = dx * rn, b = dy * rn;
+        if (dz < 0.f) {
+            const float fa = (1.f - fabsf(b)) * (a >= 0.f ? 1.f : -1.f), fb = (1.f - fabsf(a)) * (b >= 0.f ? 1.f : -1.f);
+            a = fa;
+            b = fb;
+        }
+        u = (a + 1.f) * 2047.75f;
+        v = (b + 1.f) * 2047.75f;
+    }
+    const unsigned qu = (unsigned)fminf(fmaxf(u, 0.f), 4095.f);
+    const unsigned qv = (unsigned)fminf(fmaxf(v, 0.f), 4095.f);
     return ((h & 15u) << 24) | (qv << 12) | qu;   // strip = key >> 12, u = key & 4095
 }
 
@@ -309,14 +339,19 @@ k_strip_scatter(const unsigned* __restrict__ keys, const unsigned* __restrict__ 
     pairs[cell_offset(counts, block_tot, cell) + rank[i]] = ((unsigned long long)(key & 4095u) << 32) | (unsigned)i;
 }
 
-// one strip a block at a time: its (u, ray) pairs sorted in LDS, then the permutation and the rays in the new order
+// one strip a block at a time: its (u, ray) pairs sorted by u in LDS -- a counting sort over the 4096 u cells (count, scan,
+// place: five barriers; the bitonic network of the first form took 55 for a strip of 800 rays and 49 us of the ordering's
+// 110) --, then the permutation and the rays in the new order.  Rays of one u cell (a pixel, or the same pixel of two rows)
+// come out in the order of the LDS atomics.
 __global__ void __launch_bounds__(256)
 k_strip_sort_gather(const unsigned* __restrict__ counts, const unsigned* __restrict__ block_tot,
                     const unsigned* __restrict__ strips, const unsigned* __restrict__ block_nz,
                     const unsigned long long* __restrict__ pairs, const float* __restrict__ origins,
                     const float* __restrict__ dirs, const float* __restrict__ gt, unsigned* __restrict__ perm,
                     float* __restrict__ o_s, float* __restrict__ d_s, float* __restrict__ gt_s) {
-    __shared__ unsigned long long s_p[kStripMax];
+    __shared__ unsigned s_hist[4096];            // rays per u cell, then the cell's first place
+    __shared__ unsigned s_out[kStripMax];        // ray numbers in the new order
+    __shared__ unsigned s_part[256];
     __shared__ unsigned s_nz[kScanBlocks + 1];
     const int t = threadIdx.x;
     for (int i = t; i <= kScanBlocks; i += 256) s_nz[i] = block_nz[i];
@@ -332,28 +367,47 @@ k_strip_sort_gather(const unsigned* __restrict__ counts, const unsigned* __restr
         const unsigned end = cell_offset(counts, block_tot, (strip + 1u) << kSubBits);
         for (unsigned p0 = begin; p0 < end; p0 += kStripMax) {
             const int m = (int)min((unsigned)kStripMax, end - p0);
-            int cap = 64;   // power of two >= m
-            while (cap < m) cap <<= 1;
-            for (int i = t; i < cap; i += 256) s_p[i] = i < m ? pairs[p0 + i] : ~0ull;
+            for (int i = t; i < 4096; i += 256) s_hist[i] = 0u;
             __syncthreads();
-            for (int k = 2; k <= cap; k <<= 1) {
-                for (int j = k >> 1; j > 0; j >>= 1) {
-                    for (int i = t; i < cap; i += 256) {
-                        const int l = i ^ j;
-                        if (l > i) {
-                            const unsigned long long a = s_p[i], b2 = s_p[l];
-                            const bool up = (i & k) == 0;
-                            if ((a > b2) == up) {
-                                s_p[i] = b2;
-                                s_p[l] = a;
-                            }
-                        }
-                    }
-                    __syncthreads();
-                }
+            unsigned long long mine[kStripMax / 256];
+            unsigned rank[kStripMax / 256];
+#pragma unroll
+            for (int r = 0; r < kStripMax / 256; ++r) {
+                const int i = t + 256 * r;
+                mine[r] = i < m ? pairs[p0 + i] : 0ull;
+                rank[r] = i < m ? atomicAdd(&s_hist[(unsigned)(mine[r] >> 32)], 1u) : 0u;
             }
+            __syncthreads();
+            // exclusive scan of the 4096 counts: 16 cells a thread, the threads' sums scanned across the block
+            unsigned loc[16], sum = 0u;
+#pragma unroll
+            for (int c = 0; c < 16; ++c) {
+                loc[c] = s_hist[t * 16 + c];
+                sum += loc[c];
+            }
+            s_part[t] = sum;
+            __syncthreads();
+            for (int d = 1; d < 256; d <<= 1) {
+                const unsigned v = t >= d ? s_part[t - d] : 0u;
+                __syncthreads();
+                s_part[t] += v;
+                __syncthreads();
+            }
+            unsigned run = s_part[t] - sum;
+#pragma unroll
+            for (int c = 0; c < 16; ++c) {
+                s_hist[t * 16 + c] = run;
+                run += loc[c];
+            }
+            __syncthreads();
+#pragma unroll
+            for (int r = 0; r < kStripMax / 256; ++r) {
+                const int i = t + 256 * r;
+                if (i < m) s_out[s_hist[(unsigned)(mine[r] >> 32)] + rank[r]] = (unsigned)(mine[r] & 0xffffffffull);
+            }
+            __syncthreads();
             for (int i = t; i < m; i += 256) {
-                const unsigned src = (unsigned)(s_p[i] & 0xffffffffull);
+                const unsigned src = s_out[i];
                 const size_t dst = (size_t)p0 + i;
                 perm[dst] = src;
                 reinterpret_cast<F3*>(o_s)[dst] = reinterpret_cast<const F3*>(origins)[src];
