@@ -769,7 +769,10 @@ int find_candidates(const Launch& L, const asurf_rays* rays, bool record, PipeBu
                 // lasts as long as ONE wave's chain of phases (k_sweep at 5 184 rays, 16 / 8 / 4 / 2 rays a wave: 0.035 / 0.024 / 0.021 / 0.021 ms;
                 // at 65 536 rays 0.052 / 0.054 / 0.064 / 0.091)
                 const int rpw = cfgc.sweep_rpw ? cfgc.sweep_rpw : (Q <= 8192 ? 4 : (Q <= 32768 ? 8 : kSweepWaveRays));
-                const int task_cap = (std::min(std::max(rpw * nbmax * 3 / 4, 128), 1536) + 3) & ~3;
+                // (the slice decides how many waves share a CU: LDS is handed out in 1 280-byte pieces, and at 256^3 a
+                // slice of 7 504 bytes lets the 20 waves the registers allow in, 8 016 -- 384 tasks -- only 18:
+                // 0.279 against 0.296 ms; a wave with more tasks than fit takes its rays four at a time)
+                const int task_cap = (std::min(std::max(rpw * nbmax / 2, 128), 1536) + 3) & ~3;
                 const int key_cap = (std::max((nbmax > 64 ? 2048 : (nbmax > 32 ? 1280 : 768)) * rpw / kSweepWaveRays, 256) + 15) & ~15;
                 const int wave_bytes = (int)((size_t)rpw * sizeof(SweepRay) + (size_t)task_cap * 4 + (size_t)key_cap * 5 +
                                              sizeof(SweepWaveMisc));   // (keys + a byte each for the ray they belong to)

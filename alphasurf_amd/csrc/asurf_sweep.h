@@ -489,10 +489,10 @@ struct SweepWaveMisc {
     int n[kSweepWaveRays];          // hits that pass the exact test (0 when handed back)
     int spb[kSweepWaveRays];        // spill base
     int hand[kSweepWaveRays];       // 1: handed back
-    int slot0[64];                  // first list cell of each table slot
-    unsigned fill[64];              // bit r: ray r fills the slot
     int pad[3];
 };
+// (phases 4 and 5 keep two more tables of 64 words -- the first list cell of each table slot, the rays that fill it --
+// where the task list was: tasks are dead once phase 2 has run, and task_cap >= 128)
 static_assert(sizeof(SweepWaveMisc) % 16 == 0, "the waves' LDS slices stay 16-byte aligned");
 
 // cross-lane hand-over through the wave's own LDS slice: LDS operations of a wave execute in order; the compiler must
@@ -522,7 +522,14 @@ __device__ __forceinline__ int list_segment_unit(const PipeBuf& P, unsigned unit
     return (int)(band % kListGroups) * kListShards + (int)((in_band + band / kListGroups) % kListShards);
 }
 
-__global__ void __launch_bounds__(256)
+// 5 waves a SIMD: 89 registers, no scratch (left to itself the compiler takes 102 and 4 fit), and the wave's LDS slice at
+// 256^3 -- 8 016 bytes -- lets 20 waves share a CU.  The kernel is half VALU issue and half the latency of dependent
+// instructions with few waves to switch to: 4 / 5 / 6 (36 bytes of scratch) / 8 (96 bytes) waves: 0.294 / 0.281 / 0.284 /
+// 0.322 ms at config 2.
+#ifndef ASURF_SWEEP_EU
+#define ASURF_SWEEP_EU 5
+#endif
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(ASURF_SWEEP_EU, ASURF_SWEEP_EU)))
 k_sweep_wave(KGrid g, KOpt o, const float* __restrict__ origins, const float* __restrict__ dirs, long long Q,
              PipeBuf P, int n_layers, int want_cut, int task_cap, int key_cap, int wave_bytes, int rpw) {
     extern __shared__ uint4 s_dyn4[];
@@ -538,6 +545,8 @@ k_sweep_wave(KGrid g, KOpt o, const float* __restrict__ origins, const float* __
     unsigned* const s_key = s_task + task_cap;
     unsigned char* const s_krl = reinterpret_cast<unsigned char*>(s_key + key_cap);   // the ray a key belongs to
     SweepWaveMisc* const M = reinterpret_cast<SweepWaveMisc*>(s_krl + key_cap);       // (key_cap: a multiple of 16)
+    int* const s_slot0 = reinterpret_cast<int*>(s_task);   // phases 4-5: first list cell of each table slot
+    unsigned* const s_fill = s_task + 64;                   // ... bit r: ray r fills the slot
     const float kEps = 1.f / 256.f;
 
     // ---- phase 0: lane = ray ----
@@ -968,8 +977,8 @@ k_sweep_wave(KGrid g, KOpt o, const float* __restrict__ origins, const float* __
                 for (int r2 = r_lo; r2 < r_hi; ++r2) fm |= (M->n[r2] > lane ? 1u : 0u) << r2;
             const int c = __popc(fm);
             const int ci = wave_incl_scan(c);
-            M->slot0[lane] = ci - c;
-            M->fill[lane] = fm;
+            s_slot0[lane] = ci - c;
+            s_fill[lane] = fm;
             const int cells = bcast_i(ci, 63);
             int lb = 0;
             const int shard = list_segment_unit(P, unit, rpw);
@@ -1004,9 +1013,9 @@ k_sweep_wave(KGrid g, KOpt o, const float* __restrict__ origins, const float* __
             const long long q = q0 + rl;
             if (key & kSweepCutBit) atomicMin(&P.cut[q], ord);  // rare
             if (ord < P.C1) {
-                const int before = __popc(M->fill[ord] & ((1u << rl) - 1u));  // rays in front that fill slot `ord` too
+                const int before = __popc(s_fill[ord] & ((1u << rl) - 1u));  // rays in front that fill slot `ord` too
                 P.items[(size_t)ord * Q + q] = voxel;
-                P.list[lbase + M->slot0[ord] + before] = ((unsigned)ord << kListRayBits) | (unsigned)q;
+                P.list[lbase + s_slot0[ord] + before] = ((unsigned)ord << kListRayBits) | (unsigned)q;
             } else {
                 const int at = M->spb[rl] + ord - P.C1;
                 P.sp_items[at] = voxel;
