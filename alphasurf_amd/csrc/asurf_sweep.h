@@ -648,6 +648,7 @@ k_sweep_wave(KGrid g, KOpt o, const float* __restrict__ origins, const float* __
 #endif
     ASURF_SWEEP_LEAVE(1)
     const float inv_layers = 1.f / (float)n_layers;
+    const int layers_log2 = (n_layers & (n_layers - 1)) == 0 ? 31 - __clz(n_layers) : -1;
     int group = rpw;   // rays taken together; shrinks when the wave's lists overflow
     for (int r_lo = 0; r_lo < rpw;) {
         const int r_hi = min(r_lo + group, rpw);
@@ -656,48 +657,63 @@ k_sweep_wave(KGrid g, KOpt o, const float* __restrict__ origins, const float* __
         const int pair_lo = r_lo * n_layers, pair_hi = r_hi * n_layers;
         for (int lt0 = pair_lo; lt0 < pair_hi; lt0 += 64) {
             const int lt = lt0 + lane;
-            const int rl = min((int)(((float)lt + 0.5f) * inv_layers), rpw - 1), A = lt - rl * n_layers;
+            // (ray, layer) of the pair: a shift when the layers are a power of two (the product is a quarter-rate
+            // instruction)
+            int rl, A;
+            if (layers_log2 >= 0) {
+                rl = min(lt >> layers_log2, rpw - 1);
+                A = lt - (rl << layers_log2);
+            } else {
+                rl = min((int)(((float)lt + 0.5f) * inv_layers), rpw - 1);
+                A = lt - rl * n_layers;
+            }
             unsigned m9 = 0u;   // which of the <= 3 x 3 bricks of the footprint hold a flagged voxel
             int bl = 0, cl = 0;
-            if (lt < pair_hi) {
+            {
+                // Everything the pair needs of its ray is asked of LDS at once and every lane does the arithmetic (rl is
+                // a ray of the wave whatever lt is): nested conditions made five dependent LDS round trips of this.
                 const SweepRay& R = s_ray[rl];
-                if (R.state == 1 && M->hand[rl] == 0 && A < R.na) {
-                    const float ulo = R.ulo, uhi = R.uhi, oa = R.oa;
-                    float L = (A == 0) ? -1e30f : (float)(8 * A) - kEps;
-                    float U = (A == R.na - 1) ? 1e30f : (float)(8 * A + 8) + kEps;
-                    L = fmaxf(L, ulo);
-                    U = fminf(U, uhi);
-                    if (L <= U) {
-                        const float sb = R.sb, sc = R.sc, ob = R.ob, oc = R.oc;
-                        const int size_b = R.size_b, size_c = R.size_c;
-                        const float bL = fmaf(L - oa, sb, ob), bU = fmaf(U - oa, sb, ob);
-                        const float cL = fmaf(L - oa, sc, oc), cU = fmaf(U - oa, sc, oc);
-                        bl = sweep_clampi((int)floorf(fminf(bL, bU) - kEps), 0, size_b - 2) >> 3;
-                        const int bh = sweep_clampi((int)floorf(fmaxf(bL, bU) + kEps), 0, size_b - 2) >> 3;
-                        cl = sweep_clampi((int)floorf(fminf(cL, cU) - kEps), 0, size_c - 2) >> 3;
-                        const int ch = sweep_clampi((int)floorf(fmaxf(cL, cU) + kEps), 0, size_c - 2) >> 3;
-                        const int cs_b = R.cs_b, cs_c = R.cs_c;
-                        const int lin0 = __mul24(A, R.cs_a) + __mul24(bl, cs_b) + __mul24(cl, cs_c);
-                        // 0 .. 2: the footprint of one layer is at most 8 slabs + the box's half voxel + the margins long
-                        // and the slopes are <= 1, so it spans less than two bricks' lengths
-                        const int nb_ = min(bh - bl, 2), nc_ = min(ch - cl, 2);
-                        // the 2 x 2 corner first, its four bits asked for together; a third row or column is rare
-                        const int l00 = lin0, l01 = lin0 + cs_c, l10 = lin0 + cs_b, l11 = lin0 + cs_b + cs_c;
-                        const unsigned w00 = g.coarse[l00 >> 5];
-                        const unsigned w01 = nc_ >= 1 ? g.coarse[l01 >> 5] : 0u;
-                        const unsigned w10 = nb_ >= 1 ? g.coarse[l10 >> 5] : 0u;
-                        const unsigned w11 = (nb_ >= 1 && nc_ >= 1) ? g.coarse[l11 >> 5] : 0u;
-                        m9 = ((w00 >> (l00 & 31)) & 1u) | (((w01 >> (l01 & 31)) & 1u) << 1) |
-                             (((w10 >> (l10 & 31)) & 1u) << 3) | (((w11 >> (l11 & 31)) & 1u) << 4);
-                        if (nb_ == 2 || nc_ == 2) {
-                            for (int ib = 0; ib <= nb_; ++ib)
-                                for (int ic = 0; ic <= nc_; ++ic) {
-                                    if (ib < 2 && ic < 2) continue;
-                                    const int lin = lin0 + __mul24(ib, cs_b) + __mul24(ic, cs_c);
-                                    m9 |= ((g.coarse[lin >> 5] >> (lin & 31)) & 1u) << (3 * ib + ic);
-                                }
-                        }
+                const int state = R.state, hand = M->hand[rl], na = R.na;
+                const float ulo = R.ulo, uhi = R.uhi, oa = R.oa;
+                const float sb = R.sb, sc = R.sc, ob = R.ob, oc = R.oc;
+                const int size_b = R.size_b, size_c = R.size_c;
+                const int cs_a = R.cs_a, cs_b = R.cs_b, cs_c = R.cs_c;
+                float L = (A == 0) ? -1e30f : (float)(8 * A) - kEps;
+                float U = (A == na - 1) ? 1e30f : (float)(8 * A + 8) + kEps;
+                L = fmaxf(L, ulo);
+                U = fminf(U, uhi);
+                const bool on = lt < pair_hi && state == 1 && hand == 0 && A < na && L <= U;
+                const float bL = fmaf(L - oa, sb, ob), bU = fmaf(U - oa, sb, ob);
+                const float cL = fmaf(L - oa, sc, oc), cU = fmaf(U - oa, sc, oc);
+                bl = sweep_clampi((int)floorf(fminf(bL, bU) - kEps), 0, size_b - 2) >> 3;
+                const int bh = sweep_clampi((int)floorf(fmaxf(bL, bU) + kEps), 0, size_b - 2) >> 3;
+                cl = sweep_clampi((int)floorf(fminf(cL, cU) - kEps), 0, size_c - 2) >> 3;
+                const int ch = sweep_clampi((int)floorf(fmaxf(cL, cU) + kEps), 0, size_c - 2) >> 3;
+                if (on) {
+                    const int lin0 = __mul24(A, cs_a) + __mul24(bl, cs_b) + __mul24(cl, cs_c);
+                    // 0 .. 2: the footprint of one layer is at most 8 slabs + the box's half voxel + the margins long
+                    // and the slopes are <= 1, so it spans less than two bricks' lengths
+                    const int nb_ = min(bh - bl, 2), nc_ = min(ch - cl, 2);
+                    // the 2 x 2 corner first, its four bits asked for together; a third row or column is rare.  (Byte
+                    // offsets in 32 bits beside the bitmap's base: one address instruction a load instead of three.)
+                    const int l00 = lin0, l01 = lin0 + cs_c, l10 = lin0 + cs_b, l11 = lin0 + cs_b + cs_c;
+                    const char* const cbase = reinterpret_cast<const char*>(g.coarse);
+#define ASURF_COARSE_WORD(lin_) (*reinterpret_cast<const unsigned*>(cbase + (((unsigned)(lin_) >> 5) << 2)))
+                    const unsigned w00 = ASURF_COARSE_WORD(l00);
+                    const unsigned w01 = nc_ >= 1 ? ASURF_COARSE_WORD(l01) : 0u;
+                    const unsigned w10 = nb_ >= 1 ? ASURF_COARSE_WORD(l10) : 0u;
+                    const unsigned w11 = (nb_ >= 1 && nc_ >= 1) ? ASURF_COARSE_WORD(l11) : 0u;
+                    m9 = ((w00 >> (l00 & 31)) & 1u) | (((w01 >> (l01 & 31)) & 1u) << 1) |
+                         (((w10 >> (l10 & 31)) & 1u) << 3) | (((w11 >> (l11 & 31)) & 1u) << 4);
+                    if (nb_ == 2 || nc_ == 2) {
+                        for (int ib = 0; ib <= nb_; ++ib)
+                            for (int ic = 0; ic <= nc_; ++ic) {
+                                if (ib < 2 && ic < 2) continue;
+                                const int lin = lin0 + __mul24(ib, cs_b) + __mul24(ic, cs_c);
+                                m9 |= ((ASURF_COARSE_WORD(lin) >> (lin & 31)) & 1u) << (3 * ib + ic);
+                            }
                     }
+#undef ASURF_COARSE_WORD
                 }
             }
             const int cnt = __popc(m9);
