@@ -647,6 +647,8 @@ k_sweep_wave(KGrid g, KOpt o, const float* __restrict__ origins, const float* __
 #define ASURF_SWEEP_LEAVE(n_)
 #endif
     ASURF_SWEEP_LEAVE(1)
+    const char* const cbase = reinterpret_cast<const char*>(g.coarse);
+#define ASURF_COARSE_WORD(lin_) (*reinterpret_cast<const unsigned*>(cbase + (((unsigned)(lin_) >> 5) << 2)))
     const float inv_layers = 1.f / (float)n_layers;
     const int layers_log2 = (n_layers & (n_layers - 1)) == 0 ? 31 - __clz(n_layers) : -1;
     int group = rpw;   // rays taken together; shrinks when the wave's lists overflow
@@ -654,24 +656,13 @@ k_sweep_wave(KGrid g, KOpt o, const float* __restrict__ origins, const float* __
         const int r_hi = min(r_lo + group, rpw);
         // ---- phase 1: lane = (ray, brick layer) -> tasks, in (ray, layer) order ----
         int ntask = 0;   // (wave-uniform)
-        const int pair_lo = r_lo * n_layers, pair_hi = r_hi * n_layers;
-        for (int lt0 = pair_lo; lt0 < pair_hi; lt0 += 64) {
-            const int lt = lt0 + lane;
-            // (ray, layer) of the pair: a shift when the layers are a power of two (the product is a quarter-rate
-            // instruction)
-            int rl, A;
-            if (layers_log2 >= 0) {
-                rl = min(lt >> layers_log2, rpw - 1);
-                A = lt - (rl << layers_log2);
-            } else {
-                rl = min((int)(((float)lt + 0.5f) * inv_layers), rpw - 1);
-                A = lt - rl * n_layers;
-            }
+        // one turn of 64 pairs: lane's pair is (ray rl, layer A), `in_range` false for lanes beyond the last pair
+        auto pair_turn = [&](const int rl, const int A, const bool in_range) {
             unsigned m9 = 0u;   // which of the <= 3 x 3 bricks of the footprint hold a flagged voxel
             int bl = 0, cl = 0;
             {
                 // Everything the pair needs of its ray is asked of LDS at once and every lane does the arithmetic (rl is
-                // a ray of the wave whatever lt is): nested conditions made five dependent LDS round trips of this.
+                // a ray of the wave whatever the lane): nested conditions made five dependent LDS round trips of this.
                 const SweepRay& R = s_ray[rl];
                 const int state = R.state, hand = M->hand[rl], na = R.na;
                 const float ulo = R.ulo, uhi = R.uhi, oa = R.oa;
@@ -682,7 +673,7 @@ k_sweep_wave(KGrid g, KOpt o, const float* __restrict__ origins, const float* __
                 float U = (A == na - 1) ? 1e30f : (float)(8 * A + 8) + kEps;
                 L = fmaxf(L, ulo);
                 U = fminf(U, uhi);
-                const bool on = lt < pair_hi && state == 1 && hand == 0 && A < na && L <= U;
+                const bool on = in_range && state == 1 && hand == 0 && A < na && L <= U;
                 const float bL = fmaf(L - oa, sb, ob), bU = fmaf(U - oa, sb, ob);
                 const float cL = fmaf(L - oa, sc, oc), cU = fmaf(U - oa, sc, oc);
                 bl = sweep_clampi((int)floorf(fminf(bL, bU) - kEps), 0, size_b - 2) >> 3;
@@ -697,8 +688,6 @@ k_sweep_wave(KGrid g, KOpt o, const float* __restrict__ origins, const float* __
                     // the 2 x 2 corner first, its four bits asked for together; a third row or column is rare.  (Byte
                     // offsets in 32 bits beside the bitmap's base: one address instruction a load instead of three.)
                     const int l00 = lin0, l01 = lin0 + cs_c, l10 = lin0 + cs_b, l11 = lin0 + cs_b + cs_c;
-                    const char* const cbase = reinterpret_cast<const char*>(g.coarse);
-#define ASURF_COARSE_WORD(lin_) (*reinterpret_cast<const unsigned*>(cbase + (((unsigned)(lin_) >> 5) << 2)))
                     const unsigned w00 = ASURF_COARSE_WORD(l00);
                     const unsigned w01 = nc_ >= 1 ? ASURF_COARSE_WORD(l01) : 0u;
                     const unsigned w10 = nb_ >= 1 ? ASURF_COARSE_WORD(l10) : 0u;
@@ -713,13 +702,12 @@ k_sweep_wave(KGrid g, KOpt o, const float* __restrict__ origins, const float* __
                                 m9 |= ((ASURF_COARSE_WORD(lin) >> (lin & 31)) & 1u) << (3 * ib + ic);
                             }
                     }
-#undef ASURF_COARSE_WORD
                 }
             }
             const int cnt = __popc(m9);
             const int incl = wave_incl_scan(cnt);
             const int total = bcast_i(incl, 63);
-            if (total == 0) continue;   // (wave-uniform)
+            if (total == 0) return;   // (wave-uniform)
             int at = ntask + incl - cnt;
             if (ntask + total <= task_cap) {
                 unsigned m = m9;
@@ -731,6 +719,120 @@ k_sweep_wave(KGrid g, KOpt o, const float* __restrict__ origins, const float* __
                 }
             }
             ntask += total;
+        };
+        // The rays of a wave are neighbours in the batch, and for a coherent batch neighbours in space: over a layer
+        // their footprints share a brick or two, and most layers hold nothing for any of them (26 layers a ray on the
+        // bench scene, 4 with a flagged brick).  So first lane = LAYER: the box around the footprints of all rays of the
+        // group over that layer (a ray's own footprint is inside it: floor and the clamps are monotone) against the
+        // bitmap -- a sixteenth of the pairs' arithmetic per (ray, layer) -- and then the pairs of the layers that are
+        // left only, in (ray, layer) order as before.  Needs one dominant axis for the whole group; a box wider than 3 x 3
+        // bricks (an incoherent batch) is not looked up, its layer counts as occupied.
+        bool bundled = false;
+        int nk = 0;   // layers left (wave-uniform)
+        if (r_hi - r_lo >= 8 && n_layers <= key_cap) {
+            int my_a = -1;
+            if (lane >= r_lo && lane < r_hi && s_ray[lane].state == 1) my_a = s_ray[lane].flags & 3;
+            const unsigned long long act = __ballot(my_a >= 0);
+            if (act != 0ull) {
+                const int a0 = bcast_i(my_a, __ffsll((long long)act) - 1);
+                bundled = __ballot(my_a >= 0 && my_a != a0) == 0ull;
+            }
+            if (bundled) {
+                const SweepRay& R0 = s_ray[__ffsll((long long)act) - 1];
+                const int na = R0.na, size_b = R0.size_b, size_c = R0.size_c, cs_a = R0.cs_a, cs_b = R0.cs_b, cs_c = R0.cs_c;
+                int* const s_layers = reinterpret_cast<int*>(s_key);   // (no keys yet)
+                // lanes per layer: the rays of the group are dealt to `sub` lanes, combined by xor shuffles
+                const int sub_log2 = n_layers <= 16 ? 2 : (n_layers <= 32 ? 1 : 0), sub = 1 << sub_log2;
+                const int part = lane & (sub - 1);
+                for (int A0 = 0; A0 < na; A0 += 64 >> sub_log2) {
+                    const int A = A0 + (lane >> sub_log2);
+                    const float Lr = (A == 0) ? -1e30f : (float)(8 * A) - kEps;
+                    const float Ur = (A == na - 1) ? 1e30f : (float)(8 * A + 8) + kEps;
+                    float bmin = 3e38f, bmax = -3e38f, cmin = 3e38f, cmax = -3e38f;
+                    // (a ray that is not swept has ulo > uhi -- phase 0 -- and drops out by itself; one that was handed
+                    // back only widens the box)
+                    for (int r = r_lo + part; r < r_hi; r += sub) {
+                        const SweepRay& R = s_ray[r];
+                        const float L = fmaxf(Lr, R.ulo), U = fminf(Ur, R.uhi);
+                        const bool have = L <= U;
+                        const float oa = R.oa, sb = R.sb, sc = R.sc, ob = R.ob, oc = R.oc;
+                        const float bL = fmaf(L - oa, sb, ob), bU = fmaf(U - oa, sb, ob);
+                        const float cL = fmaf(L - oa, sc, oc), cU = fmaf(U - oa, sc, oc);
+                        const float b0 = fminf(bmin, fminf(bL, bU)), b1 = fmaxf(bmax, fmaxf(bL, bU));
+                        const float c0 = fminf(cmin, fminf(cL, cU)), c1 = fmaxf(cmax, fmaxf(cL, cU));
+                        bmin = have ? b0 : bmin;
+                        bmax = have ? b1 : bmax;
+                        cmin = have ? c0 : cmin;
+                        cmax = have ? c1 : cmax;
+                    }
+                    for (int m = 1; m < sub; m <<= 1) {
+                        bmin = fminf(bmin, __shfl_xor(bmin, m));
+                        bmax = fmaxf(bmax, __shfl_xor(bmax, m));
+                        cmin = fminf(cmin, __shfl_xor(cmin, m));
+                        cmax = fmaxf(cmax, __shfl_xor(cmax, m));
+                    }
+                    bool occupied = false;
+                    if (A < na && bmin <= bmax) {
+                        const int bl = sweep_clampi((int)floorf(bmin - kEps), 0, size_b - 2) >> 3;
+                        const int bh = sweep_clampi((int)floorf(bmax + kEps), 0, size_b - 2) >> 3;
+                        const int cl = sweep_clampi((int)floorf(cmin - kEps), 0, size_c - 2) >> 3;
+                        const int ch = sweep_clampi((int)floorf(cmax + kEps), 0, size_c - 2) >> 3;
+                        const int nb_ = bh - bl, nc_ = ch - cl;
+                        if (nb_ > 2 || nc_ > 2) {
+                            occupied = true;
+                        } else {
+                            // the 2 x 2 corner together, a third row or column when the box has one
+                            const int lin0 = __mul24(A, cs_a) + __mul24(bl, cs_b) + __mul24(cl, cs_c);
+                            const int l00 = lin0, l01 = lin0 + cs_c, l10 = lin0 + cs_b, l11 = lin0 + cs_b + cs_c;
+                            const unsigned w00 = ASURF_COARSE_WORD(l00);
+                            const unsigned w01 = nc_ >= 1 ? ASURF_COARSE_WORD(l01) : 0u;
+                            const unsigned w10 = nb_ >= 1 ? ASURF_COARSE_WORD(l10) : 0u;
+                            const unsigned w11 = (nb_ >= 1 && nc_ >= 1) ? ASURF_COARSE_WORD(l11) : 0u;
+                            unsigned any = ((w00 >> (l00 & 31)) | (w01 >> (l01 & 31)) | (w10 >> (l10 & 31)) | (w11 >> (l11 & 31))) & 1u;
+                            if (nb_ == 2 || nc_ == 2) {
+                                for (int ib = 0; ib <= nb_; ++ib)
+                                    for (int ic = 0; ic <= nc_; ++ic) {
+                                        if (ib < 2 && ic < 2) continue;
+                                        const int lin = lin0 + __mul24(ib, cs_b) + __mul24(ic, cs_c);
+                                        any |= (ASURF_COARSE_WORD(lin) >> (lin & 31)) & 1u;
+                                    }
+                            }
+                            occupied = any != 0u;
+                        }
+                    }
+                    const unsigned long long mo = __ballot(occupied && part == 0);
+                    if (occupied && part == 0) s_layers[nk + __popcll(mo & ((1ull << lane) - 1ull))] = A;
+                    nk += __popcll(mo);
+                }
+                sweep_wave_sync();
+                if (nk > 0) {
+                    const int nr = r_hi - r_lo, npairs = nr * nk;
+                    const float inv_nk = 1.f / (float)nk;
+                    for (int lt0 = 0; lt0 < npairs; lt0 += 64) {
+                        const int lt = lt0 + lane;
+                        const int ri = min((int)(((float)lt + 0.5f) * inv_nk), nr - 1);
+                        const int j = min(lt - ri * nk, nk - 1);
+                        pair_turn(r_lo + ri, s_layers[j], lt < npairs);
+                    }
+                }
+            }
+        }
+        if (!bundled) {
+            const int pair_lo = r_lo * n_layers, pair_hi = r_hi * n_layers;
+            for (int lt0 = pair_lo; lt0 < pair_hi; lt0 += 64) {
+                const int lt = lt0 + lane;
+                // (ray, layer) of the pair: a shift when the layers are a power of two (the product is a quarter-rate
+                // instruction)
+                int rl, A;
+                if (layers_log2 >= 0) {
+                    rl = min(lt >> layers_log2, rpw - 1);
+                    A = lt - (rl << layers_log2);
+                } else {
+                    rl = min((int)(((float)lt + 0.5f) * inv_layers), rpw - 1);
+                    A = lt - rl * n_layers;
+                }
+                pair_turn(rl, A, lt < pair_hi);
+            }
         }
         if (ntask > task_cap) {   // (wave-uniform)
             if (group > 1) {
@@ -1041,6 +1143,7 @@ k_sweep_wave(KGrid g, KOpt o, const float* __restrict__ origins, const float* __
         sweep_wave_sync();
         r_lo = r_hi;
     }
+#undef ASURF_COARSE_WORD
     tl.end();
 }
 
