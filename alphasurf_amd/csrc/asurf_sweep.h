@@ -1091,8 +1091,12 @@ k_sweep_wave(KGrid g, KOpt o, const float* __restrict__ origins, const float* __
         int lbase;
         {
             unsigned fm = 0u;  // rays that fill slot `lane`
-            if (lane < P.C1)
-                for (int r2 = r_lo; r2 < r_hi; ++r2) fm |= (M->n[r2] > lane ? 1u : 0u) << r2;
+            // (ray r2's count sits in lane r2: read across the wave, no LDS)
+            const int n_mine = (lane >= r_lo && lane < r_hi) ? M->n[lane] : 0;
+#pragma unroll
+            for (int r2 = 0; r2 < kSweepWaveRays; ++r2)
+                fm |= (__builtin_amdgcn_readlane(n_mine, r2) > lane ? 1u : 0u) << r2;
+            if (lane >= P.C1) fm = 0u;
             const int c = __popc(fm);
             const int ci = wave_incl_scan(c);
             s_slot0[lane] = ci - c;
