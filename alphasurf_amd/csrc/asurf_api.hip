@@ -125,6 +125,7 @@ struct MaskLayout {
     size_t off_p_items, off_p_citem, off_p_nitems, off_p_cut, off_p_flagged, off_p_counters, off_p_pool;
     size_t off_p_cand;  // cand_mask [Q]
     size_t off_p_spbase, off_p_spill, off_p_list, off_rec_list;
+    int rec_depth;   // records a ray (layout_for)
     // ray ordering inside the fused call (batches of kOrderMinRays rays and more): permutation, the rays / targets /
     // colours in the new order, sort scratch, the coherence probe's two counts
     size_t off_ord_perm, off_ord_o, off_ord_d, off_ord_gt, off_ord_rgb, off_ord_tmp, off_ord_probe, ord_tmp_bytes;
@@ -147,14 +148,20 @@ static int walk_segments(long long n_rays) {
 // (asurf_fused_params::order_rays): below, the ordering's fixed costs exceed what it returns
 constexpr long long kOrderMinRays = 65536;
 
-// per-ray capacity of the sample records the fused forward leaves for the replaying
-// backward; rays with more samples fall back to the walking backward kernel
+// per-ray capacity of the sample records the fused forward leaves for the replaying backward; rays with more samples fall
+// back to the walking backward kernel.  kRecDepth is what asurf_workspace_bytes() sizes the workspace for; a caller that
+// expects more samples a ray (fake samples in every voxel: 11 a ray on the bench scene, a fifth of the rays beyond 32)
+// asks asurf_workspace_bytes_rec() for a deeper one, and every call takes the deepest of kRecDepths that the workspace
+// it is handed holds -- a function of the buffer's size alone, so a buffer has one layout.
 constexpr int kRecDepth = 32;
+constexpr int kRecDepths[] = {128, 64, 32};
+static_assert(kRecDepths[0] <= (1 << (32 - kRecRayBits)), "a record's number fits above the ray's in a list cell");
 
 size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
-MaskLayout layout_for(const int32_t size[3], int64_t n_rays, int32_t M) {
+MaskLayout layout_for(const int32_t size[3], int64_t n_rays, int32_t M, int rec_depth = kRecDepth) {
     MaskLayout L;
+    L.rec_depth = rec_depth;
     for (int i = 0; i < 3; ++i) L.nb[i] = (size[i] + 7) / 8;
     L.nwz = (L.nb[2] + 31) / 32;
     L.n_bricks = (size_t)L.nb[0] * L.nb[1] * L.nb[2];
@@ -192,7 +199,7 @@ MaskLayout layout_for(const int32_t size[3], int64_t n_rays, int32_t M) {
     off = align_up(off + (size_t)(n_rays > 0 ? n_rays : 0) * 4, 256);
     // sample records exist only for fused calls (M > 0 is not required for them, but a
     // forward-only / backward-only call never passes through the fused path)
-    const size_t rplane = (size_t)kRecDepth * (size_t)(n_rays > 0 ? n_rays : 0) * 4;
+    const size_t rplane = (size_t)rec_depth * (size_t)(n_rays > 0 ? n_rays : 0) * 4;
     L.off_rec_v = off;
     off = align_up(off + rplane, 256);
     L.off_rec_m = off;
@@ -203,7 +210,7 @@ MaskLayout layout_for(const int32_t size[3], int64_t n_rays, int32_t M) {
     off = align_up(off + (size_t)(n_rays > 0 ? n_rays : 0) * 4, 256);
     L.off_rec_sws = off;
     off = align_up(off + (size_t)(n_rays > 0 ? n_rays : 0) * 4, 256);
-    L.off_rec_f = off;  // 8 forward + 9 backward float planes [kRecDepth][Q]
+    L.off_rec_f = off;  // 8 forward + 9 backward float planes [rec_depth][Q]
     off = align_up(off + 17 * rplane, 256);
     // three-kernel forward pipeline (asurf_pipeline.h)
     const size_t nr = (size_t)(n_rays > 0 ? n_rays : 0);
@@ -235,8 +242,8 @@ MaskLayout layout_for(const int32_t size[3], int64_t n_rays, int32_t M) {
     L.list_cap = kPipeC1 * (int)(((nr + kListGroups - 1) / kListGroups + L.band_rays) / kListShards + 256);
     off = align_up(off + (size_t)L.list_cap * kListSegs * 4, 256);
     L.off_rec_list = off;    // dense list of visited records (k_bwd_seq -> k_bwd_sh, k_bwd_geo), kRecShards segments:
-                             // block b of k_bwd_seq (256 rays, kRecDepth records each at most) fills segment b % 8
-    L.rec_list_cap = (int)(((nr + kBlock - 1) / kBlock + kRecShards - 1) / kRecShards) * kBlock * kRecDepth;
+                             // block b of k_bwd_seq (256 rays, rec_depth records each at most) fills segment b % 8
+    L.rec_list_cap = (int)(((nr + kBlock - 1) / kBlock + kRecShards - 1) / kRecShards) * kBlock * rec_depth;
     off = align_up(off + (size_t)L.rec_list_cap * kRecShards * 4, 256);
     // 16 candidates a ray on average (the live config yields 0.7; three level sets with fake samples 11: with 8 a fifth of
     // the rays of such a scene went to the one-kernel path, whose walking backward then took 30 of the step's 39 ms)
@@ -261,6 +268,18 @@ MaskLayout layout_for(const int32_t size[3], int64_t n_rays, int32_t M) {
     off = align_up(off + (onr ? 256 : 0), 256);
     L.total = off;
     return L;
+}
+
+// the layout of a workspace of `bytes` bytes: the deepest records that fit (kRecDepth when nothing does: the caller's size
+// check then fails as it always did)
+MaskLayout layout_fitting(const int32_t size[3], int64_t n_rays, int32_t M, size_t bytes) {
+    if (n_rays > 0)
+        for (int d : kRecDepths) {
+            if (d == kRecDepth) break;
+            const MaskLayout L = layout_for(size, n_rays, M, d);
+            if (L.total <= bytes) return L;
+        }
+    return layout_for(size, n_rays, M);
 }
 
 int check_grid(const asurf_grid* g, bool need_surface = true) {
@@ -588,7 +607,7 @@ int prepare(const asurf_grid* grid, const asurf_rays* rays, const asurf_render_o
     if (!opt) return fail(ASURF_E_INVALID, "render options are NULL");
     if (opt->alpha_activation_type != ASURF_SIGMOID_FN && opt->alpha_activation_type != ASURF_EXP_FN)
         return fail(ASURF_E_INVALID, "alpha_activation_type must be 0 (sigmoid) or 1 (exp)");
-    L.ML = layout_for(grid->size, masks_only ? 0 : rays->n_rays, M);  // masks_only: no per-ray tables
+    L.ML = layout_fitting(grid->size, masks_only ? 0 : rays->n_rays, M, workspace ? workspace_bytes : 0);  // masks_only: no per-ray tables
     if (!workspace || workspace_bytes < L.ML.total)
         return fail(ASURF_E_WORKSPACE, "workspace of %zu bytes needed, got %zu", L.ML.total,
                     workspace ? workspace_bytes : (size_t)0);
@@ -863,10 +882,10 @@ int run_forward(const Launch& L, const asurf_rays* rays, float* rgb_out, int M, 
         const dim3 comp_grid((unsigned)((Q + (kBlock / 64) * rpw - 1) / ((kBlock / 64) * rpw)));
         if (cache)
             hipLaunchKernelGGL((k_comp<B, true>), comp_grid, dim3(kBlock), 0, L.stream, L.g, L.o,
-                               rays->dirs, Q, P, rgb_out, M, ca, cw, ct, cn, rv, rm, rn, kRecDepth, rf, rpw);
+                               rays->dirs, Q, P, rgb_out, M, ca, cw, ct, cn, rv, rm, rn, L.ML.rec_depth, rf, rpw);
         else
             hipLaunchKernelGGL((k_comp<B, false>), comp_grid, dim3(kBlock), 0, L.stream, L.g, L.o,
-                               rays->dirs, Q, P, rgb_out, M, ca, cw, ct, cn, rv, rm, rn, kRecDepth, rf, rpw);
+                               rays->dirs, Q, P, rgb_out, M, ca, cw, ct, cn, rv, rm, rn, L.ML.rec_depth, rf, rpw);
         prof_after("k_comp", 1, L.stream);
         if (int e = launch_error("forward pipeline")) return e;
         if (L.o.debug & 16) {  // diagnostics: what the pipeline's counters hold after this call
@@ -894,7 +913,7 @@ int run_forward(const Launch& L, const asurf_rays* rays, float* rgb_out, int M, 
 #define ASURF_FWD(CACHE, COUNT, CLDS)                                                            \
     hipLaunchKernelGGL((k_forward<B, CACHE, COUNT, CLDS>), L.ray_grid, dim3(kBlock), L.dyn_lds,  \
                        fstream, L.g, L.o, rays->origins, rays->dirs, (long long)rays->n_rays,    \
-                       rgb_out, M, ca, cw, ct, cn, rv, rm, rn, kRecDepth, rf, ray_list, n_list, cnt)
+                       rgb_out, M, ca, cw, ct, cn, rv, rm, rn, L.ML.rec_depth, rf, ray_list, n_list, cnt)
 #define ASURF_FWD2(CACHE, COUNT)             \
     do {                                     \
         if (L.coarse_in_lds) ASURF_FWD(CACHE, COUNT, true); \
@@ -937,7 +956,7 @@ int run_backward(const Launch& L, const asurf_rays* rays, const KLoss& loss, con
         // split replay: sequential scalars per ray, then one sample per wave step (SH) and
         // one sample per lane (geometry)
         SampleRec S;
-        const size_t plane = (size_t)kRecDepth * (size_t)rays->n_rays;
+        const size_t plane = (size_t)L.ML.rec_depth * (size_t)rays->n_rays;
         float* f = reinterpret_cast<float*>(L.ws + L.ML.off_rec_f);
         S.v = const_cast<int*>(rv);
         S.m = const_cast<int*>(rm);
@@ -964,7 +983,7 @@ int run_backward(const Launch& L, const asurf_rays* rays, const KLoss& loss, con
         S.list_cap = L.ML.rec_list_cap;
         S.n_eff = reinterpret_cast<int*>(L.ws + L.ML.off_rec_neff);
         S.sws = reinterpret_cast<float*>(L.ws + L.ML.off_rec_sws);
-        S.R = kRecDepth;
+        S.R = L.ML.rec_depth;
         const long long Q = rays->n_rays;
         // (the list's cursor lies among the pipeline's counters: the forward of this call has zeroed it if it ran the
         // pipeline -- a memset node of its own is 4 us on the stream)
@@ -1186,6 +1205,14 @@ size_t asurf_workspace_bytes(const int32_t size[3], int64_t n_rays, int32_t l_di
     return layout_for(size, n_rays, l_dist_max_sample).total;
 }
 
+size_t asurf_workspace_bytes_rec(const int32_t size[3], int64_t n_rays, int32_t l_dist_max_sample, int32_t rec_depth) {
+    if (!size) return 0;
+    int depth = kRecDepths[0];
+    for (int d : kRecDepths)
+        if (d >= rec_depth) depth = d;   // the smallest supported depth that holds rec_depth (the deepest beyond)
+    return layout_for(size, n_rays, l_dist_max_sample, depth).total;
+}
+
 int asurf_volume_render_surf_trav(const asurf_grid* grid, const asurf_rays* rays,
                                   const asurf_render_options* opt, float* rgb_out, void* workspace,
                                   size_t workspace_bytes, uint64_t* counters, void* stream) {
@@ -1306,7 +1333,7 @@ int asurf_volume_render_surf_trav_fused(const asurf_grid* grid, const asurf_rays
     const bool replay = !cfg.no_replay && grid->level_set_num <= 32 &&
                         (opt->stop_thresh <= 0.f || opt->stop_thresh >= 2e-8f);
     const bool pipe = use_pipeline(grid, rays, opt, counters);
-    const int replay_mode = (cfg.no_split_bwd || rays->n_rays >= (1ll << kListRayBits)) ? 1 : 3;
+    const int replay_mode = (cfg.no_split_bwd || rays->n_rays >= (1ll << kRecRayBits)) ? 1 : 3;
     // The rays the pipeline hands to the one-kernel path (tables, pool or records too small: none at all on most calls)
     // are rendered and differentiated by two kernels of their own -- one-kernel forward, walking backward -- that depend
     // on k_comp and on nothing after it.  On the call's stream each of them is a dependent launch in the chain (8 us

@@ -284,7 +284,7 @@ k_bwd_seq(KOpt o, KLoss L, float trunc_a, long long Q, const float* __restrict__
         const unsigned long long below = (1ull << (threadIdx.x & 63)) - 1ull;
         for (int j = 0; __any(nt > j); ++j) {
             const unsigned long long m = __ballot(nt > j);
-            if (nt > j) S.list[base0 + __popcll(m & below)] = ((unsigned)j << kListRayBits) | (unsigned)q;
+            if (nt > j) S.list[base0 + __popcll(m & below)] = ((unsigned)j << kRecRayBits) | (unsigned)q;
             base0 += __popcll(m);
         }
     }
@@ -326,8 +326,8 @@ k_bwd_sh(KGrid g, KGrads G, int want_dpos, const float* __restrict__ dirs, long 
   for (int base = wave_id * chunk; base < n_list; base += (int)gridDim.x * (kBlock / 64) * chunk) {
     const bool mine = lane < chunk && base + lane < n_list;
     const unsigned cell = mine ? RL.cell(S, base + lane) : 0u;
-    const long long q = (long long)(cell & ((1u << kListRayBits) - 1u));
-    const int r = (int)(cell >> kListRayBits);
+    const long long q = (long long)(cell & ((1u << kRecRayBits) - 1u));
+    const int r = (int)(cell >> kRecRayBits);
     const unsigned long long need0 = __ballot(mine);
     const size_t idx = (size_t)r * Q + q;
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // the previous turn's readers are done
@@ -501,8 +501,8 @@ k_bwd_geo(KGrid g, KOpt o, KLoss L, KGrads G, const float* __restrict__ origins,
     float gstd_acc = 0.f;
     if (mine) {
     const unsigned cell = RL.cell(S, i);
-    const long long q = (long long)(cell & ((1u << kListRayBits) - 1u));
-    const int r_i = (int)(cell >> kListRayBits);
+    const long long q = (long long)(cell & ((1u << kRecRayBits) - 1u));
+    const int r_i = (int)(cell >> kRecRayBits);
     const size_t idx = (size_t)r_i * Q + q;
     const int meta = S.m[idx];
     const bool fake = meta & 1;

@@ -83,6 +83,7 @@ constexpr int kRecShards = ASURF_REC_SHARDS;
 constexpr int kCtrRecShard0 = kCtrListShard0 + kListSegs * kCtrShardStride;
 constexpr int kCtrTotal = kCtrRecShard0 + kRecShards * kCtrShardStride;
 constexpr int kListRayBits = 27;  // rays per call < 2^27 for the list-driven kernels
+constexpr int kRecRayBits = 25;   // the backward's record list: record << 25 | ray (records a ray <= 128, rays < 2^25)
 // The kernels that work through a dense list are launched with a fixed number of blocks and
 // stride over it: the list length is only known on the device, and tens of thousands of
 // blocks that exit at once still cost their dispatch.

@@ -318,10 +318,11 @@ def volume_render_surf_trav_fused(grid, rays, opt, rgb_gt, beta_loss, sparsity_l
                                   lambda_l_di, l_di_alpha_thresh, surf_sparse_alpha_thresh,
                                   lambda_inplace_surf_sparse, lambda_inwards_norm_loss,
                                   lambda_conv_mode_samp, l_dist_max_sample, rgb_out, grads,
-                                  global_n_rays=0, counters=None, order_rays=0):
+                                  global_n_rays=0, counters=None, order_rays=0, rec_depth=None):
     """void volume_render_surf_trav_fused(...) -- svox2.cpp:38-40; surf_trav.cu:3802-3942;
     call site svox2/svox2.py:3594-3621.  `global_n_rays`, `counters` and `order_rays` (include/asurf.h,
-    asurf_fused_params) are extensions."""
+    asurf_fused_params) are extensions; `rec_depth`: sample records a ray the workspace is sized for (None: 32, or 128
+    with fake samples; asurf_workspace_bytes_rec)."""
     g, r, o = _pack_grid(grid), _pack_rays(rays), _pack_opt(opt)
     _check_input(rgb_gt, "rgb_gt", torch.float32)
     _check_input(rgb_out, "rgb_out", torch.float32)
@@ -354,7 +355,12 @@ def volume_render_surf_trav_fused(grid, rays, opt, rgb_gt, beta_loss, sparsity_l
     f.order_rays = int(order_rays)
     dev = grid.sh_data.device
     with torch.cuda.device(dev):
-        nb = _L.workspace_bytes(grid.links.shape, r.n_rays, int(l_dist_max_sample))
+        # fake samples leave ten times the samples a ray: room for 128 records instead of 32, or a fifth of the rays
+        # would be differentiated by the walking kernel (include/asurf.h, asurf_workspace_bytes_rec)
+        deep = bool(o.surf_fake_sample)
+        if rec_depth is None and deep:
+            rec_depth = 128
+        nb = _L.workspace_bytes(grid.links.shape, r.n_rays, int(l_dist_max_sample), rec_depth)
         ws = _workspace(dev, nb, g)
         _L.check(_L.lib().asurf_volume_render_surf_trav_fused(
             C.byref(g), C.byref(r), C.byref(o), C.byref(f), _ptr(rgb_out), C.byref(gg), _ptr(ws),

@@ -88,7 +88,7 @@ class AsurfFusedParams(C.Structure):
 N_COUNTERS = 4
 
 EXPORTS = [
-    "asurf_abi_version", "asurf_last_error", "asurf_workspace_bytes",
+    "asurf_abi_version", "asurf_last_error", "asurf_workspace_bytes", "asurf_workspace_bytes_rec",
     "asurf_volume_render_surf_trav", "asurf_volume_render_surf_trav_backward",
     "asurf_volume_render_surf_trav_fused", "asurf_volume_render_surface",
     "asurf_volume_render_surface_backward", "asurf_volume_render_surface_fused",
@@ -129,6 +129,8 @@ def lib():
         L.asurf_last_error.restype = C.c_char_p
         L.asurf_workspace_bytes.restype = C.c_size_t
         L.asurf_workspace_bytes.argtypes = [C.POINTER(C.c_int32), C.c_int64, C.c_int32]
+        L.asurf_workspace_bytes_rec.restype = C.c_size_t
+        L.asurf_workspace_bytes_rec.argtypes = [C.POINTER(C.c_int32), C.c_int64, C.c_int32, C.c_int32]
         vp = C.c_void_p
         L.asurf_volume_render_surf_trav.argtypes = [vp, vp, vp, vp, vp, C.c_size_t, vp, vp]
         L.asurf_volume_render_surf_trav_backward.argtypes = [vp, vp, vp, vp, vp, vp, vp, C.c_size_t, vp, vp]
@@ -222,6 +224,9 @@ def profile_read_spans():
     return list(zip(names.value.decode().split(","), [float(ms[i]) for i in range(n)]))
 
 
-def workspace_bytes(size, n_rays, l_dist_max_sample):
+def workspace_bytes(size, n_rays, l_dist_max_sample, rec_depth=None):
+    """Workspace size; `rec_depth`: sample records a ray for the fused call's backward (None: the library's 32)."""
     arr = (C.c_int32 * 3)(*[int(s) for s in size])
-    return int(lib().asurf_workspace_bytes(arr, int(n_rays), int(l_dist_max_sample)))
+    if rec_depth is None:
+        return int(lib().asurf_workspace_bytes(arr, int(n_rays), int(l_dist_max_sample)))
+    return int(lib().asurf_workspace_bytes_rec(arr, int(n_rays), int(l_dist_max_sample), int(rec_depth)))

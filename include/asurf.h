@@ -195,6 +195,14 @@ const char* asurf_last_error(void);
  * this grid size / ray count / sample-cache depth. */
 size_t asurf_workspace_bytes(const int32_t size[3], int64_t n_rays, int32_t l_dist_max_sample);
 
+/* The same with room for `rec_depth` sample records a ray (32, 64 or 128; rounded up, at most 128).  The fused call
+ * keeps a ray's samples for its backward pass (the reference walks the ray a second time, surf_trav.cu:1925-3140); a
+ * ray with more samples than the workspace has records for is differentiated by the walking kernel instead -- same
+ * result, a hundred times the time.  asurf_workspace_bytes() is this with 32: ample for the live configuration (0.7
+ * samples a ray), short for fake samples (surf_fake_sample: 11 a ray on the bench scene, a fifth of the rays beyond 32).  A call uses the
+ * deepest records the workspace it is handed has room for: the depth is a property of the buffer, not of the call. */
+size_t asurf_workspace_bytes_rec(const int32_t size[3], int64_t n_rays, int32_t l_dist_max_sample, int32_t rec_depth);
+
 /* Tensor volume_render_surf_trav(SparseGridSpec&, RaysSpec&, RenderOptions&)
  *   svox2.cpp:33, surf_trav.cu:3596-3654.  rgb_out: [n_rays,3] (written). */
 int asurf_volume_render_surf_trav(const asurf_grid* grid, const asurf_rays* rays,

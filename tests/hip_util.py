@@ -111,7 +111,8 @@ def render_backward(sc, origins, dirs, opts, grad_out, color_cache):
     return grads_np(gr)
 
 
-def render_fused(sc, origins, dirs, opts, rgb_gt, fused=None, global_n_rays=0, counters=False, links_epoch=0):
+def render_fused(sc, origins, dirs, opts, rgb_gt, fused=None, global_n_rays=0, counters=False, links_epoch=0,
+                 rec_depth=None):
     g, r, o = grid_spec(sc, links_epoch), rays_spec(origins, dirs), opt_spec(opts)
     gr = zero_grads(g)
     fused = dict(fused or {})
@@ -121,7 +122,7 @@ def render_fused(sc, origins, dirs, opts, rgb_gt, fused=None, global_n_rays=0, c
     rgb = torch.zeros_like(gt)
     cnt = torch.zeros(4, dtype=torch.int64, device=dev()) if counters else None
     _C.volume_render_surf_trav_fused(g, r, o, gt, *args, rgb, gr, global_n_rays=global_n_rays,
-                                     counters=cnt)
+                                     counters=cnt, rec_depth=rec_depth)
     torch.cuda.synchronize()
     out = (rgb.cpu().numpy(), grads_np(gr))
     return out + (cnt.cpu().numpy(),) if counters else out

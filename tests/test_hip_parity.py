@@ -713,6 +713,33 @@ def test_fallback_kernels_beside_the_backward_pipeline(hip, oracle):
     assert (g_a["mask"].astype(bool) == go["mask"].astype(bool)).all()
 
 
+def test_record_depth_follows_the_workspace(hip, oracle):
+    """Fake samples in every voxel of a thick shell: most rays leave more than 32 samples.  With a workspace sized for
+    32 records a ray they are differentiated by the walking kernel, with one sized for 128 (what the binding asks for
+    with these options: asurf_workspace_bytes_rec) by the replaying kernels -- same gradients either way, and the
+    oracle's."""
+    from alphasurf_amd import synth
+    sc = synth.make_sparse_scene(48, 4, seed=11, band=9.0, level_set=(-0.4, 0.0, 0.4), trunc_a=4.0, fake_sample_std=0.9)
+    o, d = synth.random_rays(2500, 43)
+    gt = np.random.RandomState(9).rand(o.shape[0], 3).astype(np.float32)
+    opts = OPTION_SETS["fake_all"]
+    fused = dict(lambda_l2=1.0, lambda_l_entropy=1e-3)
+    size = sc["links"].shape
+    assert (_asurf_lib.workspace_bytes(size, 2500, 64, 128) > _asurf_lib.workspace_bytes(size, 2500, 64, 64) >
+            _asurf_lib.workspace_bytes(size, 2500, 64, 32) == _asurf_lib.workspace_bytes(size, 2500, 64))
+    assert _asurf_lib.workspace_bytes(size, 2500, 64, 500) == _asurf_lib.workspace_bytes(size, 2500, 64, 128)
+    rgb_s, g_s, cnt = hip.render_fused(sc, o, d, opts, gt, fused, rec_depth=32, counters=True)
+    assert cnt[2] / cnt[3] > 20, "the scene is meant to leave rays with more than 32 samples"
+    rgb_m, g_m = hip.render_fused(sc, o, d, opts, gt, fused, rec_depth=64)
+    rgb_d, g_d = hip.render_fused(sc, o, d, opts, gt, fused)
+    rgb_o, go, _ = oracle.render_fused(sc, o, d, opts, gt, fused)
+    for rgb, g, what in ((rgb_s, g_s, "32 records"), (rgb_m, g_m, "64 records"), (rgb_d, g_d, "128 records")):
+        assert np.abs(rgb - rgb_o).max() <= RGB_TOL_ORACLE, what
+        for k in ("sh", "density", "surface"):
+            grad_close(g[k], go[k], GRAD_RTOL, f"grad_{k} vs oracle, {what}")
+        assert (g["mask"].astype(bool) == go["mask"].astype(bool)).all(), what
+
+
 def test_ray_ordering_handles_many_origins_and_crowded_strips(hip):
     """The ordering's two sort paths on batches that are not one camera's pixels: rays with an origin each (every ray its
     own hash, strips of a ray or two), eight cameras mixed and shuffled, and 6 000 copies of one ray (one strip far beyond
