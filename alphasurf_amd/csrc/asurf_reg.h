@@ -210,98 +210,151 @@ k_surface_normal_grad_sparse(RegGrid G, const float* __restrict__ surface,
                              int con_check, int ignore_empty, int use_l1, uint8_t* __restrict__ mask_out,
                              float* __restrict__ grad_data) {
     const long long tid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (tid >= Q) return;
-    int x, y, z;
-    reg_decode(G, rand_cells[tid], x, y, z);
+    const bool in_range = tid < Q;
+    const int cell = in_range ? rand_cells[tid] : -0x40000000;   // (never next to a listed cell)
+    int x = 0, y = 0, z = 0;
     RegCell c0;
-    reg_cell(G, surface, x, y, z, c0);
-    if (!c0.exist) return;
-    const bool empty0 = ignore_empty ? reg_all_one_side(c0.s, 8, lv_set) : false;
-    float n0[3];
-    reg_normal(c0, n0);
-    // neighbours along x (i = 0), y (1), z (2); the face shared with c0 decides connectivity
+    c0.exist = false;
     RegCell cn[3];
-    bool use[3];
-    int count = 0;
-#pragma unroll
-    for (int i = 0; i < 3; ++i) {
-        reg_cell_next(G, surface, x + (i == 0), y + (i == 1), z + (i == 2), 4 >> i, c0, cn[i]);
-        bool ok = cn[i].exist;
-        if (ok && con_check) {
-            const int bit = 4 >> i;  // corners of cn[i] on its low face along axis i
-            float f[4];
-            int k = 0;
-#pragma unroll
-            for (int j = 0; j < 8; ++j)
-                if (!(j & bit)) f[k++] = cn[i].s[j];
-            ok = !reg_all_one_side(f, 4, lv_set);
-        }
-        if (ok && ignore_empty) ok = !empty0 || !reg_all_one_side(cn[i].s, 8, lv_set);
-        use[i] = ok;
-        count += ok ? 1 : 0;
-    }
-    if (count == 0) return;
-    const float N0 = sqrtf(1e-9f + n0[0] * n0[0] + n0[1] * n0[1] + n0[2] * n0[2]);  // _NORM3
-    const float sc = scale * 1.f / count;
+    bool active = false;   // the cell exists and has a neighbour that counts
     // The reference issues 16 atomics per used neighbour (8 rows of c0, 8 of the neighbour).  The rows of c0,
     // and the neighbour's low face (which IS c0's high face), are summed in registers and leave once: at
     // most 8 + 3 * 4 atomics per cell instead of 48; a row is marked touched when any of its terms was non-zero.
     float acc0[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    bool nz0[8] = {false, false, false, false, false, false, false, false};
+    unsigned nz0 = 0u;                       // bit j: some term of acc0[j] was non-zero
+    float far_z[4] = {0.f, 0.f, 0.f, 0.f};   // the z neighbour's high face (rows at z + 2), corner (jj << 1) | 1
+    unsigned nz_far = 0u;
+    if (in_range) {
+        reg_decode(G, cell, x, y, z);
+        reg_cell(G, surface, x, y, z, c0);
+    }
+    if (c0.exist) {
+        const bool empty0 = ignore_empty ? reg_all_one_side(c0.s, 8, lv_set) : false;
+        float n0[3];
+        reg_normal(c0, n0);
+        // neighbours along x (i = 0), y (1), z (2); the face shared with c0 decides connectivity
+        bool use[3];
+        int count = 0;
 #pragma unroll
-    for (int i = 0; i < 3; ++i) {
-        if (!use[i]) continue;
-        float n1[3];
-        reg_normal(cn[i], n1);
-        const float N1 = sqrtf(1e-9f + n1[0] * n1[0] + n1[1] * n1[1] + n1[2] * n1[2]);
-        float w[3];  // dLoss / d(L_b), L = n0/N0 - n1/N1
+        for (int i = 0; i < 3; ++i) {
+            reg_cell_next(G, surface, x + (i == 0), y + (i == 1), z + (i == 2), 4 >> i, c0, cn[i]);
+            bool ok = cn[i].exist;
+            if (ok && con_check) {
+                const int bit = 4 >> i;  // corners of cn[i] on its low face along axis i
+                float f[4];
+                int k = 0;
 #pragma unroll
-        for (int b = 0; b < 3; ++b) {
-            const float L = n0[b] / N0 - n1[b] / N1;
-            w[b] = use_l1 ? ((L > 0.f) ? 1.f : (L == 0.f ? 0.f : -1.f)) : 2.f * L;
-        }
-        float d0[3], d1[3];
-        const float i0 = 1.f / (N0 * N0 * N0), i1 = 1.f / (N1 * N1 * N1);
-#pragma unroll
-        for (int a = 0; a < 3; ++a) {
-            float s0 = 0.f, s1 = 0.f;
-#pragma unroll
-            for (int b = 0; b < 3; ++b) {
-                s0 += w[b] * (((a == b) ? 1.f / N0 : 0.f) - n0[a] * n0[b] * i0);
-                s1 += w[b] * (((a == b) ? -1.f / N1 : 0.f) + n1[a] * n1[b] * i1);
+                for (int j = 0; j < 8; ++j)
+                    if (!(j & bit)) f[k++] = cn[i].s[j];
+                ok = !reg_all_one_side(f, 4, lv_set);
             }
-            d0[a] = s0;
-            d1[a] = s1;
+            if (ok && ignore_empty) ok = !empty0 || !reg_all_one_side(cn[i].s, 8, lv_set);
+            use[i] = ok;
+            count += ok ? 1 : 0;
         }
-        const int bit = 4 >> i;
+        if (count > 0) {
+            active = true;
+            const float N0 = sqrtf(1e-9f + n0[0] * n0[0] + n0[1] * n0[1] + n0[2] * n0[2]);  // _NORM3
+            const float sc = scale * 1.f / count;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const float g0 = ((j & 4) ? 0.25f : -0.25f) * d0[0] + ((j & 2) ? 0.25f : -0.25f) * d0[1] +
-                             ((j & 1) ? 0.25f : -0.25f) * d0[2];
-            const float v0 = sc * g0;
-            if (v0 != 0.f) {
-                acc0[j] += v0;
-                nz0[j] = true;
-            }
-            const float g1 = ((j & 4) ? 0.25f : -0.25f) * d1[0] + ((j & 2) ? 0.25f : -0.25f) * d1[1] +
-                             ((j & 1) ? 0.25f : -0.25f) * d1[2];
-            const float v1 = sc * g1;
-            if (v1 != 0.f) {
-                if (j & bit) {
-                    atomicAdd(&grad_data[cn[i].lk[j]], v1);
-                    if (mask_out != nullptr) mask_out[cn[i].lk[j]] = 1;
-                } else {
-                    acc0[j | bit] += v1;
-                    nz0[j | bit] = true;
+            for (int i = 0; i < 3; ++i) {
+                if (!use[i]) continue;
+                float n1[3];
+                reg_normal(cn[i], n1);
+                const float N1 = sqrtf(1e-9f + n1[0] * n1[0] + n1[1] * n1[1] + n1[2] * n1[2]);
+                float w[3];  // dLoss / d(L_b), L = n0/N0 - n1/N1
+#pragma unroll
+                for (int b = 0; b < 3; ++b) {
+                    const float L = n0[b] / N0 - n1[b] / N1;
+                    w[b] = use_l1 ? ((L > 0.f) ? 1.f : (L == 0.f ? 0.f : -1.f)) : 2.f * L;
+                }
+                float d0[3], d1[3];
+                const float i0 = 1.f / (N0 * N0 * N0), i1 = 1.f / (N1 * N1 * N1);
+#pragma unroll
+                for (int a = 0; a < 3; ++a) {
+                    float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+                    for (int b = 0; b < 3; ++b) {
+                        s0 += w[b] * (((a == b) ? 1.f / N0 : 0.f) - n0[a] * n0[b] * i0);
+                        s1 += w[b] * (((a == b) ? -1.f / N1 : 0.f) + n1[a] * n1[b] * i1);
+                    }
+                    d0[a] = s0;
+                    d1[a] = s1;
+                }
+                const int bit = 4 >> i;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float g0 = ((j & 4) ? 0.25f : -0.25f) * d0[0] + ((j & 2) ? 0.25f : -0.25f) * d0[1] +
+                                     ((j & 1) ? 0.25f : -0.25f) * d0[2];
+                    const float v0 = sc * g0;
+                    if (v0 != 0.f) {
+                        acc0[j] += v0;
+                        nz0 |= 1u << j;
+                    }
+                    const float g1 = ((j & 4) ? 0.25f : -0.25f) * d1[0] + ((j & 2) ? 0.25f : -0.25f) * d1[1] +
+                                     ((j & 1) ? 0.25f : -0.25f) * d1[2];
+                    const float v1 = sc * g1;
+                    if (v1 != 0.f) {
+                        if (!(j & bit)) {
+                            acc0[j | bit] += v1;
+                            nz0 |= 1u << (j | bit);
+                        } else if (i == 2) {   // (j & 1: the rows at z + 2 -- held back for the merge along z below)
+                            far_z[j >> 1] += v1;
+                            nz_far |= 1u << (j >> 1);
+                        } else {
+                            atomicAdd(&grad_data[cn[i].lk[j]], v1);
+                            if (mask_out != nullptr) mask_out[cn[i].lk[j]] = 1;
+                        }
+                    }
                 }
             }
         }
     }
+    // Merge along z.  The cells of the list mostly come as runs along z (the non-empty cells in storage order), a
+    // lane a cell: the four rows at level z of lane's cell also receive the high-face sums of the cell below (lane - 1)
+    // and the far-face sums of the cell two below (lane - 2).  Those travel across the wave and leave with the owner's
+    // atomic: 12 atomics a cell inside a run instead of 20 (the normal loss is the longest kernel of an iteration at
+    // the training script's batch size).  A lane keeps what nobody takes: the run's last cells, the wave's last lanes.
+    const int lane = (int)(threadIdx.x & 63);
+    const int cell_m1 = __shfl_up(cell, 1), cell_m2 = __shfl_up(cell, 2);
+    const int cell_p1 = __shfl_down(cell, 1), cell_p2 = __shfl_down(cell, 2);
+    const int iact = active ? 1 : 0;
+    const int act_p1 = __shfl_down(iact, 1), act_p2 = __shfl_down(iact, 2);
+    const bool recv1 = active && lane >= 1 && cell_m1 == cell - 1 && z >= 1;
+    const bool recv2 = active && lane >= 2 && cell_m2 == cell - 2 && z >= 2;
+    const bool send1 = active && lane <= 62 && cell_p1 == cell + 1 && z + 1 < G.size[2] && act_p1 != 0;
+    const bool send2 = active && lane <= 61 && cell_p2 == cell + 2 && z + 2 < G.size[2] && act_p2 != 0;
+    const unsigned nz_hi = ((nz0 >> 1) & 1u) | ((nz0 >> 2) & 2u) | ((nz0 >> 3) & 4u) | ((nz0 >> 4) & 8u);
+    const int flags = (int)(nz_hi | (nz_far << 4));
+    const int flags_m1 = __shfl_up(flags, 1), flags_m2 = __shfl_up(flags, 2);
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj) {
+        const float from_hi = __shfl_up(acc0[2 * jj + 1], 1);
+        const float from_far = __shfl_up(far_z[jj], 2);
+        if (recv1) {
+            acc0[2 * jj] += from_hi;
+            nz0 |= (unsigned)((flags_m1 >> jj) & 1) << (2 * jj);
+        }
+        if (recv2) {
+            acc0[2 * jj] += from_far;
+            nz0 |= (unsigned)((flags_m2 >> (4 + jj)) & 1) << (2 * jj);
+        }
+    }
+    if (!active) return;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-        if (nz0[j]) {
+        if (((nz0 >> j) & 1u) && (!(j & 1) || !send1)) {
             atomicAdd(&grad_data[c0.lk[j]], acc0[j]);
             if (mask_out != nullptr) mask_out[c0.lk[j]] = 1;
+        }
+    }
+    if (!send2) {
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+            if ((nz_far >> jj) & 1u) {
+                atomicAdd(&grad_data[cn[2].lk[2 * jj + 1]], far_z[jj]);
+                if (mask_out != nullptr) mask_out[cn[2].lk[2 * jj + 1]] = 1;
+            }
         }
     }
 }

@@ -1056,16 +1056,20 @@ class SparseGrid(nn.Module):
             first = (torch.rand(1, device=dev) * n_cells).long().clamp_(max=n_cells - 1)
             return (torch.arange(count, dtype=torch.int64, device=dev) + first).remainder_(n_cells).to(torch.int32)
         first = int(np.random.randint(0, n_cells))
+        if first + count <= n_cells:   # (no wrap: one kernel instead of four)
+            return torch.arange(first, first + count, dtype=torch.int32, device=dev)
         run = torch.arange(count, dtype=torch.int64, device=dev).add_(first)
         return run.remainder_(n_cells).to(torch.int32)
 
     def _get_rand_cells_non_empty(self, sparse_frac: float, frac_of_remaining: bool = True,
-                                  contiguous: bool = True):
-        """:6354-6376: the same over the cells whose first corner exists."""
+                                  contiguous: bool = True, borrow: bool = False):
+        """:6354-6376: the same over the cells whose first corner exists.  `borrow`: the caller only reads the list
+        (the regulariser kernels): it may be handed the cached tensor or a view of it instead of a copy (two copies of
+        5 MB an iteration at 256^3 otherwise)."""
         grid_size = self.links.numel()
         non_empty_ids = self._non_empty_ids()
         if sparse_frac >= 1.0:
-            return non_empty_ids.clone()  # never the cached tensor itself
+            return non_empty_ids if borrow else non_empty_ids.clone()  # never the cached tensor itself
         non_empty_num = len(non_empty_ids)
         if frac_of_remaining:
             sparse_num = int(non_empty_num * sparse_frac)
@@ -1077,7 +1081,8 @@ class SparseGrid(nn.Module):
                 start = (torch.rand(1, device=non_empty_ids.device) * span).long().clamp_(max=span - 1)
                 return non_empty_ids.index_select(0, torch.arange(sparse_num, device=non_empty_ids.device) + start)
             start = np.random.randint(0, non_empty_num - sparse_num + 1)
-            return non_empty_ids[start:start + sparse_num].clone()
+            run = non_empty_ids[start:start + sparse_num]
+            return run if borrow else run.clone()
         return non_empty_ids[torch.randint(0, non_empty_num, (sparse_num,), dtype=torch.long,
                                            device=self.links.device)]
 
@@ -1229,7 +1234,7 @@ class SparseGrid(nn.Module):
                                 ignore_edge: bool = True, edge_value: float = -1.0, contiguous: bool = True):
         """TV of the surface scalar added into `grad` (:5121-5163)."""
         assert self.surface_data.is_cuda and grad.is_cuda, "the HIP extension is required for total variation"
-        rand_cells = self._get_rand_cells_non_empty(sparse_frac, contiguous=contiguous)
+        rand_cells = self._get_rand_cells_non_empty(sparse_frac, contiguous=contiguous, borrow=True)
         if rand_cells.size(0) > 0:
             _C.surf_tv_grad_sparse(self.links, self.surface_data, self.density_data, rand_cells,
                                    self._get_sparse_grad_indexer(), 0, 1, scaling, ignore_edge, edge_value,
@@ -1245,7 +1250,7 @@ class SparseGrid(nn.Module):
         if not use_kernel:
             raise NotImplementedError("the PyTorch debugging path is not part of this build (no CPU fallback)")
         assert self.surface_data.is_cuda and grad.is_cuda, "the HIP extension is required"
-        rand_cells = self._get_rand_cells_non_empty(sparse_frac, contiguous=contiguous)
+        rand_cells = self._get_rand_cells_non_empty(sparse_frac, contiguous=contiguous, borrow=True)
         if rand_cells.size(0) > 0:
             _C.surface_normal_grad_sparse(self.links, self.surface_data, rand_cells,
                                           self._get_sparse_grad_indexer(), 0.0, 0, 1, scaling, 0.0,
@@ -1259,7 +1264,7 @@ class SparseGrid(nn.Module):
         sparse indexer alone; so does this (whatever `use_kernel` says: there is one implementation)."""
         if self.surface_data is None:
             return
-        rand_cells = self._get_rand_cells_non_empty(sparse_frac, contiguous=contiguous)
+        rand_cells = self._get_rand_cells_non_empty(sparse_frac, contiguous=contiguous, borrow=True)
         target = self._get_data_grads()["surface_data"]
         if rand_cells.size(0) == 0:
             return torch.zeros((), device=self.surface_data.device)
@@ -1277,7 +1282,7 @@ class SparseGrid(nn.Module):
         if only_trained_cells:
             rand_cells = self._get_data_to_links()[trained_cells_mask].to(self.density_data.device)
         else:
-            rand_cells = self._get_rand_cells_non_empty(sparse_frac, contiguous=contiguous)
+            rand_cells = self._get_rand_cells_non_empty(sparse_frac, contiguous=contiguous, borrow=True)
         if self.opt.alpha_activation_type == CONSTANTS["SIGMOID_FN"]:
             surf_sparse_thresh = float(np.log(surf_sparse_thresh / (1.0 - surf_sparse_thresh)))
             alpha_sparsify_bound = float(np.log(alpha_sparsify_bound / (1.0 - alpha_sparsify_bound)))

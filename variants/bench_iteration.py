@@ -1,6 +1,8 @@
 """One training iteration of opt.py with surface_cuda_syn.yaml's terms on the bench scene, through the SparseGrid
-mirror (Python overhead included): fused render of one 800x800 view (or --rays N shuffled rays), surface TV,
-normal loss, eikonal loss, alpha sparsify, the optimizer steps.  ms per iteration and rays/s."""
+mirror (Python overhead included): fused render of one 800x800 view (or --rays N shuffled rays), TV on alpha (1 % of
+the cells: lambda_tv_alpha 1e-5, tv_sparsity 0.01 -- opt.py:952-957), surface TV, normal loss, alpha sparsify, the
+optimizer steps; --eikonal adds the eikonal loss (lambda_surface_eikonal is 0 in that yaml: config_util.py:558).
+ms per iteration and rays/s."""
 import argparse, json, os, sys
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -10,6 +12,7 @@ from alphasurf_amd import synth
 ap = argparse.ArgumentParser()
 ap.add_argument("--rays", type=int, default=0, help="0: the whole 800x800 view in image order; N: N shuffled rays of it")
 ap.add_argument("--iters", type=int, default=30)
+ap.add_argument("--eikonal", action="store_true", help="also the eikonal loss (off in surface_cuda_syn.yaml)")
 ap.add_argument("--graph", action="store_true", help="capture the iteration into one HIP graph (SparseGrid.capture_iteration)")
 args = ap.parse_args()
 dev = torch.device("cuda:0")
@@ -44,11 +47,13 @@ def iteration(rays=rays, gt=gt):
                              lambda_l_entropy=F["lambda_l_entropy"], lambda_conv_mode_samp=F["lambda_conv_mode_samp"],
                              l_dist_max_sample=F["l_dist_max_sample"], l_di_alpha_thresh=F["l_di_alpha_thresh"],
                              surf_sparse_alpha_thresh=F["surf_sparse_alpha_thresh"])
+    grid.inplace_tv_grad(grid.density_data.grad, scaling=1e-5, sparse_frac=0.01, contiguous=True)
     grid.inplace_tv_surface_grad(grid.surface_data.grad, scaling=1e-3, sparse_frac=1, ignore_edge=True,
                                  edge_value=-1.0, alpha_dependency=True)
     grid.inplace_surface_normal_grad(grid.surface_data.grad, scaling=1e-6, sparse_frac=1, connectivity_check=True,
                                      ignore_empty=False, use_l1=True)
-    grid.inplace_surface_eikonal_grad(grid.surface_data.grad, scaling=1e-4, sparse_frac=1, use_kernel=False)
+    if args.eikonal:
+        grid.inplace_surface_eikonal_grad(grid.surface_data.grad, scaling=1e-4, sparse_frac=1, use_kernel=False)
     grid.inplace_alpha_surf_sparsify_grad(grid.density_data.grad, grid.surface_data.grad, scaling_alpha=1e-9,
                                           scaling_surf=0.0, sparse_frac=0.1)
     grid.optim_density_step(1e-1, beta=0.95, optim="rmsprop")
