@@ -487,7 +487,10 @@ def test_random_option_fuzz(hip, oracle):
     import fuzz_util
     seed = int(os.environ.get("ASURF_FUZZ_SEED", "2024"))
     n_draws = int(os.environ.get("ASURF_FUZZ_DRAWS", "24"))     # a longer sweep: set the two variables
+    known_edges = {(31337, 107), (424242, 109)}                  # test_fuzz_knife_edge_draw takes these apart
     for it, sc, o, d, opts, fused, gt, tag in fuzz_util.draws(seed, n_draws):
+        if (seed, it) in known_edges:
+            continue
         rgb, g = hip.render_fused(sc, o, d, opts, gt, fused)
         rgb_o, go, st = oracle.render_fused(sc, o, d, opts, gt, fused)
         assert np.abs(rgb - rgb_o).max() <= RGB_TOL_ORACLE, tag
@@ -537,15 +540,21 @@ INTERNAL_FORMS = (("default", {}), ("no filter", {"ASURF_DEBUG": "32"}), ("one-k
                   ("block-synchronous k_sweep", {"ASURF_SWEEP": "block"}), ("per-voxel occupancy pass", {"ASURF_MASKS": "row"}))
 
 
-def test_fuzz_knife_edge_draw(hip, oracle):
+@pytest.mark.parametrize("seed,draw", [(31337, 107), (424242, 109)])
+def test_fuzz_knife_edge_draw(hip, oracle, seed, draw):
     """Draw 107 of sweep seed 31337 (round 2's long sweep): one sample sits on a knife edge -- the sign test of the
     inwards-normal loss term, decided one way by the host's libm and the other way by the device's -- and ONE element
-    of grad_surface differs from the oracle by 4 % of the plane's maximum.  Kept as a case: (1) every internal form
+    of grad_surface differs from the oracle by 4 % of the plane's maximum.  (Draw 109 of seed 424242, found by round 3's
+    sweeps, is the second of its kind: three samples in one voxel whose weighted mean distance falls within an ulp
+    of the middle sample's -- the levels' spacing happens to be in the ratio that does it, 8.2 -- so that the sign in the
+    sample-distance loss, surf_trav.cu:2385-2390, is decided by the last bit of expf: five rays, 0.5 % of the plane's
+    maximum, the same in every internal form.)  Kept as cases: (1) every internal form
     of the HIP path (pipeline or one kernel, k_sweep or the stepping walk, filter on or off, replay or walking
     backward) gives the same result; (2) wherever the HIP path differs from the oracle by more than the usual bound,
-    the ORACLE itself moves by as much when its surface values are perturbed by 1e-6 relative."""
+    the ORACLE itself moves by as much when its surface values or its raw opacities are perturbed by 1e-6 relative,
+    or one of its levels by 1e-5."""
     import fuzz_util
-    (it, sc, o, d, opts, fused, gt, tag), = list(fuzz_util.draws(31337, 108, only=107))
+    (it, sc, o, d, opts, fused, gt, tag), = list(fuzz_util.draws(seed, draw + 1, only=draw))
     res = {}
     for name, switches in INTERNAL_FORMS:
         for k, v in switches.items():
@@ -564,11 +573,22 @@ def test_fuzz_knife_edge_draw(hip, oracle):
     assert (g["mask"].astype(bool) == go["mask"].astype(bool)).all()
     # the oracle's own sensitivity, element by element
     moved = {k: np.zeros_like(go[k]) for k in ("sh", "density", "surface")}
-    for eps in (1e-6, -1e-6):
-        sc2 = dict(sc, surface=(sc["surface"].astype(np.float64) * (1.0 + eps)).astype(np.float32))
-        _, go2, _ = oracle.render_fused(sc2, o, d, opts, gt, fused)
-        for k in moved:
-            moved[k] = np.maximum(moved[k], np.abs(go2[k] - go[k]))
+    for plane in ("surface", "density"):   # (a gate on the surface: a root, a normal's sign; on the opacity: an alpha threshold)
+        for eps in (1e-6, -1e-6):
+            sc2 = dict(sc)
+            sc2[plane] = (sc[plane].astype(np.float64) * (1.0 + eps)).astype(np.float32)
+            _, go2, _ = oracle.render_fused(sc2, o, d, opts, gt, fused)
+            for k in moved:
+                moved[k] = np.maximum(moved[k], np.abs(go2[k] - go[k]))
+    # (... on where the samples lie relative to one another -- sign(mean t - t_i) of the sample-distance loss,
+    # surf_trav.cu:2385-2390 --: the levels, one at a time)
+    for li in range(len(sc["level_set"])):
+        for eps in (1e-5, -1e-5):
+            lv = np.array(sc["level_set"], np.float32).copy()
+            lv[li] += eps
+            _, go2, _ = oracle.render_fused(dict(sc, level_set=lv), o, d, opts, gt, fused)
+            for k in moved:
+                moved[k] = np.maximum(moved[k], np.abs(go2[k] - go[k]))
     edge_rows = set()
     for k in ("sh", "density", "surface"):
         scale = float(np.abs(go[k]).max())
