@@ -61,6 +61,8 @@ struct Config {
     int no_split_bwd = 0;  // ASURF_NO_SPLIT_BWD: the one-kernel replay
     int eval_walk = 0;     // ASURF_EVAL=walk: the stepping evaluation renders
     int timeline = 0;      // ASURF_TIMELINE = kernel id (instrumented build)
+    int masks_single = 0;  // ASURF_MASKS=single / split: the full occupancy pass as one kernel / in three steps whatever
+    int masks_split = 0;   // ... the grid's size (tests; by default grids of kMaskSplitRows rows and more are split)
     int side_stream = 0;   // ASURF_SIDE_STREAM: the fused call's fallback kernels on a stream of their own (measured: slower)
     int order_radix = 0;   // ASURF_ORDER=radix: the ray ordering through rocPRIM's radix sort instead of the strip sort
     int masks_row = 0;     // ASURF_MASKS=row: the one-pass occupancy kernel (k_build_masks) instead of the two stages
@@ -91,7 +93,11 @@ bool config_assign(Config& c, const char* name, const char* value) {
     else if (!strcmp(name, "ASURF_TIMELINE")) c.timeline = n;
     else if (!strcmp(name, "ASURF_SIDE_STREAM")) c.side_stream = n ? 1 : 0;
     else if (!strcmp(name, "ASURF_ORDER")) c.order_radix = (value && !strcmp(value, "radix")) ? 1 : 0;
-    else if (!strcmp(name, "ASURF_MASKS")) c.masks_row = (value && !strcmp(value, "row")) ? 1 : 0;
+    else if (!strcmp(name, "ASURF_MASKS")) {
+        c.masks_row = (value && !strcmp(value, "row")) ? 1 : 0;
+        c.masks_single = (value && !strcmp(value, "single")) ? 1 : 0;
+        c.masks_split = (value && !strcmp(value, "split")) ? 1 : 0;
+    }
     else if (!strcmp(name, "ASURF_SWEEP")) c.sweep_block = (value && !strcmp(value, "block")) ? 1 : 0;
     else if (!strcmp(name, "ASURF_SWEEP_WPB")) c.sweep_wpb = (n == 1 || n == 2 || n == 4) ? n : 0;
     else if (!strcmp(name, "ASURF_SWEEP_RPW")) c.sweep_rpw = (n == 2 || n == 4 || n == 8 || n == 16) ? n : 0;
@@ -154,6 +160,7 @@ constexpr long long kOrderMinRays = 65536;
 // asks asurf_workspace_bytes_rec() for a deeper one, and every call takes the deepest of kRecDepths that the workspace
 // it is handed holds -- a function of the buffer's size alone, so a buffer has one layout.
 constexpr int kRecDepth = 32;
+constexpr int kMaskSplitRows = 16384;   // rows of 8 bricks from which the full occupancy pass is split (512^3: 32 768)
 constexpr int kRecDepths[] = {128, 64, 32};
 static_assert(kRecDepths[0] <= (1 << (32 - kRecRayBits)), "a record's number fits above the ray's in a list cell");
 
@@ -669,6 +676,30 @@ int prepare(const asurf_grid* grid, const asurf_rays* rays, const asurf_render_o
     } else {
         // a full pass rewrites every plane: whatever the header said is void from here on, on this call and on every
         // replay of a graph this call is captured into (the memset is a node of that graph)
+        // Large grids take the pass in three steps (asurf_masks2.h, k_rows_alive): the planes, the header and the
+        // counters lie one after the other and are cleared together; the rows that hold a vertex are listed; the
+        // vertex-plane kernel takes the listed rows.
+        const bool split = fast && (L.ML.n_rows >= kMaskSplitRows || config().masks_split) && (grid->size[2] & 3) == 0 &&
+                           (reinterpret_cast<uintptr_t>(grid->links) & 15) == 0 && !config().masks_single;
+        if (split) {
+            const size_t all = (L.ML.off_mask_hdr - L.ML.off_fine_work) + hdr_and_counters;
+            if (hipMemsetAsync(L.ws + L.ML.off_fine_work, 0, all, L.stream) != hipSuccess)
+                return fail(ASURF_E_LAUNCH, "hipMemsetAsync(occupancy planes) failed");
+            hipLaunchKernelGGL(k_rows_alive, dim3((unsigned)((L.ML.n_rows + 3) / 4)), dim3(256), 0, L.stream, L.g, nzg,
+                               L.ML.n_rows, hdr, live_rows);
+            const bool leave = cached == 0 && epoch != 0ull;
+            const MaskRows R{hdr, live_rows, epoch, L.ML.n_rows, 2};
+            hipLaunchKernelGGL(k_build_masks2, dim3((unsigned)std::min(L.ML.n_rows, 8192)), dim3(512), 0, L.stream, L.g,
+                               opt->sigma_thresh, need_surf ? 1 : 0, n_sets, fw, fl, cw, cl,
+                               (leave || L.sweep) ? fy : nullptr, (leave || L.sweep) ? fz : nullptr, use_live ? 1 : 0, nzg, R,
+                               static_cast<MaskHdr*>(nullptr), static_cast<int*>(nullptr), static_cast<int*>(nullptr), 0);
+            if (leave) {
+                hipLaunchKernelGGL(k_mask_seal, dim3(1), dim3(1), 0, L.stream, hdr, epoch);
+                mask_cache_store(workspace, epoch, grid, &hdr->n_live, L.stream);
+            }
+            prof_after("k_build_masks2", 0, L.stream);
+            return launch_error("k_build_masks");
+        }
         if (hipMemsetAsync(hdr, 0, hdr_and_counters, L.stream) != hipSuccess)
             return fail(ASURF_E_LAUNCH, "hipMemsetAsync(mask header, pipeline counters) failed");
         // first call with this value: the full pass leaves the list (and zeros in EVERY plane of the empty rows: the

@@ -507,9 +507,11 @@ def test_vertex_plane_occupancy_pass_equals_per_voxel_pass(hip, optname):
     """The occupancy pyramid built in bit arithmetic on vertex bit planes (asurf_masks2.h) against the
     per-voxel kernel (ASURF_MASKS=row): the same planes, so the same picture, gradients and masks bit for bit -- one and
     three level sets, a non-cubic crop whose sizes are no multiples of 8 or 64, the `live` plane (fake_all), the
-    density gate."""
+    density gate; and the full pass in three steps (ASURF_MASKS=split: the planes cleared, the rows that hold a vertex
+    listed, the listed rows built -- what grids of 512^3 and more take by default; it needs a z size that is a multiple
+    of 4, the crop (45, 61, 68) has one, (45, 61, 70) makes it fall back)."""
     from alphasurf_amd import synth
-    for lv, crop in (((0.0,), None), ((-0.3, 0.0, 0.4), None), ((0.0,), (45, 61, 70))):
+    for lv, crop in (((0.0,), None), ((-0.3, 0.0, 0.4), None), ((0.0,), (45, 61, 70)), ((0.0, 0.3), (45, 61, 68))):
         sc = synth.make_sparse_scene(72, 4, seed=9, level_set=lv, trunc_a=3.0, fake_sample_std=0.8)
         if crop is not None:
             links = np.ascontiguousarray(sc["links"][:crop[0], :crop[1], :crop[2]])
@@ -518,26 +520,28 @@ def test_vertex_plane_occupancy_pass_equals_per_voxel_pass(hip, optname):
         gt = np.random.RandomState(3).rand(o.shape[0], 3).astype(np.float32)
         fused = dict(lambda_l2=1.0, lambda_l_entropy=1e-4)
         res = []
-        for form in (None, "row"):
+        for form in (None, "row", "split"):
             _asurf_lib.config_set("ASURF_MASKS", form)
             res.append(hip.render_fused(sc, o, d, OPTION_SETS[optname], gt, fused))
         _asurf_lib.config_set("ASURF_MASKS", None)
-        (rgb_a, g_a), (rgb_b, g_b) = res
-        if optname == "fake_all":
-            # every voxel of the shell is a work voxel here: rays overflow their tables, and WHICH rays the spill list
-            # turns away (to the one-kernel path, which sums a ray's colours in another order) depends on timing
-            assert np.abs(rgb_a - rgb_b).max() <= 2.5e-7, (optname, lv, crop)
-        else:
-            assert np.array_equal(rgb_a, rgb_b), (optname, lv, crop)
-        assert (g_a["mask"] == g_b["mask"]).all()
-        for k in ("sh", "density", "surface"):
-            grad_close(g_a[k], g_b[k], 1e-5, f"{optname} {lv} {crop} grad_{k}")
+        rgb_a, g_a = res[0]
+        for form, (rgb_b, g_b) in zip(("row", "split"), res[1:]):
+            if optname == "fake_all":
+                # every voxel of the shell is a work voxel here: rays overflow their tables, and WHICH rays the spill list
+                # turns away (to the one-kernel path, which sums a ray's colours in another order) depends on timing
+                assert np.abs(rgb_a - rgb_b).max() <= 2.5e-7, (optname, lv, crop, form)
+            else:
+                assert np.array_equal(rgb_a, rgb_b), (optname, lv, crop, form)
+            assert (g_a["mask"] == g_b["mask"]).all(), form
+            for k in ("sh", "density", "surface"):
+                grad_close(g_a[k], g_b[k], 1e-5, f"{optname} {lv} {crop} {form} grad_{k}")
 
 
 INTERNAL_FORMS = (("default", {}), ("no filter", {"ASURF_DEBUG": "32"}), ("one-kernel replay", {"ASURF_NO_SPLIT_BWD": "1"}),
                   ("walking backward", {"ASURF_NO_REPLAY": "1"}), ("one-kernel forward", {"ASURF_NO_PIPELINE": "1"}),
                   ("k_walk", {"ASURF_WALK": "step"}), ("fallbacks on a side stream", {"ASURF_SIDE_STREAM": "1"}),
-                  ("block-synchronous k_sweep", {"ASURF_SWEEP": "block"}), ("per-voxel occupancy pass", {"ASURF_MASKS": "row"}))
+                  ("block-synchronous k_sweep", {"ASURF_SWEEP": "block"}), ("per-voxel occupancy pass", {"ASURF_MASKS": "row"}),
+                  ("occupancy pass in three steps", {"ASURF_MASKS": "split"}))
 
 
 @pytest.mark.parametrize("seed,draw", [(31337, 107), (424242, 109)])

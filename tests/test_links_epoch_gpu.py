@@ -8,9 +8,15 @@ from test_hip_parity import OPTION_SETS, hip, sparse_case  # noqa: F401
 pytestmark = pytest.mark.gpu
 
 
-def test_epoch_pass_equals_full_pass(hip):
+@pytest.mark.parametrize("full_pass", [None, "split"])
+def test_epoch_pass_equals_full_pass(hip, full_pass):
+    """(full_pass "split": the full pass in three steps -- memset, k_rows_alive, the listed rows -- leaves the list that
+    the later calls use; grids of 512^3 and more take it by default)"""
     import hip_util as H
+    from alphasurf_amd import lib as _asurf_lib
+    _asurf_lib.config_set("ASURF_MASKS", full_pass)
     sc, o, d = sparse_case(9, level_set=(0.0,), trunc_a=4.0)
+    assert sc["links"].shape[2] % 4 == 0
     gt = np.random.RandomState(4).rand(o.shape[0], 3).astype(np.float32)
     fused = dict(lambda_l2=1.0, lambda_l_entropy=1e-4)
     ref_rgb, ref_g = H.render_fused(sc, o, d, OPTION_SETS["syn_yaml"], gt, fused)
@@ -28,8 +34,11 @@ def test_epoch_pass_equals_full_pass(hip):
             np.testing.assert_allclose(g[k], ref_g[k], rtol=1e-4, atol=1e-6 * max(1.0, float(np.abs(ref_g[k]).max())))
 
 
-def test_links_change_is_seen(hip):
+@pytest.mark.parametrize("full_pass", [None, "split"])
+def test_links_change_is_seen(hip, full_pass):
     import hip_util as H
+    from alphasurf_amd import lib as _asurf_lib
+    _asurf_lib.config_set("ASURF_MASKS", full_pass)
     sc, o, d = sparse_case(4, level_set=(0.0,))
     gt = np.random.RandomState(4).rand(o.shape[0], 3).astype(np.float32)
     fused = dict(lambda_l2=1.0)
