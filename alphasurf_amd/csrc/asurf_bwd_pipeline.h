@@ -480,7 +480,11 @@ __device__ __forceinline__ void acc8(float* dst, const float* w) {
 }
 
 // ------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(kBlock)
+// (2 / 3 / 4 waves a SIMD -- 188 registers / 168 and 12 bytes of scratch / 128 and 172 bytes: 0.1105 / 0.1077 / 0.1197 ms)
+#ifndef ASURF_BGEO_WAVES
+#define ASURF_BGEO_WAVES 3
+#endif
+__global__ void __launch_bounds__(kBlock, ASURF_BGEO_WAVES)
 k_bwd_geo(KGrid g, KOpt o, KLoss L, KGrads G, const float* __restrict__ origins,
           const float* __restrict__ dirs, long long Q, SampleRec S) {
     const TlScope tl(7);
