@@ -1616,16 +1616,30 @@ int asurf_rows_pack(const int32_t* rows, int64_t n_list, int32_t sh_dim, const f
     return launch_error("rows_pack");
 }
 
-int asurf_rows_unpack(const int32_t* rows, int64_t n_list, int32_t sh_dim, const float* packed, float* grad_sh,
-                      float* grad_density, float* grad_surface, uint8_t* mask, void* stream) {
+static int rows_unpack_impl(bool add, const int32_t* rows, int64_t n_list, int32_t sh_dim, const float* packed,
+                            float* grad_sh, float* grad_density, float* grad_surface, uint8_t* mask, void* stream) {
     if (n_list < 0 || sh_dim <= 0) return fail(ASURF_E_INVALID, "rows_unpack: bad shape");
     if (n_list == 0) return 0;
     if (!rows || !grad_sh || !grad_density || !packed) return fail(ASURF_E_INVALID, "rows_unpack: NULL tensor");
     const long long total = (long long)n_list * (sh_dim + 2);
     const unsigned blocks = (unsigned)std::min<long long>((total + 255) / 256, 256 * 32);
-    hipLaunchKernelGGL(k_rows_unpack, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(stream), rows, (long long)n_list,
-                       sh_dim, packed, grad_sh, grad_density, grad_surface, mask);
+    if (add)
+        hipLaunchKernelGGL(k_rows_unpack<true>, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(stream), rows,
+                           (long long)n_list, sh_dim, packed, grad_sh, grad_density, grad_surface, mask);
+    else
+        hipLaunchKernelGGL(k_rows_unpack<false>, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(stream), rows,
+                           (long long)n_list, sh_dim, packed, grad_sh, grad_density, grad_surface, mask);
     return launch_error("rows_unpack");
+}
+
+int asurf_rows_unpack(const int32_t* rows, int64_t n_list, int32_t sh_dim, const float* packed, float* grad_sh,
+                      float* grad_density, float* grad_surface, uint8_t* mask, void* stream) {
+    return rows_unpack_impl(false, rows, n_list, sh_dim, packed, grad_sh, grad_density, grad_surface, mask, stream);
+}
+
+int asurf_rows_unpack_add(const int32_t* rows, int64_t n_list, int32_t sh_dim, const float* packed, float* grad_sh,
+                          float* grad_density, float* grad_surface, uint8_t* mask, void* stream) {
+    return rows_unpack_impl(true, rows, n_list, sh_dim, packed, grad_sh, grad_density, grad_surface, mask, stream);
 }
 
 int asurf_profile_enable(int on) {

@@ -102,6 +102,8 @@ k_rows_pack(const int* __restrict__ rows, long long n_list, int D, const float* 
     }
 }
 
+// ADD: the sums are added to what the buffers hold (a second partial batch of the same step, dist.PipelinedReduce)
+template <bool ADD>
 __global__ void __launch_bounds__(256)
 k_rows_unpack(const int* __restrict__ rows, long long n_list, int D, const float* __restrict__ packed,
               float* __restrict__ grad_sh, float* __restrict__ grad_density, float* __restrict__ grad_surface,
@@ -113,11 +115,11 @@ k_rows_unpack(const int* __restrict__ rows, long long n_list, int D, const float
         const int c = (int)(t - u * W);
         const long long row = rows[u];
         const float v = packed[t];
-        if (c < D) grad_sh[row * D + c] = v;
+        if (c < D) grad_sh[row * D + c] = ADD ? grad_sh[row * D + c] + v : v;
         else if (c == D) {
-            grad_density[row] = v;
+            grad_density[row] = ADD ? grad_density[row] + v : v;
             if (mask) mask[row] = 1;
-        } else if (grad_surface) grad_surface[row] = v;
+        } else if (grad_surface) grad_surface[row] = ADD ? grad_surface[row] + v : v;
     }
 }
 

@@ -391,12 +391,14 @@ def rows_pack(rows, n_list, grad_sh, grad_density, grad_surface, out):
                                           _ptr(grad_surface), _ptr(out), _stream(dev)))
 
 
-def rows_unpack(rows, n_list, packed, grad_sh, grad_density, grad_surface, mask):
+def rows_unpack(rows, n_list, packed, grad_sh, grad_density, grad_surface, mask, add=False):
+    """`add`: the sums are added to what the buffers hold (asurf_rows_unpack_add)."""
     dev = grad_sh.device
     m8 = None if mask is None else (mask.view(torch.uint8) if mask.dtype == torch.bool else mask)
+    fn = _L.lib().asurf_rows_unpack_add if add else _L.lib().asurf_rows_unpack
     with torch.cuda.device(dev):
-        _L.check(_L.lib().asurf_rows_unpack(_ptr(rows), int(n_list), int(grad_sh.shape[1]), _ptr(packed), _ptr(grad_sh),
-                                            _ptr(grad_density), _ptr(grad_surface), _ptr(m8), _stream(dev)))
+        _L.check(fn(_ptr(rows), int(n_list), int(grad_sh.shape[1]), _ptr(packed), _ptr(grad_sh),
+                    _ptr(grad_density), _ptr(grad_surface), _ptr(m8), _stream(dev)))
 
 
 def _pack_ray_vox(rv):

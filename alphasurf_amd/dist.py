@@ -156,6 +156,136 @@ class GradArena:
                                  extra=self.grad_fake_sample_std, dense_above=DENSE_ABOVE if mode == "auto" else None)
 
 
+def _pack_rows(rows, U, grad_sh, grad_density, grad_surface, packed):
+    if grad_sh.is_cuda:
+        from . import csrc_api as _C
+        _C.rows_pack(rows, U, grad_sh, grad_density, grad_surface, packed)
+    elif U:
+        D = grad_sh.shape[1]
+        idx = rows[:U].long()
+        body = packed[:U * (D + 2)].view(U, D + 2)
+        body[:, :D] = grad_sh[idx]
+        body[:, D] = grad_density.view(-1)[idx]
+        body[:, D + 1] = grad_surface.view(-1)[idx] if grad_surface is not None else 0.0
+
+
+def _unpack_rows(rows, U, packed, grad_sh, grad_density, grad_surface, mask, add=False):
+    if grad_sh.is_cuda:
+        from . import csrc_api as _C
+        _C.rows_unpack(rows, U, packed, grad_sh, grad_density, grad_surface, mask, add=add)
+    elif U:
+        D = grad_sh.shape[1]
+        idx = rows[:U].long()
+        body = packed[:U * (D + 2)].view(U, D + 2)
+        if add:
+            grad_sh[idx] += body[:, :D]
+            grad_density.view(-1)[idx] += body[:, D]
+            if grad_surface is not None:
+                grad_surface.view(-1)[idx] += body[:, D + 1]
+        else:
+            grad_sh[idx] = body[:, :D]
+            grad_density.view(-1)[idx] = body[:, D]
+            if grad_surface is not None:
+                grad_surface.view(-1)[idx] = body[:, D + 1]
+        if mask is not None:
+            mask.view(-1)[idx] = True if mask.dtype == torch.bool else 1
+
+
+class PipelinedReduce:
+    """The exchange of a step taken in PARTS, each part's rows travelling under the render of the next part.
+
+    Nothing inside ONE fused call can overlap its exchange: the touched-row mask is complete only when the call's last
+    kernel ends.  But a rank's batch may be rendered as two (or more) partial batches -- e.g. the upper and the lower
+    half of its view, each with the global ray count in the loss normaliser, each into an arena of its own:
+
+        px = PipelinedReduce(device)
+        render(part_0 -> arena_0); px.submit(arena_0)     # queues the union-mask exchange of part 0 on a side stream
+        render(part_1 -> arena_1)                         # queued at once: the device goes on rendering
+        px.progress()                                     # host: reads part 0's row count, packs, starts its all-reduce
+        px.submit(arena_1)
+        px.finish(arena_0)                                # arena_0 <- sum over ranks and parts; its mask <- the union
+
+    so that part 0's all-reduce runs while part 1 renders, and only the last part's exchange is exposed.  The parts'
+    gradients must not share buffers (part 1's atomics would race with part 0's pack).  Every rank issues the same
+    collectives in the same order (mask 0, rows 0, mask 1, rows 1).  With gloo (tests, rehearsals; CPU tensors too) the
+    collectives are synchronous host round trips: same results, no overlap."""
+
+    def __init__(self, device, group=None):
+        self.device, self.group = torch.device(device), group
+        self.side = torch.cuda.Stream(self.device) if self.device.type == "cuda" else None
+        self.parts = []
+
+    def _on_side(self):
+        import contextlib
+        return torch.cuda.stream(self.side) if self.side is not None else contextlib.nullcontext()
+
+    def submit(self, arena):
+        """After the part's render has been queued on the current stream: its mask -> union over the ranks -> ordered
+        row list, all on the side stream; the list's length travels to pinned host memory.  Does not block."""
+        if _world(self.group) == 1:
+            self.parts.append(dict(arena=arena, single=True))
+            return
+        if self.side is None:      # CPU tensors: everything at once
+            rows, U = _union_rows(arena.mask, self.group)
+            self.parts.append(dict(arena=arena, rows=rows, U=U))
+            return
+        from . import csrc_api as _C
+        done = torch.cuda.Event()
+        done.record(torch.cuda.current_stream(self.device))
+        with self._on_side():
+            self.side.wait_event(done)
+            _reduce(arena.mask.view(torch.uint8), dist.ReduceOp.MAX, self.group)
+            rows, count = _C.rows_list(arena.mask)
+            host = torch.empty(1, dtype=torch.int32, pin_memory=True)
+            host.copy_(count, non_blocking=True)
+            known = torch.cuda.Event()
+            known.record(self.side)
+        self.parts.append(dict(arena=arena, rows=rows, count=count, host=host, known=known))
+
+    def progress(self):
+        """Host side of every submitted part that has not been packed yet: wait for its row count (the side stream
+        only), pack its rows, start their all-reduce.  Call it after the NEXT part's render has been queued."""
+        for p in self.parts:
+            if p.get("single") or "packed" in p:
+                continue
+            if "U" not in p:
+                p["known"].synchronize()
+                p["U"] = int(p["host"][0])
+            U, a = p["U"], p["arena"]
+            W = a.grad_sh.shape[1] + 2
+            with self._on_side():
+                packed = torch.empty(U * W + 1, dtype=a.grad_sh.dtype, device=a.grad_sh.device)
+                _pack_rows(p["rows"], U, a.grad_sh, a.grad_density, a.grad_surface, packed)
+                packed[U * W:].copy_(a.grad_fake_sample_std.view(-1))
+                _reduce(packed, dist.ReduceOp.SUM, self.group)
+            p.update(W=W, packed=packed)
+
+    def finish(self, into):
+        """All parts in: `into` (the first part's arena) receives the sums over ranks and parts, its mask the union of
+        the parts' unions.  The current stream waits for the side stream."""
+        self.progress()
+        parts, self.parts = self.parts, []
+        if parts and parts[0].get("single"):          # one rank: the parts' sums, no exchange
+            for p in parts:
+                if p["arena"] is not into:
+                    into.flat.add_(p["arena"].flat)
+                    into.mask.logical_or_(p["arena"].mask)
+            return "single"
+        assert parts and parts[0]["arena"] is into, "finish(into): `into` is the first part's arena"
+        with self._on_side():
+            std = None
+            for i, p in enumerate(parts):
+                U, W = p["U"], p["W"]
+                _unpack_rows(p["rows"], U, p["packed"], into.grad_sh, into.grad_density, into.grad_surface, into.mask,
+                             add=i > 0)
+                tail = p["packed"][U * W:]
+                std = tail.clone() if std is None else std.add_(tail)
+            into.grad_fake_sample_std.view(-1).copy_(std)
+        if self.side is not None:
+            torch.cuda.current_stream(self.device).wait_stream(self.side)
+        return "pipelined"
+
+
 def all_reduce_grads(grad_sh, grad_density, grad_surface, mask, grad_fake_sample_std=None,
                      group=None, dense_threshold=DENSE_ABOVE, mode="auto"):
     """Sum the sparse gradient buffers of a fused render across ranks.

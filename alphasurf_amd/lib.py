@@ -104,7 +104,7 @@ EXPORTS = [
     "asurf_volume_render_cuvol", "asurf_volume_render_cuvol_backward", "asurf_volume_render_cuvol_fused",
     "asurf_grid_weight_render", "asurf_sparse_grid_weight_render", "asurf_render_eval_cuvol",
     "asurf_ray_order_tmp_bytes", "asurf_ray_order", "asurf_test_quotient",
-    "asurf_rows_list_tmp_bytes", "asurf_rows_list", "asurf_rows_pack", "asurf_rows_unpack",
+    "asurf_rows_list_tmp_bytes", "asurf_rows_list", "asurf_rows_pack", "asurf_rows_unpack", "asurf_rows_unpack_add",
 ]
 
 _lib = None
@@ -182,6 +182,7 @@ def lib():
         L.asurf_rows_list.argtypes = [vp, C.c_int64, vp, vp, vp, C.c_size_t, vp]
         L.asurf_rows_pack.argtypes = [vp, C.c_int64, C.c_int32, vp, vp, vp, vp, vp]
         L.asurf_rows_unpack.argtypes = [vp, C.c_int64, C.c_int32, vp, vp, vp, vp, vp, vp]
+        L.asurf_rows_unpack_add.argtypes = [vp, C.c_int64, C.c_int32, vp, vp, vp, vp, vp, vp]
         if L.asurf_abi_version() != 3:
             raise RuntimeError("libasurf_hip.so ABI version mismatch")
         _lib = L

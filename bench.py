@@ -13,6 +13,7 @@ all-reduced over RCCL inside the timed step: weak scaling, value = total rays / 
 Rank 0 prints ONE JSON line.
 """
 import argparse
+import itertools
 import json
 import os
 import sys
@@ -57,8 +58,11 @@ def parse():
     ap.add_argument("--graph", action="store_true",
                     help="capture one step in a HIP graph after the warm-up and replay it in the timed region")
     ap.add_argument("--cpu-rays", type=int, default=40000)
-    ap.add_argument("--exchange", default="auto", choices=["dense", "sparse", "auto"],
-                    help="gradient exchange for --gpus > 1 (alphasurf_amd/dist.py)")
+    ap.add_argument("--exchange", default="pipelined", choices=["dense", "sparse", "auto", "pipelined"],
+                    help="gradient exchange for --gpus > 1 (alphasurf_amd/dist.py).  pipelined: the rank's view is rendered as "
+                         "two half batches, the first half's touched rows are exchanged while the second half renders "
+                         "(dist.PipelinedReduce); the others exchange after the whole view: one ring all-reduce of all "
+                         "buffers (dense), of the union of the touched rows (sparse), or whichever moves fewer bytes (auto)")
     return ap.parse_args()
 
 
@@ -311,7 +315,48 @@ def main():
         if args.sort:
             rgb_user[perm] = rgb
 
+    # --exchange pipelined: the two half batches, an arena of its own for the second one (the first half's rows are being
+    # packed while the second half's atomics run), a value of links_epoch that changes every step -- the first half's
+    # occupancy pass is the full one, the second half's is told that `links` has not changed SINCE THE FIRST HALF
+    pipelined = world > 1 and args.exchange == "pipelined" and not args.sort
+    if pipelined:
+        h = Q // 2
+        halves = []
+        for lo, hi in ((0, h), (h, Q)):
+            rh = _C.RaysSpec()
+            rh.origins, rh.dirs, rh.masks = r.origins[lo:hi], r.dirs[lo:hi], r.masks[lo:hi]
+            halves.append((rh, gt[lo:hi], rgb[lo:hi]))
+        arena_b = adist.GradArena(g.density_data.shape[0], g.sh_data.shape[1], dev)
+        gr_b = _C.GridOutputGrads()
+        gr_b.grad_density_out, gr_b.grad_sh_out, gr_b.grad_surface_out = arena_b.grad_density, arena_b.grad_sh, arena_b.grad_surface
+        gr_b.mask_out = arena_b.mask
+        px = adist.PipelinedReduce(dev)
+        step_epochs = itertools.count(1000)
+
+    def _render(rays, target, out, grads, counters=None):
+        _C.volume_render_surf_trav_fused(
+            g, rays, opt, target, 0.0, 0.0, 0.0, True, False, F["lambda_l2"], F["lambda_l1"], 0.0,
+            F["lambda_l_entropy"], False, 0.0, 0.0, 0.0, 0.0, F["l_di_alpha_thresh"],
+            F["surf_sparse_alpha_thresh"], 0.0, 0.0, F["lambda_conv_mode_samp"], M, out, grads,
+            global_n_rays=Q_global, counters=counters, order_rays=args.order_rays)
+
+    def _step_pipelined():
+        arena.zero_()
+        arena_b.zero_()
+        if not args.links_epoch:
+            g.links_epoch = next(step_epochs)
+        _render(halves[0][0], halves[0][1], halves[0][2], gr)
+        px.submit(arena)
+        _render(halves[1][0], halves[1][1], halves[1][2], gr_b)
+        px.progress()          # (the second half is queued: the host may wait for the first half's row count now)
+        px.submit(arena_b)
+        px.finish(arena)
+        if not args.links_epoch:
+            g.links_epoch = 0
+
     def _step(counters=None, exchange=True):
+        if pipelined and exchange and counters is None:
+            return _step_pipelined()
         if world > 1:
             # the exchange sums whatever the buffers hold, so they must hold this step only
             # (in training the optimizer kernels zero them, optim_kernel.cu:24)
@@ -327,13 +372,24 @@ def main():
             # data-parallel exchange: sum of per-shard gradients == gradient of the global batch (alphasurf_amd/dist.py:
             # "dense" = one ring all-reduce of the whole arena, "sparse" = the rows of the union of the ranks' masks
             # only, "auto" = sparse unless the union exceeds half of the rows)
-            arena.all_reduce(mode=args.exchange)
+            arena.all_reduce(mode="auto" if args.exchange == "pipelined" else args.exchange)
 
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
+    if pipelined:
+        # (the pipelined exchange has run over gloo only -- tests/test_dist_gpu.py --: should its first step raise on this
+        # stack, every rank raises alike and the run goes on with the exchange after the whole view)
+        try:
+            step()
+            torch.cuda.synchronize()
+        except Exception as e:  # noqa: BLE001
+            print(f"bench.py: rank {rank}: pipelined exchange failed ({e!r}); falling back to --exchange auto", file=sys.stderr)
+            pipelined = False
+            args.exchange = "auto"
+            g.links_epoch = 1 if args.links_epoch else 0
     for _ in range(args.warmup):
         step()
     barrier()

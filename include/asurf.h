@@ -462,7 +462,9 @@ int asurf_profile_read_spans(char* names, size_t names_cap, float* ms, int max_s
  *   asurf_rows_list   the rows the mask names, in increasing order (the same list on every rank: no atomics), their
  *                     number in count_out[0] on the device; tmp: asurf_rows_list_tmp_bytes(n_rows);
  *   asurf_rows_pack   packed[u] = grad_sh[rows[u]] | grad_density[rows[u]] | grad_surface[rows[u]]  (sh_dim + 2 floats);
- *   asurf_rows_unpack the inverse after the all-reduce of `packed`; sets mask[rows[u]] = 1 (mask may be NULL). */
+ *   asurf_rows_unpack the inverse after the all-reduce of `packed`; sets mask[rows[u]] = 1 (mask may be NULL);
+ *   asurf_rows_unpack_add  the same, ADDING the sums to what the buffers hold: the second (third ...) partial batch of a
+ *                     step whose batch is exchanged in parts under the render of the next part (dist.PipelinedReduce). */
 size_t asurf_rows_list_tmp_bytes(int64_t n_rows);
 int asurf_rows_list(const uint8_t* mask, int64_t n_rows, int32_t* rows_out, int32_t* count_out, void* tmp, size_t tmp_bytes,
                     void* stream);
@@ -470,6 +472,8 @@ int asurf_rows_pack(const int32_t* rows, int64_t n_list, int32_t sh_dim, const f
                     const float* grad_surface, float* packed, void* stream);
 int asurf_rows_unpack(const int32_t* rows, int64_t n_list, int32_t sh_dim, const float* packed, float* grad_sh,
                       float* grad_density, float* grad_surface, uint8_t* mask, void* stream);
+int asurf_rows_unpack_add(const int32_t* rows, int64_t n_list, int32_t sh_dim, const float* packed, float* grad_sh,
+                          float* grad_density, float* grad_surface, uint8_t* mask, void* stream);
 
 /* Internal switches (no reference counterpart).  Each selects between internal forms that compute the same results
  * -- the parity tests compare the forms with each other: ASURF_DEBUG (8: per-voxel stepping walk, 16: print the

@@ -64,6 +64,26 @@ def main():
                 scale = max(float(b.abs().max()), 1e-30)
                 case[name] = float((a - b).abs().max()) / scale
             res["cases"][mode] = case
+        # the step taken in two parts, the first part's rows exchanged "under" the second part's render
+        # (dist.PipelinedReduce; over gloo the collectives are synchronous, the arithmetic is the same)
+        mid = (lo + hi) // 2
+        px = adist.PipelinedReduce(dev)
+        a0, a1 = adist.GradArena(n, D, dev), adist.GradArena(n, D, dev)
+        rgb0 = render(lo, mid, a0)
+        px.submit(a0)
+        rgb1 = render(mid, hi, a1)
+        px.progress()
+        px.submit(a1)
+        used = px.finish(a0)
+        torch.cuda.synchronize()
+        rgb = torch.cat([rgb0, rgb1])
+        case = dict(used=used, rgb_equal=bool(torch.equal(rgb, rgb_ref[lo:hi])),
+                    masks_equal=bool(torch.equal(a0.mask, ref.mask)), touched=float(ref.mask.float().mean()))
+        for name in ("grad_sh", "grad_density", "grad_surface", "grad_fake_sample_std"):
+            a, b = getattr(a0, name), getattr(ref, name)
+            scale = max(float(b.abs().max()), 1e-30)
+            case[name] = float((a - b).abs().max()) / scale
+        res["cases"]["pipelined"] = case
         res["ok"] = True
     except Exception as e:  # noqa: BLE001 -- reported to the test
         import traceback

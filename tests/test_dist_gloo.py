@@ -42,6 +42,31 @@ def _worker(rank, world, port, mode, frac, n, d, out):
         t_sh, t_de, t_su = torch.from_numpy(g_sh), torch.from_numpy(g_de), torch.from_numpy(g_su)
         t_m = torch.from_numpy(mask.copy())
         t_std = torch.tensor([[float(rank + 1)]])
+        if mode == "pipelined":   # the step in two parts (dist.PipelinedReduce): each part a shard of its own
+            parts = []
+            for part in range(2):
+                a = adist.GradArena(n, d, torch.device("cpu"))
+                p_sh, p_de, p_su, p_m = _shard_grads(rank, n, d, frac, 42 + 1000 * part)
+                a.grad_sh.copy_(torch.from_numpy(p_sh))
+                a.grad_density.copy_(torch.from_numpy(p_de))
+                a.grad_surface.copy_(torch.from_numpy(p_su))
+                a.grad_fake_sample_std.fill_(float(rank + 1 + 10 * part))
+                a.mask.copy_(torch.from_numpy(p_m.copy()))
+                parts.append(a)
+            px = adist.PipelinedReduce(torch.device("cpu"))
+            px.submit(parts[0])
+            px.progress()
+            px.submit(parts[1])
+            used = px.finish(parts[0])
+            a = parts[0]
+            exp = [_shard_grads(r, n, d, frac, 42 + 1000 * part) for r in range(world) for part in range(2)]
+            ok = (np.allclose(a.grad_sh.numpy(), sum(e[0] for e in exp), atol=1e-5)
+                  and np.allclose(a.grad_density.numpy(), sum(e[1] for e in exp), atol=1e-5)
+                  and np.allclose(a.grad_surface.numpy(), sum(e[2] for e in exp), atol=1e-5)
+                  and (a.mask.numpy() == np.logical_or.reduce([e[3] for e in exp])).all()
+                  and float(a.grad_fake_sample_std.item()) == sum(r + 1 + 10 * part for r in range(world) for part in range(2)))
+            out.put((rank, bool(ok), used))
+            return
         if mode.startswith("arena"):  # the same buffers as views of one flat allocation, one collective
             arena = adist.GradArena(n, d, torch.device("cpu"))
             arena.grad_sh.copy_(t_sh)
@@ -74,7 +99,8 @@ def _worker(rank, world, port, mode, frac, n, d, out):
                                               ("auto", 0.03, "sparse"), ("auto", 0.5, "dense"),
                                               ("sparse", 0.0, "sparse"), ("arena", 0.3, "arena:dense"),
                                               ("arena_sparse", 0.2, "arena:sparse"), ("arena_auto", 0.1, "arena:sparse"),
-                                              ("arena_auto", 0.6, "arena:dense")])
+                                              ("arena_auto", 0.6, "arena:dense"), ("pipelined", 0.1, "pipelined"),
+                                              ("pipelined", 0.0, "pipelined")])
 def test_gradient_exchange_world2(mode, frac, expect):
     world, n, d = 2, 4001, 27
     ctx = mp.get_context("spawn")

@@ -1,5 +1,6 @@
 """Two ranks on one device (`pytest -m gpu`): each renders its shard of one view with the GLOBAL ray count in the loss
-normaliser, the gradient buffers are exchanged (dense ring, union-of-rows, auto), and every rank must end up with the
+normaliser, the gradient buffers are exchanged (dense ring, union-of-rows, auto, and the step in two parts with the first
+part's rows exchanged beside the second part's render), and every rank must end up with the
 single-batch gradients and masks.  The ranks are child processes that tests/conftest.py starts at session start --
 before this process touches the GPU (a process that has initialised the GPU must not start programs)."""
 import json
@@ -18,7 +19,7 @@ def test_two_ranks_share_one_device(dist_gpu_job):
     for rank in range(2):
         res = json.load(open(os.path.join(out_dir, f"rank{rank}.json")))
         assert res["ok"], res.get("error")
-        assert set(res["cases"]) == {"dense", "sparse", "auto"}
+        assert set(res["cases"]) == {"dense", "sparse", "auto", "pipelined"}
         for mode, c in res["cases"].items():
             assert c["rgb_equal"] and c["masks_equal"], (rank, mode, c)
             assert 0.01 < c["touched"] < 0.5
@@ -27,3 +28,4 @@ def test_two_ranks_share_one_device(dist_gpu_job):
         assert res["cases"]["dense"]["used"] == "dense"
         assert res["cases"]["sparse"]["used"] == "sparse"
         assert res["cases"]["auto"]["used"] == "sparse"     # a view touches well under half of the rows
+        assert res["cases"]["pipelined"]["used"] == "pipelined"   # the step in two parts (dist.PipelinedReduce)
