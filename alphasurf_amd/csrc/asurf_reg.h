@@ -237,17 +237,23 @@ k_surface_normal_grad_sparse(RegGrid G, const float* __restrict__ surface,
         int count = 0;
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
-            reg_cell_next(G, surface, x + (i == 0), y + (i == 1), z + (i == 2), 4 >> i, c0, cn[i]);
-            bool ok = cn[i].exist;
-            if (ok && con_check) {
-                const int bit = 4 >> i;  // corners of cn[i] on its low face along axis i
+            const int bit = 4 >> i;
+            cn[i].exist = false;
+            if (con_check) {
+                // the neighbour's low face along axis i IS c0's high face: whether the level crosses it is known
+                // before anything of the neighbour is loaded, and in a band around a surface most faces hold no crossing
                 float f[4];
                 int k = 0;
 #pragma unroll
                 for (int j = 0; j < 8; ++j)
-                    if (!(j & bit)) f[k++] = cn[i].s[j];
-                ok = !reg_all_one_side(f, 4, lv_set);
+                    if (j & bit) f[k++] = c0.s[j];
+                if (reg_all_one_side(f, 4, lv_set)) {
+                    use[i] = false;
+                    continue;
+                }
             }
+            reg_cell_next(G, surface, x + (i == 0), y + (i == 1), z + (i == 2), bit, c0, cn[i]);
+            bool ok = cn[i].exist;
             if (ok && ignore_empty) ok = !empty0 || !reg_all_one_side(cn[i].s, 8, lv_set);
             use[i] = ok;
             count += ok ? 1 : 0;
