@@ -1,5 +1,5 @@
 """The randomised option sweep's draw stream, shared by tests/test_hip_parity.py::test_random_option_fuzz, its
-regression case and variants/fuzz_draw.py: draw `it` of seed `seed` is the same scene, rays, options and loss weights
+regression case and tests/tools/fuzz_draw.py: draw `it` of seed `seed` is the same scene, rays, options and loss weights
 wherever it is replayed."""
 import numpy as np
 

@@ -2,8 +2,9 @@
 oracle's division-based DDA, bit for bit, on millions of rays."""
 import os, sys, time
 import numpy as np
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+_root = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, _root)
+sys.path.insert(0, os.path.join(_root, "tests"))
 from alphasurf_amd import synth
 from oracle import oracle as O
 import hip_util as hip

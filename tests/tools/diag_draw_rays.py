@@ -3,7 +3,7 @@ draw's ray count, so that every ray's loss terms are scaled as in the whole batc
 density / SH gradients differ most: usage diag_draw_rays.py <seed> <draw>."""
 import os, sys
 import numpy as np
-root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+root = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, root); sys.path.insert(0, os.path.join(root, "tests"))
 import hip_util as hip
 from oracle import oracle as oracle_mod

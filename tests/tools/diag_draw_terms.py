@@ -1,8 +1,8 @@
 """One ray of a fuzz draw, the fused loss terms one at a time: which term makes the HIP path and the oracle differ?
-usage diag_draw_terms.py <seed> <draw> <ray>   (the ray: variants/diag_draw_rays.py)"""
+usage diag_draw_terms.py <seed> <draw> <ray>   (the ray: tests/tools/diag_draw_rays.py)"""
 import os, sys
 import numpy as np
-root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+root = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, root); sys.path.insert(0, os.path.join(root, "tests"))
 import hip_util as hip
 from oracle import oracle as oracle_mod

@@ -2,7 +2,7 @@
 the oracle under several internal configurations: usage fuzz_draw.py <seed> <draw>."""
 import os, sys
 import numpy as np
-root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+root = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, root); sys.path.insert(0, os.path.join(root, "tests"))
 import hip_util as hip
 from alphasurf_amd import lib as _lib, synth
