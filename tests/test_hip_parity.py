@@ -481,25 +481,88 @@ def test_brick_skipping_is_exact(hip, monkeypatch):
                     grad_close(g[k], g_ref[k], 1e-5, f"reso {reso} {extra} seg {seg} grad_{k}")
 
 
+def oracle_sensitivity(oracle, sc, o, d, opts, fused, gt, go):
+    """How far each gradient element of the ORACLE moves under perturbations far below anything the data means: surface
+    values and raw opacities by 1e-6 relative (a root at a voxel face, a normal's sign, an alpha threshold), one level at
+    a time by 1e-5 (where the samples of a ray lie relative to one another: sign(mean t - t_i) of the sample-distance loss,
+    surf_trav.cu:2385-2390, the mode of the conv-mode loss), the targets by 2e-7 (the sign of the L1 residual,
+    surf_trav.cu:3310-3315: a colour that equals its target to the last bit), and the surface values vertex by vertex
+    by 1e-6 (four draws of noise: a ray that grazes the surface)."""
+    moved = {k: np.zeros_like(go[k]) for k in ("sh", "density", "surface")}
+
+    def take(sc2, gt2):
+        _, go2, _ = oracle.render_fused(sc2, o, d, opts, gt2, fused)
+        for k in moved:
+            moved[k] = np.maximum(moved[k], np.abs(go2[k] - go[k]))
+    for plane in ("surface", "density"):
+        for eps in (1e-6, -1e-6):
+            sc2 = dict(sc)
+            sc2[plane] = (sc[plane].astype(np.float64) * (1.0 + eps)).astype(np.float32)
+            take(sc2, gt)
+    for li in range(len(sc["level_set"])):
+        for eps in (1e-5, -1e-5):
+            lv = np.array(sc["level_set"], np.float32).copy()
+            lv[li] += eps
+            take(dict(sc, level_set=lv), gt)
+    for eps in (2e-7, -2e-7):
+        take(sc, (gt.astype(np.float64) + eps).astype(np.float32))
+    # vertex by vertex (a ray that grazes the surface: two roots a hair apart, the normal across the ray -- the pair is
+    # there or not, and passes the outward test or not, by the last bits of single corner values)
+    rs = np.random.RandomState(12345)
+    for _ in range(4):
+        noise = 1.0 + 1e-6 * rs.randn(*sc["surface"].shape)
+        take(dict(sc, surface=(sc["surface"].astype(np.float64) * noise).astype(np.float32)), gt)
+    return moved
+
+
+def explained_by_sensitivity(g, go, moved, max_rows=64):
+    """Wherever the HIP path differs from the oracle by more than the usual bound, the oracle itself moves by as much
+    under the perturbations of oracle_sensitivity(), and it does so in a handful of rows (a sample's voxel and the
+    neighbours its loss terms read; one ray's samples).  Returns (ok, what)."""
+    rows = set()
+    for k in ("sh", "density", "surface"):
+        scale = float(np.abs(go[k]).max())
+        err = np.abs(g[k].reshape(go[k].shape) - go[k])
+        over = err > 3e-4 * scale
+        rows |= set(np.nonzero(over.any(axis=1))[0].tolist())
+        if not (err[over] <= 1.1 * moved[k][over] + 3e-4 * scale).all():
+            return False, f"grad_{k}: differs from the oracle by {float(err[over].max()):.3e} where the oracle is stable"
+    if len(rows) > max_rows:
+        return False, f"{len(rows)} rows differ"
+    return True, f"{len(rows)} rows on a knife edge"
+
+
 def test_random_option_fuzz(hip, oracle):
     """Randomised sweep over scenes, options and loss weights: every draw must agree with the
-    oracle (RGB, gradients, masks).  Seeds are fixed; each draw is printed on failure."""
+    oracle (RGB, gradients, masks).  Seeds are fixed; each draw is printed on failure.
+    The fused losses hold sign and threshold tests (the L1 residual, sign(mean t - t_i), the inwards-normal term, alpha
+    gates): about one draw in a thousand puts a sample within an ulp of such an edge, where the host's libm and the
+    device's decide differently and a few gradient rows jump.  A draw that misses the bound must therefore be EXPLAINED:
+    the oracle itself moves by as much under perturbations of 1e-6 (explained_by_sensitivity); test_fuzz_knife_edge_draw
+    keeps one draw of each kind found so far and also asks that every internal form of the HIP path agrees there."""
     import fuzz_util
     seed = int(os.environ.get("ASURF_FUZZ_SEED", "2024"))
     n_draws = int(os.environ.get("ASURF_FUZZ_DRAWS", "24"))     # a longer sweep: set the two variables
-    known_edges = {(31337, 107), (424242, 109)}                  # test_fuzz_knife_edge_draw takes these apart
+    edges = []
     for it, sc, o, d, opts, fused, gt, tag in fuzz_util.draws(seed, n_draws):
-        if (seed, it) in known_edges:
-            continue
         rgb, g = hip.render_fused(sc, o, d, opts, gt, fused)
         rgb_o, go, st = oracle.render_fused(sc, o, d, opts, gt, fused)
         assert np.abs(rgb - rgb_o).max() <= RGB_TOL_ORACLE, tag
-        for k in ("sh", "density", "surface"):
-            if np.abs(go[k]).max() > 0:
-                grad_close(g[k], go[k], 3e-4, tag + f" grad_{k}")
+        try:
+            for k in ("sh", "density", "surface"):
+                if np.abs(go[k]).max() > 0:
+                    grad_close(g[k], go[k], 3e-4, tag + f" grad_{k}")
+        except AssertionError as miss:
+            ok, what = explained_by_sensitivity(g, go, oracle_sensitivity(oracle, sc, o, d, opts, fused, gt, go))
+            assert ok, f"{miss}\n... and not a knife edge: {what}"
+            edges.append((it, what))
         scale = max(abs(float(go["fake_sample_std"][0])), float(np.abs(go["density"]).max()), 1e-12)
-        assert abs(float(g["fake_sample_std"][0]) - float(go["fake_sample_std"][0])) <= 1e-2 * scale, tag
+        if not edges or edges[-1][0] != it:
+            assert abs(float(g["fake_sample_std"][0]) - float(go["fake_sample_std"][0])) <= 1e-2 * scale, tag
         assert (g["mask"].astype(bool) == go["mask"].astype(bool)).all(), tag
+    if edges:
+        print(f"seed {seed}: {len(edges)} of {n_draws} draws on a knife edge: {edges}")
+    assert len(edges) <= max(1, n_draws // 100), edges
 
 
 @pytest.mark.parametrize("optname", ["syn_yaml", "density_gate", "fake_limited", "fake_all", "sigmoid_stop"])
@@ -556,7 +619,7 @@ def test_fuzz_knife_edge_draw(hip, oracle, seed, draw):
     of the HIP path (pipeline or one kernel, k_sweep or the stepping walk, filter on or off, replay or walking
     backward) gives the same result; (2) wherever the HIP path differs from the oracle by more than the usual bound,
     the ORACLE itself moves by as much when its surface values or its raw opacities are perturbed by 1e-6 relative,
-    or one of its levels by 1e-5."""
+    one of its levels by 1e-5, or its targets by 2e-7 (oracle_sensitivity)."""
     import fuzz_util
     (it, sc, o, d, opts, fused, gt, tag), = list(fuzz_util.draws(seed, draw + 1, only=draw))
     res = {}
@@ -575,33 +638,8 @@ def test_fuzz_knife_edge_draw(hip, oracle, seed, draw):
     rgb_o, go, _ = oracle.render_fused(sc, o, d, opts, gt, fused)
     assert np.abs(rgb - rgb_o).max() <= RGB_TOL_ORACLE
     assert (g["mask"].astype(bool) == go["mask"].astype(bool)).all()
-    # the oracle's own sensitivity, element by element
-    moved = {k: np.zeros_like(go[k]) for k in ("sh", "density", "surface")}
-    for plane in ("surface", "density"):   # (a gate on the surface: a root, a normal's sign; on the opacity: an alpha threshold)
-        for eps in (1e-6, -1e-6):
-            sc2 = dict(sc)
-            sc2[plane] = (sc[plane].astype(np.float64) * (1.0 + eps)).astype(np.float32)
-            _, go2, _ = oracle.render_fused(sc2, o, d, opts, gt, fused)
-            for k in moved:
-                moved[k] = np.maximum(moved[k], np.abs(go2[k] - go[k]))
-    # (... on where the samples lie relative to one another -- sign(mean t - t_i) of the sample-distance loss,
-    # surf_trav.cu:2385-2390 --: the levels, one at a time)
-    for li in range(len(sc["level_set"])):
-        for eps in (1e-5, -1e-5):
-            lv = np.array(sc["level_set"], np.float32).copy()
-            lv[li] += eps
-            _, go2, _ = oracle.render_fused(dict(sc, level_set=lv), o, d, opts, gt, fused)
-            for k in moved:
-                moved[k] = np.maximum(moved[k], np.abs(go2[k] - go[k]))
-    edge_rows = set()
-    for k in ("sh", "density", "surface"):
-        scale = float(np.abs(go[k]).max())
-        err = np.abs(g[k].reshape(go[k].shape) - go[k])
-        over = err > 3e-4 * scale
-        edge_rows |= set(np.nonzero(over.any(axis=1))[0].tolist())
-        assert (err[over] <= 1.1 * moved[k][over] + 3e-4 * scale).all(), \
-            f"grad_{k}: differs from the oracle by {float(err[over].max()):.3e} where the oracle is stable"
-    assert len(edge_rows) <= 32, sorted(edge_rows)     # local: the knife-edge sample's voxel and the neighbours its normal term reads
+    ok, what = explained_by_sensitivity(g, go, oracle_sensitivity(oracle, sc, o, d, opts, fused, gt, go))
+    assert ok, what
 
 
 def test_walk_quotient_is_the_ieee_quotient(hip):
