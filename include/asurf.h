@@ -480,7 +480,8 @@ int asurf_rows_unpack_add(const int32_t* rows, int64_t n_list, int32_t sh_dim, c
  * pipeline's counters after a call, 32: k_geom without its no-root filter), ASURF_WALK ("step"), ASURF_WALK_SEG,
  * ASURF_RPW, ASURF_CUVOL_RPW, ASURF_NO_PIPELINE, ASURF_NO_REPLAY, ASURF_NO_SPLIT_BWD, ASURF_EVAL ("walk"),
  * ASURF_SWEEP ("block": the block-synchronous k_sweep), ASURF_SWEEP_WPB, ASURF_SWEEP_RPW, ASURF_MASKS ("row": the
- * per-voxel occupancy pass), ASURF_SIDE_STREAM (the fused call's fallback kernels on a stream of the library's own).  The
+ * per-voxel occupancy pass; "split" / "single": the full pass in three steps / as one kernel whatever the grid's size),
+ * ASURF_ORDER ("radix": rocPRIM's sort instead of the strip sort), ASURF_SIDE_STREAM (the fused call's fallback kernels on a stream of the library's own).  The
  * environment variables of these names are read ONCE, by the first entry point that runs; afterwards only this
  * function changes a switch (value NULL = default).  Nothing on the call path reads the environment.  The
  * measurement aids that make results invalid (ASURF_DEBUG bits 1, 2, 4, 256 * n) exist in the instrumented build
