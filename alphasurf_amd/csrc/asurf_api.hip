@@ -69,6 +69,8 @@ struct Config {
     int sweep_block = 0;   // ASURF_SWEEP=block: the block-synchronous form of k_sweep (round 2)
     int sweep_wpb = 0;     // ASURF_SWEEP_WPB = 1, 2, 4: waves per block of k_sweep_wave (measurement)
     int sweep_rpw = 0;     // ASURF_SWEEP_RPW = 2, 4, 8, 16: rays per wave of k_sweep_wave (0: by batch size)
+    int lazy_rays = -1;    // ASURF_LAZY = n: batches of up to n rays run over planes of `links` alone (asurf_masks2.h);
+                           // 0 never, -1 the default (kLazyMaxRays)
 };
 #ifdef ASURF_INSTRUMENT
 constexpr int kDebugMask = 1 | 2 | 4 | 8 | 16 | 32 | (7 << 8);
@@ -100,7 +102,8 @@ bool config_assign(Config& c, const char* name, const char* value) {
     }
     else if (!strcmp(name, "ASURF_SWEEP")) c.sweep_block = (value && !strcmp(value, "block")) ? 1 : 0;
     else if (!strcmp(name, "ASURF_SWEEP_WPB")) c.sweep_wpb = (n == 1 || n == 2 || n == 4) ? n : 0;
-    else if (!strcmp(name, "ASURF_SWEEP_RPW")) c.sweep_rpw = (n == 2 || n == 4 || n == 8 || n == 16) ? n : 0;
+    else if (!strcmp(name, "ASURF_SWEEP_RPW")) c.sweep_rpw = (n == 1 || n == 2 || n == 4 || n == 8 || n == 16) ? n : 0;
+    else if (!strcmp(name, "ASURF_LAZY")) c.lazy_rays = (value && *value) ? std::max(n, 0) : -1;
     else return false;
     return true;
 }
@@ -109,7 +112,8 @@ Config config() {  // a copy: a call works with one consistent set
     std::call_once(g_cfg_once, [] {
         static const char* const names[] = {"ASURF_DEBUG", "ASURF_WALK_SEG", "ASURF_WALK", "ASURF_RPW", "ASURF_NO_PIPELINE",
                                             "ASURF_CUVOL_RPW", "ASURF_NO_REPLAY", "ASURF_NO_SPLIT_BWD", "ASURF_EVAL",
-                                            "ASURF_TIMELINE", "ASURF_SWEEP", "ASURF_SWEEP_WPB", "ASURF_SWEEP_RPW", "ASURF_MASKS", "ASURF_SIDE_STREAM", "ASURF_ORDER"};
+                                            "ASURF_TIMELINE", "ASURF_SWEEP", "ASURF_SWEEP_WPB", "ASURF_SWEEP_RPW", "ASURF_MASKS", "ASURF_SIDE_STREAM", "ASURF_ORDER",
+                                            "ASURF_LAZY"};
         std::lock_guard<std::mutex> lock(g_cfg_mu);
         for (const char* nm : names)
             if (const char* v = getenv(nm)) config_assign(g_cfg, nm, v);
@@ -160,6 +164,13 @@ constexpr long long kOrderMinRays = 65536;
 // asks asurf_workspace_bytes_rec() for a deeper one, and every call takes the deepest of kRecDepths that the workspace
 // it is handed holds -- a function of the buffer's size alone, so a buffer has one layout.
 constexpr int kRecDepth = 32;
+// Batches up to this many rays test planes of `links` alone and apply the value gates to the voxels they meet
+// (asurf_masks2.h, k_links_planes; KOpt::lazy_gates): the per-call pass over the volume costs 0.063 ms at 256^3 whatever
+// the batch, the gates in k_sweep's exact test a few us per thousand rays.  ASURF_LAZY overrides.
+constexpr long long kLazyMaxRays = 32768;
+// blocks of k_links_planes: as a rule they read the header, find the planes vouched for and leave -- few blocks, few
+// tickets; when the planes must be rebuilt (once per change of `links`) each takes its share of the rows
+constexpr int kLinksPlanesBlocks = 64;
 constexpr int kMaskSplitRows = 16384;   // rows of 8 bricks from which the full occupancy pass is split (512^3: 32 768)
 constexpr int kRecDepths[] = {128, 64, 32};
 static_assert(kRecDepths[0] <= (1 << (32 - kRecRayBits)), "a record's number fits above the ray's in a list cell");
@@ -375,6 +386,7 @@ KOpt make_kopt(const asurf_render_options* o) {
     k.trunc_vol_weight_min = o->trunc_vol_weight_min;
     const Config c = config();
     k.debug = c.debug;
+    k.lazy_gates = 0;
 #ifdef ASURF_TIMELINE
     static std::once_flag tl_once;  // ASURF_TIMELINE=<kernel id>: that kernel's waves leave their times (asurf_device.h)
     std::call_once(tl_once, [&c] {
@@ -397,6 +409,7 @@ struct Launch {
     size_t dyn_lds;
     dim3 ray_grid;
     bool sweep;  // the forward pipeline finds its work voxels with k_sweep instead of k_walk
+    bool lazy;   // the planes hold the links' test only (small batches): KOpt::lazy_gates is set
 };
 
 // k_sweep serves the calls whose walk tests the sparse `work` plane (on the `live` plane nearly every voxel
@@ -456,6 +469,7 @@ struct MaskCacheEntry {
     bool pending = false;
     int count = -1;
     unsigned long long used = 0;
+    int kind = 0;   // 0: the list of live rows beside per-call planes; 1: planes of `links` alone (k_links_planes)
 };
 constexpr int kMaskCacheEntries = 8;
 std::mutex g_mask_cache_mu;
@@ -470,9 +484,9 @@ int mask_cache_lookup(void* ws, unsigned long long epoch, const asurf_grid* grid
     std::lock_guard<std::mutex> lock(g_mask_cache_mu);
     for (MaskCacheEntry& e : g_mask_cache) {
         if (e.ws != ws) continue;
-        if (epoch == 0ull) {
-            e.ws = nullptr;
-            return -1;
+        if (epoch == 0ull || e.kind != 0) {   // (kind 1: the planes of links alone are about to be overwritten, their
+            e.ws = nullptr;                   //  header cleared by the full pass's memset)
+            return epoch == 0ull ? -1 : 0;
         }
         if (e.epoch != epoch || e.links != grid->links || e.size[0] != grid->size[0] || e.size[1] != grid->size[1] ||
             e.size[2] != grid->size[2]) {
@@ -517,6 +531,7 @@ void mask_cache_store(void* ws, unsigned long long epoch, const asurf_grid* grid
     for (int i = 0; i < 3; ++i) slot->size[i] = grid->size[i];
     slot->count = -1;
     slot->pending = false;
+    slot->kind = 0;
     slot->used = ++g_mask_cache_clock;
     if (!slot->h_count && hipHostMalloc(reinterpret_cast<void**>(&slot->h_count), sizeof(int)) != hipSuccess) {
         slot->h_count = nullptr;
@@ -529,6 +544,41 @@ void mask_cache_store(void* ws, unsigned long long epoch, const asurf_grid* grid
     if (hipMemcpyAsync(slot->h_count, d_count, sizeof(int), hipMemcpyDeviceToHost, stream) == hipSuccess &&
         hipEventRecord(slot->ev, stream) == hipSuccess)
         slot->pending = true;
+}
+
+// Planes of `links` alone (small batches): has this workspace's header been initialised for these links?  The header on
+// the device decides whether the planes are trusted (k_links_planes); this table only spares the memset that makes a
+// header of unknown content safe to read.  1: yes; 0: no -- the caller clears the header, and the entry is made;
+// -1: no, and nothing may be cleared or stored now (a graph is being captured): the call takes the per-call pass.
+int lazy_cache_lookup(void* ws, const asurf_grid* grid, bool capturing) {
+    std::lock_guard<std::mutex> lock(g_mask_cache_mu);
+    MaskCacheEntry* slot = nullptr;
+    for (MaskCacheEntry& e : g_mask_cache)
+        if (e.ws == ws) slot = &e;
+    if (slot != nullptr && slot->kind == 1 && slot->links == grid->links && slot->size[0] == grid->size[0] &&
+        slot->size[1] == grid->size[1] && slot->size[2] == grid->size[2]) {
+        slot->used = ++g_mask_cache_clock;
+        return 1;
+    }
+    if (capturing) return -1;
+    if (!slot) {
+        slot = &g_mask_cache[0];
+        for (MaskCacheEntry& e : g_mask_cache)
+            if (e.ws == nullptr || e.used < slot->used) {
+                slot = &e;
+                if (e.ws == nullptr) break;
+            }
+    }
+    if (slot->pending) (void)hipEventSynchronize(slot->ev);  // (its old copy still writes h_count)
+    slot->ws = ws;
+    slot->epoch = 0;
+    slot->links = grid->links;
+    for (int i = 0; i < 3; ++i) slot->size[i] = grid->size[i];
+    slot->count = -1;
+    slot->pending = false;
+    slot->kind = 1;
+    slot->used = ++g_mask_cache_clock;
+    return 0;
 }
 
 // --- asurf_fused_params::order_rays = 0 (auto): was the last batch rendered through this workspace coherent? ---
@@ -608,7 +658,7 @@ int order_probe(void* ws, const float* origins, const float* dirs, long long n, 
 // Common prologue: validation, workspace carve-up and the occupancy-pyramid pass.
 int prepare(const asurf_grid* grid, const asurf_rays* rays, const asurf_render_options* opt,
             int32_t M, void* workspace, size_t workspace_bytes, void* stream, Launch& L,
-            bool masks_only = false, bool cuvol = false) {
+            bool masks_only = false, bool cuvol = false, bool allow_lazy = false) {
     if (int e = check_grid(grid, !cuvol)) return e;
     if (int e = check_rays(rays)) return e;
     if (!opt) return fail(ASURF_E_INVALID, "render options are NULL");
@@ -631,6 +681,7 @@ int prepare(const asurf_grid* grid, const asurf_rays* rays, const asurf_render_o
     L.dyn_lds = L.coarse_in_lds ? L.ML.coarse_words * 4 : 0;
     L.ray_grid = dim3((unsigned)((rays->n_rays + kBlock - 1) / kBlock));
     L.sweep = !cuvol && !masks_only && want_sweep(use_live, L.o);
+    L.lazy = false;
     prof_begin(L.stream);
     const int nzg = (L.ML.nb[2] + 7) / 8;  // groups of 8 bricks along z
     unsigned long long* fw = reinterpret_cast<unsigned long long*>(L.ws + L.ML.off_fine_work);
@@ -651,6 +702,32 @@ int prepare(const asurf_grid* grid, const asurf_rays* rays, const asurf_render_o
     const size_t hdr_and_counters = (L.ML.off_p_counters - L.ML.off_mask_hdr) + (size_t)kCtrTotal * sizeof(int);
     hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
     const bool capturing = hipStreamIsCapturing(L.stream, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone;
+    // ---- small batches: planes of `links` alone, kept from call to call (asurf_masks2.h) ----
+    {
+        const int cfg_lazy = config().lazy_rays;
+        const long long lazy_max = cfg_lazy < 0 ? kLazyMaxRays : (long long)cfg_lazy;
+        if (allow_lazy && L.sweep && !config().sweep_block && rays->n_rays > 0 && rays->n_rays <= lazy_max) {
+            const int have = lazy_cache_lookup(workspace, grid, capturing);
+            if (have >= 0) {
+                if (have == 0 && hipMemsetAsync(hdr, 0, sizeof(MaskHdr), L.stream) != hipSuccess)
+                    return fail(ASURF_E_LAUNCH, "hipMemsetAsync(mask header) failed");
+                const long long n_links = (long long)grid->size[0] * grid->size[1] * grid->size[2];
+                const int use_sum = epoch == 0ull ? 1 : 0;
+                if (use_sum) {
+                    // enough 16-byte pieces in flight to stream: 8 blocks of 256 a CU at most, 8 pieces a thread at least
+                    const long long pieces = (n_links + 3) / 4;
+                    const unsigned blocks = (unsigned)std::min<long long>(std::max<long long>(pieces / (256 * 8), 1), 2048);
+                    hipLaunchKernelGGL(k_links_checksum, dim3(blocks), dim3(256), 0, L.stream, grid->links, n_links, hdr);
+                }
+                hipLaunchKernelGGL(k_links_planes, dim3((unsigned)std::min(L.ML.n_rows, kLinksPlanesBlocks)), dim3(512), 0, L.stream, L.g, fw, fl,
+                                   cw, cl, fy, fz, nzg, L.ML.n_rows, hdr, epoch, use_sum, zero_ptr, zero_n);
+                L.lazy = true;
+                L.o.lazy_gates = 1;
+                prof_after("k_links_planes", 0, L.stream);
+                return launch_error("k_links_planes");
+            }
+        }
+    }
     int live_blocks = 0;
     int cached = mask_cache_lookup(workspace, epoch, grid, L.ML.n_rows, &live_blocks, capturing);
     // building the list allocates pinned memory and reads a counter back: not while a graph is being captured
@@ -822,13 +899,20 @@ int find_candidates(const Launch& L, const asurf_rays* rays, bool record, PipeBu
                 // (the slice decides how many waves share a CU: LDS is handed out in 1 280-byte pieces, and at 256^3 a
                 // slice of 7 504 bytes lets the 20 waves the registers allow in, 8 016 -- 384 tasks -- only 18:
                 // 0.279 against 0.296 ms; a wave with more tasks than fit takes its rays four at a time)
-                const int task_cap = (std::min(std::max(rpw * nbmax / 2, 128), 1536) + 3) & ~3;
-                const int key_cap = (std::max((nbmax > 64 ? 2048 : (nbmax > 32 ? 1280 : 768)) * rpw / kSweepWaveRays, 256) + 15) & ~15;
+                // (over planes of links alone a ray meets every voxel of the shell it crosses, five times the work voxels
+                // on the bench scene: four times the keys, twice the tasks)
+                const int task_cap = (std::min(std::max(rpw * nbmax / 2, 128) * (L.lazy ? 2 : 1), 1536) + 3) & ~3;
+                const int key_cap = (std::max((nbmax > 64 ? 2048 : (nbmax > 32 ? 1280 : 768)) * rpw / kSweepWaveRays, 256) * (L.lazy ? 4 : 1) + 15) & ~15;
                 const int wave_bytes = (int)((size_t)rpw * sizeof(SweepRay) + (size_t)task_cap * 4 + (size_t)key_cap * 5 +
                                              sizeof(SweepWaveMisc));   // (keys + a byte each for the ray they belong to)
                 const long long waves = (Q + rpw - 1) / rpw;
                 const int wpb = cfgc.sweep_wpb ? cfgc.sweep_wpb : kSweepWavesPerBlock;
                 const dim3 sgrid((unsigned)((waves + wpb - 1) / wpb));
+                if (L.lazy)
+                    hipLaunchKernelGGL(k_sweep_wave_lazy, sgrid, dim3(64 * wpb), (size_t)wave_bytes * wpb,
+                                       L.stream, L.g, L.o, rays->origins, rays->dirs, Q, P, nbmax, record ? 1 : 0, task_cap,
+                                       key_cap, wave_bytes, rpw);
+                else
                 hipLaunchKernelGGL(k_sweep_wave, sgrid, dim3(64 * wpb), (size_t)wave_bytes * wpb,
                                    L.stream, L.g, L.o, rays->origins, rays->dirs, Q, P, nbmax, record ? 1 : 0, task_cap,
                                    key_cap, wave_bytes, rpw);
@@ -1248,11 +1332,14 @@ int asurf_volume_render_surf_trav(const asurf_grid* grid, const asurf_rays* rays
                                   const asurf_render_options* opt, float* rgb_out, void* workspace,
                                   size_t workspace_bytes, uint64_t* counters, void* stream) {
     Launch L;
-    if (int e = prepare(grid, rays, opt, 0, workspace, workspace_bytes, stream, L)) return e;
+    if (int e = check_grid(grid)) return e;
+    if (int e = check_rays(rays)) return e;
+    if (!opt) return fail(ASURF_E_INVALID, "render options are NULL");
+    const bool pipe = use_pipeline(grid, rays, opt, counters);
+    if (int e = prepare(grid, rays, opt, 0, workspace, workspace_bytes, stream, L, false, false, pipe)) return e;
     if (rays->n_rays == 0) return 0;
     if (!rgb_out) return fail(ASURF_E_INVALID, "rgb_out is NULL");
     int rc = 0;
-    const bool pipe = use_pipeline(grid, rays, opt, counters);
     ASURF_DISPATCH_B(grid->basis_dim, run_forward<B_>(L, rays, rgb_out, 0, false, false, counters, pipe));
     return rc;
 }
@@ -1289,7 +1376,12 @@ int asurf_volume_render_surf_trav_fused(const asurf_grid* grid, const asurf_rays
     const int M = fused->l_dist_max_sample;
     if (M < 0) return fail(ASURF_E_INVALID, "l_dist_max_sample < 0");
     Launch L;
-    if (int e = prepare(grid, rays, opt, M, workspace, workspace_bytes, stream, L)) return e;
+    if (int e = check_grid(grid)) return e;
+    if (int e = check_rays(rays)) return e;
+    if (!opt) return fail(ASURF_E_INVALID, "render options are NULL");
+    if (int e = prepare(grid, rays, opt, M, workspace, workspace_bytes, stream, L, false, false,
+                        use_pipeline(grid, rays, opt, counters)))
+        return e;
     if (!grads) return fail(ASURF_E_INVALID, "grads is NULL");
     if (rays->n_rays == 0) return 0;
     if (!fused->rgb_gt || !rgb_out) return fail(ASURF_E_INVALID, "rgb_gt / rgb_out is NULL");

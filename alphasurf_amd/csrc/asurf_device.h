@@ -69,6 +69,9 @@ struct KOpt {
     // one-kernel path; 256 * n: k_sweep leaves after phase n - 1 -- are compiled into the instrumented build only
     // (`make timeline`: -DASURF_INSTRUMENT); the host masks their bits off otherwise.
     int debug;
+    // 1: the occupancy planes say "all 8 corner links exist" only (small batches, asurf_masks2.h): whoever reads a flagged
+    // voxel applies the value gates of surf_trav.cu:230-239 itself (k_sweep_wave; the one-kernel paths)
+    int lazy_gates;
 };
 #ifdef ASURF_INSTRUMENT
 #define ASURF_AID(o, bit) (((o).debug & (bit)) != 0)

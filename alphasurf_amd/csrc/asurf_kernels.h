@@ -188,9 +188,16 @@ __device__ __forceinline__ bool build_masks_row(const KGrid& g, float sigma_thre
 // MaskHdr: what a workspace remembers about `links` between calls (asurf_grid::links_epoch, include/asurf.h): the
 // rows of bricks in which some 64-run of vertices along z holds a link >= 0.  Every other row is empty space whatever
 // the densities and surfaces: its words in all planes are zero and stay zero.
+constexpr int kSumSlots = 64;
 struct MaskHdr {
     unsigned long long magic, epoch;
     int n_live, pad;
+    // links-only planes (asurf_masks2.h, k_links_planes): the checksum of `links` they were built under, the blocks'
+    // ticket, and the slots this call's checksum is added up in (zero between calls)
+    unsigned long long sum[2];
+    unsigned int ticket;
+    int sum_known;
+    unsigned long long acc[kSumSlots][2];
 };
 constexpr unsigned long long kMaskMagic = 0x61737572666d736bull;
 
@@ -526,6 +533,15 @@ struct Vox {
     float smin, smax;
     float t_close, t_far;
 };
+
+// all 8 corner densities below the gate: the reference skips the voxel (surf_trav.cu:230-239).  The per-call planes hold
+// the test; under planes of links only (KOpt::lazy_gates) the one-kernel paths apply it to the voxels they load.
+__device__ __forceinline__ bool voxel_all_below(const Vox& v, float sigma_thresh) {
+    bool all_below = true;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) all_below = all_below && (v.dens[i] < sigma_thresh);
+    return all_below;
+}
 
 // Work voxels found by the walk are parked in a small per-lane FIFO (LDS) so that the lanes
 // of a wave do not have to rendezvous at every one of them: x,y,z packed 10 bits each.
@@ -1202,12 +1218,13 @@ k_forward(KGrid g, KOpt o, const float* __restrict__ origins, const float* __res
         if (!__any(qn > 0)) break;
       // (B,C) drain the FIFOs in order, slot by slot
       for (int qi = 0; __any(qi < qn); ++qi) {
-        const bool found = qi < qn;
+        bool found = qi < qn;
         const bool rec_ok = do_rec && found && (n_drained < rec_cut);
         if (found) ++n_drained;
         // (B) geometry
         Vox v;
         if (found) load_voxel(g, r, s_queue[qi * kBlock + tid], v);
+        if (o.lazy_gates && found && voxel_all_below(v, o.sigma_thresh)) found = false;   // (planes of links only: :230-239 here)
         bool vox_has_sample = false, vox_has_surf = false;
         // (C) real intersections, one level set at a time
         for (int li = 0; li < g.level_set_num; ++li) {
@@ -1556,9 +1573,10 @@ k_backward(KGrid g, KOpt o, KLoss L, KGrads G, const float* __restrict__ origins
         }
         if (!__any(qn > 0)) break;
       for (int qi = 0; __any(qi < qn); ++qi) {
-        const bool found = qi < qn;
+        bool found = qi < qn;
         Vox v;
         if (found) load_voxel(g, r, s_queue[qi * kBlock + tid], v);
+        if (!REC && o.lazy_gates && found && voxel_all_below(v, o.sigma_thresh)) found = false;   // (as k_forward)
         bool vox_has_sample = false, vox_has_surf = false;
         // record fields: bit0 fake, bits1-2 root index, bits3-7 level-set index,
         // bits8.. intersection ordinal + 1 at the sample

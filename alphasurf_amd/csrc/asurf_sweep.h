@@ -529,9 +529,40 @@ __device__ __forceinline__ int list_segment_unit(const PipeBuf& P, unsigned unit
 #ifndef ASURF_SWEEP_EU
 #define ASURF_SWEEP_EU 5
 #endif
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(ASURF_SWEEP_EU, ASURF_SWEEP_EU)))
-k_sweep_wave(KGrid g, KOpt o, const float* __restrict__ origins, const float* __restrict__ dirs, long long Q,
-             PipeBuf P, int n_layers, int want_cut, int task_cap, int key_cap, int wave_bytes, int rpw) {
+// The value gates a voxel passes before it is a work voxel (surf_trav.cu:230-239, 265-277), decided the way
+// k_build_masks2 decides them for the per-call planes (asurf_masks2.h: live = not all 8 densities below the gate;
+// work = live and some level neither above all 8 surface values nor below all of them) -- for the calls whose planes
+// hold the links' test only (KOpt::lazy_gates).
+__device__ __forceinline__ bool lazy_gates_pass(const KGrid& g, float sigma_thresh, const int32_t* lk) {
+    bool ok = true, all_below = true;
+    float sv[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) ok = ok && lk[i] >= 0;
+    if (!ok) return false;   // (cannot happen under planes that match `links`: memory safety under a broken promise)
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        all_below = all_below && (g.density[lk[i]] < sigma_thresh);
+        sv[i] = g.surface[lk[i]];
+    }
+    if (all_below) return false;
+    bool any = false;
+    for (int s = 0; s < g.level_set_num; ++s) {
+        const float lv = g.level_set[s];
+        bool all_g = true, all_h = true;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            all_g = all_g && (sv[i] > lv);
+            all_h = all_h && (sv[i] < lv);
+        }
+        any = any || (!all_g && !all_h);
+    }
+    return any;
+}
+
+template <bool LAZY>
+__device__ __forceinline__ void
+sweep_wave_body(const KGrid& g, const KOpt& o, const float* __restrict__ origins, const float* __restrict__ dirs, long long Q,
+                const PipeBuf& P, int n_layers, int want_cut, int task_cap, int key_cap, int wave_bytes, int rpw) {
     extern __shared__ uint4 s_dyn4[];
     const TlScope tl(2);
     const int lane = threadIdx.x & 63;
@@ -1034,6 +1065,19 @@ k_sweep_wave(KGrid g, KOpt o, const float* __restrict__ origins, const float* __
                 r.tmin = R.tmin;
                 r.tmax = R.tmax;
                 const int n0[3] = {R.n0[0], R.n0[1], R.n0[2]};
+                int32_t lk[8];
+                if constexpr (LAZY) {   // asked for before the exact test's arithmetic: one round trip hidden behind it
+                    const bool in = vv[0] + 1 < g.size[0] && vv[1] + 1 < g.size[1] && vv[2] + 1 < g.size[2];
+                    const int32_t* lp = g.links + ((size_t)vv[0] * g.offx + (size_t)vv[1] * g.offy + vv[2]);
+                    lk[0] = in ? lp[0] : -1;
+                    lk[1] = in ? lp[1] : -1;
+                    lk[2] = in ? lp[g.offy] : -1;
+                    lk[3] = in ? lp[g.offy + 1] : -1;
+                    lk[4] = in ? lp[g.offx] : -1;
+                    lk[5] = in ? lp[g.offx + 1] : -1;
+                    lk[6] = in ? lp[g.offx + g.offy] : -1;
+                    lk[7] = in ? lp[g.offx + g.offy + 1] : -1;
+                }
                 float tc[3], tf[3], t_entry;
                 if (R.fast_div) {  // the IEEE quotients, three instructions each (quotient(), asurf_kernels.h)
 #pragma unroll
@@ -1046,7 +1090,9 @@ k_sweep_wave(KGrid g, KOpt o, const float* __restrict__ origins, const float* __
                 } else {
                     voxel_times(r, vv[0], vv[1], vv[2], tc, tf);
                 }
-                if (walk_visits(r, n0, vv, tc, tf, &t_entry)) {
+                bool keep = walk_visits(r, n0, vv, tc, tf, &t_entry);
+                if constexpr (LAZY) keep = keep && lazy_gates_pass(g, o.sigma_thresh, lk);
+                if (keep) {
                     atomicAdd(&M->n[rl], 1);
                     if (want_cut && (t_entry + o.step_size > r.tmax) &&
                         walk_cut_before(g, r, o.step_size, n0, vv, tc))
@@ -1149,6 +1195,20 @@ k_sweep_wave(KGrid g, KOpt o, const float* __restrict__ origins, const float* __
     }
 #undef ASURF_COARSE_WORD
     tl.end();
+}
+
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(ASURF_SWEEP_EU, ASURF_SWEEP_EU)))
+k_sweep_wave(KGrid g, KOpt o, const float* __restrict__ origins, const float* __restrict__ dirs, long long Q,
+             PipeBuf P, int n_layers, int want_cut, int task_cap, int key_cap, int wave_bytes, int rpw) {
+    sweep_wave_body<false>(g, o, origins, dirs, Q, P, n_layers, want_cut, task_cap, key_cap, wave_bytes, rpw);
+}
+
+// Small batches over links-only planes (asurf_masks2.h): the exact test also applies the value gates.  No occupancy
+// attribute: the launch is a few hundred waves, and the 24 gathered values may have their registers.
+__global__ void __launch_bounds__(256)
+k_sweep_wave_lazy(KGrid g, KOpt o, const float* __restrict__ origins, const float* __restrict__ dirs, long long Q,
+                  PipeBuf P, int n_layers, int want_cut, int task_cap, int key_cap, int wave_bytes, int rpw) {
+    sweep_wave_body<true>(g, o, origins, dirs, Q, P, n_layers, want_cut, task_cap, key_cap, wave_bytes, rpw);
 }
 
 }  // namespace asurf

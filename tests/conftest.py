@@ -59,7 +59,18 @@ def oracle():
 
 
 _SWITCHES = ("ASURF_DEBUG", "ASURF_WALK_SEG", "ASURF_WALK", "ASURF_RPW", "ASURF_NO_PIPELINE", "ASURF_CUVOL_RPW",
-             "ASURF_NO_REPLAY", "ASURF_NO_SPLIT_BWD", "ASURF_EVAL", "ASURF_MASKS", "ASURF_SWEEP", "ASURF_SIDE_STREAM", "ASURF_ORDER")
+             "ASURF_NO_REPLAY", "ASURF_NO_SPLIT_BWD", "ASURF_EVAL", "ASURF_MASKS", "ASURF_SWEEP", "ASURF_SIDE_STREAM", "ASURF_ORDER",
+             "ASURF_LAZY")
+
+
+@pytest.fixture(params=["links_planes", "value_planes"])
+def planes(request):
+    """Both forms of the occupancy planes for the small batches the tests render: planes of `links` alone kept from call
+    to call, the value gates applied where a ray meets a voxel (the default up to 32 768 rays: asurf_masks2.h), and the
+    per-call planes that hold the gates (what larger batches use)."""
+    from alphasurf_amd import lib
+    lib.config_set("ASURF_LAZY", None if request.param == "links_planes" else "0")
+    return request.param
 
 
 @pytest.fixture(autouse=True)

@@ -120,7 +120,7 @@ def test_oracle_slab_constant_sigma_has_no_surface_gradient(oracle, axis):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("gate", list(SPHERE_GATES))
-def test_hip_sphere_known_answers(gate):
+def test_hip_sphere_known_answers(gate, planes):
     import hip_util
 
     def render(sc, o, d, opts, gt, fused):
@@ -143,7 +143,7 @@ def test_hip_slab_constant_sigma_has_no_surface_gradient(axis):
 @pytest.mark.gpu
 @pytest.mark.parametrize("gate", list(GATES))
 @pytest.mark.parametrize("axis", [0, 1, 2])
-def test_hip_against_closed_form(axis, gate):
+def test_hip_against_closed_form(axis, gate, planes):
     import hip_util
 
     def render(sc, o, d, opts, gt, fused):

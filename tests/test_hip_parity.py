@@ -33,7 +33,7 @@ def scene_of(oracle, z, meta):
 
 
 @pytest.mark.parametrize("name", ALL_CASES)
-def test_golden_forward(hip, oracle, name):
+def test_golden_forward(hip, oracle, planes, name):
     z, meta = load_case(name)
     sc = scene_of(oracle, z, meta)
     rgb = hip.render_forward(sc, z["origins"], z["dirs"], meta["opt"])
@@ -43,7 +43,7 @@ def test_golden_forward(hip, oracle, name):
 
 
 @pytest.mark.parametrize("name", ALL_CASES)
-def test_golden_fused(hip, oracle, name):
+def test_golden_fused(hip, oracle, planes, name):
     z, meta = load_case(name)
     sc = scene_of(oracle, z, meta)
     gt, fused = fused_args(z, meta)
@@ -156,7 +156,7 @@ AUX_SETS = {
 
 
 @pytest.mark.parametrize("auxname", list(AUX_SETS))
-def test_fused_aux_losses_vs_oracle(hip, oracle, auxname):
+def test_fused_aux_losses_vs_oracle(hip, oracle, planes, auxname):
     sc, o, d = sparse_case(9, level_set=(-0.2, 0.0, 0.3), trunc_a=4.0, fake_sample_std=0.7)
     opts = dict(sigma_thresh=-20, stop_thresh=0.0, surf_fake_sample=True, limited_fake_sample=True,
                 surf_fake_sample_min_vox_len=0.05, truncated_vol_render=True)
@@ -181,7 +181,7 @@ def test_backward_entry_point(hip, oracle):
         grad_close(g[k], go[k], GRAD_RTOL, f"grad_{k}")
 
 
-def test_edge_cases(hip, oracle):
+def test_edge_cases(hip, oracle, planes):
     from alphasurf_amd import synth
     sc = synth.make_sparse_scene(32, 4, seed=9)
     opts = OPTION_SETS["syn_yaml"]
@@ -532,7 +532,7 @@ def explained_by_sensitivity(g, go, moved, max_rows=64):
     return True, f"{len(rows)} rows on a knife edge"
 
 
-def test_random_option_fuzz(hip, oracle):
+def test_random_option_fuzz(hip, oracle, planes):
     """Randomised sweep over scenes, options and loss weights: every draw must agree with the
     oracle (RGB, gradients, masks).  Seeds are fixed; each draw is printed on failure.
     The fused losses hold sign and threshold tests (the L1 residual, sign(mean t - t_i), the inwards-normal term, alpha
