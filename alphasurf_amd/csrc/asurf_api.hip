@@ -70,7 +70,7 @@ struct Config {
     int sweep_wpb = 0;     // ASURF_SWEEP_WPB = 1, 2, 4: waves per block of k_sweep_wave (measurement)
     int sweep_rpw = 0;     // ASURF_SWEEP_RPW = 2, 4, 8, 16: rays per wave of k_sweep_wave (0: by batch size)
     int lazy_rays = -1;    // ASURF_LAZY = n: batches of up to n rays run over planes of `links` alone (asurf_masks2.h);
-                           // 0 never, -1 the default (kLazyMaxRays)
+                           // 0 never, -1 the default (kLazyMaxRays: off)
 };
 #ifdef ASURF_INSTRUMENT
 constexpr int kDebugMask = 1 | 2 | 4 | 8 | 16 | 32 | (7 << 8);
@@ -165,9 +165,14 @@ constexpr long long kOrderMinRays = 65536;
 // it is handed holds -- a function of the buffer's size alone, so a buffer has one layout.
 constexpr int kRecDepth = 32;
 // Batches up to this many rays test planes of `links` alone and apply the value gates to the voxels they meet
-// (asurf_masks2.h, k_links_planes; KOpt::lazy_gates): the per-call pass over the volume costs 0.063 ms at 256^3 whatever
-// the batch, the gates in k_sweep's exact test a few us per thousand rays.  ASURF_LAZY overrides.
-constexpr long long kLazyMaxRays = 32768;
+// (asurf_masks2.h, k_links_planes; KOpt::lazy_gates).  Built for the training script's 5 000-ray batches, where the
+// per-call pass over the volume is 0.063 of the call's 0.158 ms -- measured (MI355X, 5 184 shuffled rays of the bench
+// scene) and left OFF: the checksum of `links` takes 0.017 ms and the decision 0.006, but a ray meets 34 voxels of the
+// shell where it meets 6 work voxels, and in k_sweep's exact test each turn of 64 of them is two dependent gathers
+// (links, then values): k_sweep 0.024 -> 0.053-0.065 ms (1 to 4 rays a wave; larger task and key buffers change
+// nothing), the call 0.1617 -> 0.1519 ms without a promise and 0.1337 -> 0.148 with links_epoch.  ASURF_LAZY = n turns
+// it on for batches of up to n rays (tests/test_links_planes_gpu.py keeps the form alive).
+constexpr long long kLazyMaxRays = 0;
 // blocks of k_links_planes: as a rule they read the header, find the planes vouched for and leave -- few blocks, few
 // tickets; when the planes must be rebuilt (once per change of `links`) each takes its share of the rows
 constexpr int kLinksPlanesBlocks = 64;
@@ -718,6 +723,7 @@ int prepare(const asurf_grid* grid, const asurf_rays* rays, const asurf_render_o
                     const long long pieces = (n_links + 3) / 4;
                     const unsigned blocks = (unsigned)std::min<long long>(std::max<long long>(pieces / (256 * 8), 1), 2048);
                     hipLaunchKernelGGL(k_links_checksum, dim3(blocks), dim3(256), 0, L.stream, grid->links, n_links, hdr);
+                    prof_after("k_links_checksum", 0, L.stream);
                 }
                 hipLaunchKernelGGL(k_links_planes, dim3((unsigned)std::min(L.ML.n_rows, kLinksPlanesBlocks)), dim3(512), 0, L.stream, L.g, fw, fl,
                                    cw, cl, fy, fz, nzg, L.ML.n_rows, hdr, epoch, use_sum, zero_ptr, zero_n);
@@ -901,8 +907,9 @@ int find_candidates(const Launch& L, const asurf_rays* rays, bool record, PipeBu
                 // 0.279 against 0.296 ms; a wave with more tasks than fit takes its rays four at a time)
                 // (over planes of links alone a ray meets every voxel of the shell it crosses, five times the work voxels
                 // on the bench scene: four times the keys, twice the tasks)
-                const int task_cap = (std::min(std::max(rpw * nbmax / 2, 128) * (L.lazy ? 2 : 1), 1536) + 3) & ~3;
-                const int key_cap = (std::max((nbmax > 64 ? 2048 : (nbmax > 32 ? 1280 : 768)) * rpw / kSweepWaveRays, 256) * (L.lazy ? 4 : 1) + 15) & ~15;
+                const int lazy_tm = 2, lazy_km = 4;
+                const int task_cap = (std::min(std::max(rpw * nbmax / 2, 128) * (L.lazy ? lazy_tm : 1), 4096) + 3) & ~3;
+                const int key_cap = (std::max((nbmax > 64 ? 2048 : (nbmax > 32 ? 1280 : 768)) * rpw / kSweepWaveRays, 256) * (L.lazy ? lazy_km : 1) + 15) & ~15;
                 const int wave_bytes = (int)((size_t)rpw * sizeof(SweepRay) + (size_t)task_cap * 4 + (size_t)key_cap * 5 +
                                              sizeof(SweepWaveMisc));   // (keys + a byte each for the ray they belong to)
                 const long long waves = (Q + rpw - 1) / rpw;

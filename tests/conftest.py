@@ -63,13 +63,13 @@ _SWITCHES = ("ASURF_DEBUG", "ASURF_WALK_SEG", "ASURF_WALK", "ASURF_RPW", "ASURF_
              "ASURF_LAZY")
 
 
-@pytest.fixture(params=["links_planes", "value_planes"])
+@pytest.fixture(params=["value_planes", "links_planes"])
 def planes(request):
-    """Both forms of the occupancy planes for the small batches the tests render: planes of `links` alone kept from call
-    to call, the value gates applied where a ray meets a voxel (the default up to 32 768 rays: asurf_masks2.h), and the
-    per-call planes that hold the gates (what larger batches use)."""
+    """Both forms of the occupancy planes for the small batches the tests render: the per-call planes that hold the value
+    gates (the default), and planes of `links` alone kept from call to call with the gates applied where a ray meets a
+    voxel (asurf_masks2.h; ASURF_LAZY, off by default)."""
     from alphasurf_amd import lib
-    lib.config_set("ASURF_LAZY", None if request.param == "links_planes" else "0")
+    lib.config_set("ASURF_LAZY", "32768" if request.param == "links_planes" else None)
     return request.param
 
 

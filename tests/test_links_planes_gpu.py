@@ -2,7 +2,8 @@
 k_sweep_wave_lazy's exact test, asurf_sweep.h).  The tables the sweep leaves must be those of the per-call planes, so the
 picture is the same bit for bit and the gradients differ by the order of float atomics only; the planes must follow
 `links` -- through the call's own checksum when the caller promises nothing, through links_epoch when it does -- and
-must not follow the values.  `pytest -m gpu`."""
+must not follow the values.  The form is OFF by default (measured slower than the per-call planes it was built to
+replace: asurf_api.hip, kLazyMaxRays); ASURF_LAZY turns it on here.  `pytest -m gpu`."""
 import numpy as np
 import pytest
 from test_hip_parity import OPTION_SETS, hip, sparse_case  # noqa: F401
@@ -12,9 +13,9 @@ pytestmark = pytest.mark.gpu
 
 def _both(hip, sc, o, d, opts, gt, fused, **kw):
     from alphasurf_amd import lib
-    lib.config_set("ASURF_LAZY", "0")
-    ref = hip.render_fused(sc, o, d, opts, gt, fused, **kw)
     lib.config_set("ASURF_LAZY", None)
+    ref = hip.render_fused(sc, o, d, opts, gt, fused, **kw)
+    lib.config_set("ASURF_LAZY", "32768")
     got = hip.render_fused(sc, o, d, opts, gt, fused, **kw)
     return ref, got
 
@@ -74,9 +75,9 @@ def test_dense_scene_hands_rays_back(hip):
     gt = rs.rand(o.shape[0], 3).astype(np.float32)
     opts = dict(sigma_thresh=0.3, stop_thresh=0.0)
     from alphasurf_amd import lib
-    lib.config_set("ASURF_LAZY", "0")
-    ref = hip.render_fused(sc, o, d, opts, gt, dict(lambda_l2=1.0))
     lib.config_set("ASURF_LAZY", None)
+    ref = hip.render_fused(sc, o, d, opts, gt, dict(lambda_l2=1.0))
+    lib.config_set("ASURF_LAZY", "32768")
     got = hip.render_fused(sc, o, d, opts, gt, dict(lambda_l2=1.0))
     # (which rays are handed back depends on the capacity of the lists, and the one-kernel path sums a ray's colours in
     # another order than k_comp: an ulp, not bit equality)
@@ -135,9 +136,9 @@ def test_planes_follow_links_and_not_the_values(hip, epoch):
             links_t.copy_(torch.from_numpy(sc["links"]))
             if epoch:
                 g.links_epoch = epoch + 2
-        lib.config_set("ASURF_LAZY", "0")
-        ref = H.render_fused(cur, o, d, opts, gt, fused)
         lib.config_set("ASURF_LAZY", None)
+        ref = H.render_fused(cur, o, d, opts, gt, fused)
+        lib.config_set("ASURF_LAZY", "32768")
         got = _spec_call(H, g, r, op, gt_t, fused)
         _same(ref, got, f"step {step}")
 
@@ -147,10 +148,11 @@ def test_graph_capture_and_big_batches_through_the_same_workspace(hip):
     the header) in between makes the next small call build its planes again."""
     import torch
     H = hip
-    from alphasurf_amd import csrc_api as _C, synth
+    from alphasurf_amd import csrc_api as _C, synth, lib
     sc, o, d = sparse_case(4, level_set=(0.0,))
     opts = OPTION_SETS["syn_yaml"]
     ref = H.render_forward(sc, o, d, opts)
+    lib.config_set("ASURF_LAZY", "32768")
     ob, db = synth.random_rays(40000, 5)           # beyond the small-batch bound
     ref_big = H.render_forward(sc, ob, db, opts)
     g, r, op = H.grid_spec(sc), H.rays_spec(o, d), H.opt_spec(opts)
