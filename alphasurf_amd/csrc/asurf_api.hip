@@ -69,6 +69,7 @@ struct Config {
     int sweep_block = 0;   // ASURF_SWEEP=block: the block-synchronous form of k_sweep (round 2)
     int sweep_wpb = 0;     // ASURF_SWEEP_WPB = 1, 2, 4: waves per block of k_sweep_wave (measurement)
     int sweep_rpw = 0;     // ASURF_SWEEP_RPW = 2, 4, 8, 16: rays per wave of k_sweep_wave (0: by batch size)
+    int bwd_sh_run = 0;    // ASURF_BWD_SH=run: k_bwd_sh's sums along runs of one voxel instead of the chunk's LDS table (k_bwd_sh_tab)
     int lazy_rays = -1;    // ASURF_LAZY = n: batches of up to n rays run over planes of `links` alone (asurf_masks2.h);
                            // 0 never, -1 the default (kLazyMaxRays: off)
 };
@@ -103,6 +104,7 @@ bool config_assign(Config& c, const char* name, const char* value) {
     else if (!strcmp(name, "ASURF_SWEEP")) c.sweep_block = (value && !strcmp(value, "block")) ? 1 : 0;
     else if (!strcmp(name, "ASURF_SWEEP_WPB")) c.sweep_wpb = (n == 1 || n == 2 || n == 4) ? n : 0;
     else if (!strcmp(name, "ASURF_SWEEP_RPW")) c.sweep_rpw = (n == 1 || n == 2 || n == 4 || n == 8 || n == 16) ? n : 0;
+    else if (!strcmp(name, "ASURF_BWD_SH")) c.bwd_sh_run = (value && !strcmp(value, "run")) ? 1 : 0;
     else if (!strcmp(name, "ASURF_LAZY")) c.lazy_rays = (value && *value) ? std::max(n, 0) : -1;
     else return false;
     return true;
@@ -113,7 +115,7 @@ Config config() {  // a copy: a call works with one consistent set
         static const char* const names[] = {"ASURF_DEBUG", "ASURF_WALK_SEG", "ASURF_WALK", "ASURF_RPW", "ASURF_NO_PIPELINE",
                                             "ASURF_CUVOL_RPW", "ASURF_NO_REPLAY", "ASURF_NO_SPLIT_BWD", "ASURF_EVAL",
                                             "ASURF_TIMELINE", "ASURF_SWEEP", "ASURF_SWEEP_WPB", "ASURF_SWEEP_RPW", "ASURF_MASKS", "ASURF_SIDE_STREAM", "ASURF_ORDER",
-                                            "ASURF_LAZY"};
+                                            "ASURF_LAZY", "ASURF_BWD_SH"};
         std::lock_guard<std::mutex> lock(g_cfg_mu);
         for (const char* nm : names)
             if (const char* v = getenv(nm)) config_assign(g_cfg, nm, v);
@@ -1116,8 +1118,13 @@ int run_backward(const Launch& L, const asurf_rays* rays, const KLoss& loss, con
         hipLaunchKernelGGL(k_bwd_seq, dim3((unsigned)((Q + (kBlock / 64) * rpw - 1) / ((kBlock / 64) * rpw))), dim3(kBlock), 0,
                            L.stream, L.o, loss, L.g.trunc_a, Q, grad_in, color_cache, M, ca, cw, ct, cn, S, rpw);
         prof_after("k_bwd_seq", 2, L.stream);
+        if (config().bwd_sh_run)
         hipLaunchKernelGGL((k_bwd_sh<B>), dim3(list_blocks(Q, 8)), dim3(kBlock), 0, L.stream, L.g, G,
                            L.o.no_surf_grad_from_sh ? 0 : 1, rays->dirs, Q, S);
+        else   // (the same number of waves: its blocks are half as large)
+            hipLaunchKernelGGL((k_bwd_sh_tab<B>), dim3(list_blocks(Q, 8) * (kBlock / BwdShTab<B>::kThreads)),
+                               dim3(BwdShTab<B>::kThreads), 0, L.stream, L.g, G, L.o.no_surf_grad_from_sh ? 0 : 1,
+                               rays->dirs, Q, S);
         prof_after("k_bwd_sh", 2, L.stream);
         hipLaunchKernelGGL(k_bwd_geo, dim3(list_blocks(Q, 2)), dim3(kBlock), 0, L.stream, L.g, L.o, loss, G, rays->origins,
                            rays->dirs, Q, S);

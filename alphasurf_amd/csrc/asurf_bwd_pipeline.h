@@ -474,6 +474,212 @@ k_bwd_sh(KGrid g, KGrads G, int want_dpos, const float* __restrict__ dirs, long 
   tl.end();
 }
 
+// ------------------------------------------------------------------------------------
+// k_bwd_sh with the SH gradient rows of a whole chunk summed in LDS before they leave (round 4).
+//
+// k_bwd_sh merges along the list only: the sums of a run of samples in ONE voxel stay in registers, a face shared with
+// the next run's voxel is carried over, everything else is written out -- 3.0 rows of 27 floats a sample on the bench
+// scene (WRITE_SIZE 148 MB a launch), at 0.67 of the chip's float-atomic rate.  But the 64 samples of a chunk are
+// neighbouring rays of an image, they fall into a patch of a few dozen voxels, and the vertices of that patch are shared
+// in every direction: a row that comes back five entries later was written out and is written again.  Here a wave keeps
+// a table of kTabRows gradient rows in LDS, keyed by row number (slot = row mod kTabRows, linear probing: rows numbered
+// one after the other -- the two corners of a voxel along z, where links are in grid order -- stay neighbours in the
+// table), every sample adds its 8 x D terms there with LDS atomics (ds_add_f32: no return value, the lanes of an
+// instruction hit 8 different rows), and the chunk's rows leave once, CPR rows an instruction.  A sample one of whose
+// corners finds no place within kTabProbes probes (an incoherent batch: 512 different rows) adds to memory directly, as
+// before.  Phase A (the colour's d/dpos through the SH rows held in registers) is k_bwd_sh's.
+template <int B>
+struct BwdShTab {
+    using C = Coop<B>;
+    static constexpr int kWaves = 2;                         // waves a block (the table is 13.8 KB a wave at B = 9)
+    static constexpr int kThreads = 64 * kWaves;
+    static constexpr int kTabRows = (C::D > 27) ? 64 : 128;  // power of two
+    static constexpr int kTabProbes = 8;
+};
+
+template <int B>
+__global__ void __launch_bounds__(BwdShTab<B>::kThreads)
+k_bwd_sh_tab(KGrid g, KGrads G, int want_dpos, const float* __restrict__ dirs, long long Q, SampleRec S) {
+    const TlScope tl(6);
+    using C = Coop<B>;
+    using T = BwdShTab<B>;
+    constexpr int NT = T::kThreads, H = T::kTabRows;
+    constexpr int SP = B | 1;  // odd LDS row stride of the per-sample SH basis
+    __shared__ float s_sph[NT * SP];
+    __shared__ LaneRec s_rec[NT];
+    __shared__ float4 s_smp[NT];  // position in the voxel | real sample?   (in), d/dpos (out)
+    __shared__ float4 s_gch[NT];  // d(loss)/d(colour channel) | packed voxel
+    __shared__ float s_tab[T::kWaves][H * C::D];
+    __shared__ int s_key[T::kWaves][H];
+    __shared__ unsigned char s_slot[NT][8];   // table slot of the sample's corner; 255: none (adds go to memory)
+    __shared__ unsigned char s_used[T::kWaves][H];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    RecList RL;
+    RL.init(S);
+    const int n_list = RL.n;
+    const int wave_id = blockIdx.x * T::kWaves + (tid >> 6);
+    const int wbase = tid & ~63;
+    const float* sph_wave = s_sph + wbase * SP;
+    const LaneRec* rec_wave = s_rec + wbase;
+    float* const tab = s_tab[tid >> 6];
+    int* const key = s_key[tid >> 6];
+    unsigned char* const used = s_used[tid >> 6];
+    for (int i = lane; i < H * C::D; i += 64) tab[i] = 0.f;
+    for (int i = lane; i < H; i += 64) key[i] = -1;
+    const int half = lane >> 5, chA = (lane >> 3) & 3, cA = lane & 7;
+    const int cs = lane / C::D;
+    const int e = lane - cs * C::D;
+    const int ch = e / B;
+    const int k = e - ch * B;
+    const bool on = cs < C::CPR;
+  const int chunk = n_list >= (1 << 18) ? 64 : n_list >= (1 << 17) ? 32 : n_list >= (1 << 16) ? 16 : 8;
+  for (int base = wave_id * chunk; base < n_list; base += (int)gridDim.x * T::kWaves * chunk) {
+    const bool mine = lane < chunk && base + lane < n_list;
+    const unsigned cell = mine ? RL.cell(S, base + lane) : 0u;
+    const long long q = (long long)(cell & ((1u << kRecRayBits) - 1u));
+    const int r = (int)(cell >> kRecRayBits);
+    const unsigned long long need0 = __ballot(mine);
+    const size_t idx = (size_t)r * Q + q;
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // the previous turn's readers are done
+    if (mine) {
+        const int pv = S.v[idx];
+        const int vx = pv >> 20, vy = (pv >> 10) & 1023, vz = pv & 1023;
+        const int32_t* p = g.links + ((size_t)vx * g.offx + (size_t)vy * g.offy + vz);
+        int lk[8];
+        lk[0] = p[0];
+        lk[1] = p[1];
+        lk[2] = p[g.offy];
+        lk[3] = p[g.offy + 1];
+        lk[4] = p[g.offx];
+        lk[5] = p[g.offx + 1];
+        lk[6] = p[g.offx + g.offy];
+        lk[7] = p[g.offx + g.offy + 1];
+        float d[3] = {dirs[3 * q], dirs[3 * q + 1], dirs[3 * q + 2]};
+        float sph[B];
+        eval_sh<B>(d, sph);
+#pragma unroll
+        for (int kk = 0; kk < B; ++kk) s_sph[tid * SP + kk] = sph[kk];
+        // fake samples carry no d/dpos (surf_trav.cu:2722)
+        s_smp[tid] = make_float4(S.px[idx], S.py[idx], S.pz[idx], (S.m[idx] & 1) ? 0.f : 1.f);
+        s_gch[tid] = make_float4(S.g0[idx], S.g1[idx], S.g2[idx], __builtin_bit_cast(float, pv));
+        // the sample's 8 rows take their places in the table
+        unsigned char sl8[8];
+        bool all_in = G.grad_sh != nullptr;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            s_rec[tid].link[c] = lk[c];
+            int h = lk[c] & (H - 1), got = -1;
+            for (int pr = 0; pr < T::kTabProbes && lk[c] >= 0; ++pr) {
+                const int old = atomicCAS(&key[h], -1, lk[c]);
+                if (old == -1 || old == lk[c]) {
+                    got = h;
+                    break;
+                }
+                h = (h + 1) & (H - 1);
+            }
+            sl8[c] = (unsigned char)(got < 0 ? 255 : got);
+            all_in = all_in && got >= 0;
+        }
+#pragma unroll
+        for (int c = 0; c < 8; ++c) s_slot[tid][c] = all_in ? sl8[c] : (unsigned char)255;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    unsigned long long need = need0;
+    int held = -1;  // voxel whose SH rows this lane holds (phase A, per half)
+    float val[B];
+#pragma unroll
+    for (int kk = 0; kk < B; ++kk) val[kk] = 0.f;
+    while (need) {
+        int r0, r1;
+        bool two;
+        next_pair(need, &r0, &r1, &two);
+        // ---- phase A: per lane (channel, corner): A = w_c * gout[ch]; d/dpos through the colour ----
+        const int rr = wbase + (half ? r1 : r0);
+        const bool mineA = chA < 3 && (half == 0 || two);
+        const float4 sp = s_smp[rr];
+        const float4 sg = s_gch[rr];
+        const float gch = chA == 0 ? sg.x : chA == 1 ? sg.y : sg.z;
+        const float wx = (cA & 4) ? sp.x : 1.f - sp.x;
+        const float wy = (cA & 2) ? sp.y : 1.f - sp.y;
+        const float wz = (cA & 1) ? sp.z : 1.f - sp.z;
+        const float A = mineA ? (wx * wy * wz) * gch : 0.f;
+        if (want_dpos) {  // :2249-2264
+            const int pvA = __builtin_bit_cast(int, sg.w);
+            if (mineA && pvA != held) {
+                held = pvA;
+                const float* row = g.sh + ((size_t)s_rec[rr].link[cA] * C::D + chA * B);
+#pragma unroll
+                for (int kk = 0; kk < B; ++kk) val[kk] = row[kk];
+            }
+            float dsh = 0.f;
+#pragma unroll
+            for (int kk = 0; kk < B; ++kk) dsh = fmaf(s_sph[rr * SP + kk], val[kk], dsh);
+            const float cgd = mineA ? gch * dsh * sp.w : 0.f;
+            const float gx = dpp_sum32(cgd * (((cA & 4) ? wy : -wy) * wz));
+            const float gy = dpp_sum32(cgd * (((cA & 2) ? wx : -wx) * wz));
+            const float gz = dpp_sum32(cgd * (((cA & 1) ? wx : -wx) * wy));
+            if ((lane & 31) == 31 && (half == 0 || two)) s_smp[rr] = make_float4(gx, gy, gz, 0.f);
+        }
+        // ---- phase B: row[c][e] += A[ch(e)][c] * sph[k(e)], into the table ----
+        if (G.grad_sh != nullptr) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                if (h == 0 || two) {
+                    const int sl = h ? r1 : r0;
+                    const float sphk = on ? sph_wave[sl * SP + k] : 0.f;  // :2120-2122
+#pragma unroll
+                    for (int rd = 0; rd < C::ROUNDS; ++rd) {
+                        const int c = rd * C::CPR + cs;
+                        const float Av = __builtin_bit_cast(
+                            float, __builtin_amdgcn_ds_bpermute((h * 32 + ch * 8 + (c & 7)) << 2, __builtin_bit_cast(int, A)));
+                        if (on && c < 8) {
+                            const float v = Av * sphk;
+                            const int slot = s_slot[wbase + sl][c];
+                            if (v != 0.f) {
+                                if (slot != 255) atomicAdd(&tab[slot * C::D + e], v);
+                                else atomicAdd(&G.grad_sh[(size_t)rec_wave[sl].link[c] * C::D + e], v);
+                            }
+                        }
+                    }
+                }
+            }
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    // ---- the chunk's rows leave: the used slots in table order, CPR rows an instruction ----
+    if (G.grad_sh != nullptr) {
+        int n_used = 0;
+#pragma unroll
+        for (int h0 = 0; h0 < H; h0 += 64) {
+            const bool u = key[h0 + lane] >= 0;
+            const unsigned long long mu = __ballot(u);
+            if (u) used[n_used + __popcll(mu & ((1ull << lane) - 1ull))] = (unsigned char)(h0 + lane);
+            n_used += __popcll(mu);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        for (int i0 = 0; i0 < n_used; i0 += C::CPR) {
+            if (on && i0 + cs < n_used) {
+                const int slot = used[i0 + cs];
+                const float v = tab[slot * C::D + e];
+                tab[slot * C::D + e] = 0.f;
+                if (v != 0.f) atomicAdd(&G.grad_sh[(size_t)key[slot] * C::D + e], v);
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+#pragma unroll
+        for (int h0 = 0; h0 < H; h0 += 64) key[h0 + lane] = -1;
+    }
+    if (mine) {
+        const float4 go = want_dpos ? s_smp[tid] : make_float4(0.f, 0.f, 0.f, 0.f);
+        S.gx[idx] = go.x;
+        S.gy[idx] = go.y;
+        S.gz[idx] = go.z;
+    }
+  }
+  tl.end();
+}
+
 __device__ __forceinline__ void acc8(float* dst, const float* w) {
 #pragma unroll
     for (int c = 0; c < 8; ++c) dst[c] += w[c];
