@@ -69,7 +69,10 @@ struct Config {
     int sweep_block = 0;   // ASURF_SWEEP=block: the block-synchronous form of k_sweep (round 2)
     int sweep_wpb = 0;     // ASURF_SWEEP_WPB = 1, 2, 4: waves per block of k_sweep_wave (measurement)
     int sweep_rpw = 0;     // ASURF_SWEEP_RPW = 2, 4, 8, 16: rays per wave of k_sweep_wave (0: by batch size)
-    int bwd_sh_run = 0;    // ASURF_BWD_SH=run: k_bwd_sh's sums along runs of one voxel instead of the chunk's LDS table (k_bwd_sh_tab)
+    int bwd_sh_tab = 0;    // ASURF_BWD_SH=tab: the chunk-wide merge of the SH gradient rows (k_bwd_sh_tab) instead of k_bwd_sh's
+                           // sums along runs of one voxel (measured slower: asurf_bwd_pipeline.h)
+    int tiles = 0;         // ASURF_TILES=1: image batches (asurf_fused_params::image_width) are rendered in tile order
+                           // (measured slower with the kernels as they are: include/asurf.h)
     int lazy_rays = -1;    // ASURF_LAZY = n: batches of up to n rays run over planes of `links` alone (asurf_masks2.h);
                            // 0 never, -1 the default (kLazyMaxRays: off)
 };
@@ -104,7 +107,8 @@ bool config_assign(Config& c, const char* name, const char* value) {
     else if (!strcmp(name, "ASURF_SWEEP")) c.sweep_block = (value && !strcmp(value, "block")) ? 1 : 0;
     else if (!strcmp(name, "ASURF_SWEEP_WPB")) c.sweep_wpb = (n == 1 || n == 2 || n == 4) ? n : 0;
     else if (!strcmp(name, "ASURF_SWEEP_RPW")) c.sweep_rpw = (n == 1 || n == 2 || n == 4 || n == 8 || n == 16) ? n : 0;
-    else if (!strcmp(name, "ASURF_BWD_SH")) c.bwd_sh_run = (value && !strcmp(value, "run")) ? 1 : 0;
+    else if (!strcmp(name, "ASURF_BWD_SH")) c.bwd_sh_tab = (value && !strcmp(value, "tab")) ? 1 : 0;
+    else if (!strcmp(name, "ASURF_TILES")) c.tiles = (value && !strcmp(value, "1")) ? 1 : 0;
     else if (!strcmp(name, "ASURF_LAZY")) c.lazy_rays = (value && *value) ? std::max(n, 0) : -1;
     else return false;
     return true;
@@ -115,7 +119,7 @@ Config config() {  // a copy: a call works with one consistent set
         static const char* const names[] = {"ASURF_DEBUG", "ASURF_WALK_SEG", "ASURF_WALK", "ASURF_RPW", "ASURF_NO_PIPELINE",
                                             "ASURF_CUVOL_RPW", "ASURF_NO_REPLAY", "ASURF_NO_SPLIT_BWD", "ASURF_EVAL",
                                             "ASURF_TIMELINE", "ASURF_SWEEP", "ASURF_SWEEP_WPB", "ASURF_SWEEP_RPW", "ASURF_MASKS", "ASURF_SIDE_STREAM", "ASURF_ORDER",
-                                            "ASURF_LAZY", "ASURF_BWD_SH"};
+                                            "ASURF_LAZY", "ASURF_BWD_SH", "ASURF_TILES"};
         std::lock_guard<std::mutex> lock(g_cfg_mu);
         for (const char* nm : names)
             if (const char* v = getenv(nm)) config_assign(g_cfg, nm, v);
@@ -1118,7 +1122,7 @@ int run_backward(const Launch& L, const asurf_rays* rays, const KLoss& loss, con
         hipLaunchKernelGGL(k_bwd_seq, dim3((unsigned)((Q + (kBlock / 64) * rpw - 1) / ((kBlock / 64) * rpw))), dim3(kBlock), 0,
                            L.stream, L.o, loss, L.g.trunc_a, Q, grad_in, color_cache, M, ca, cw, ct, cn, S, rpw);
         prof_after("k_bwd_seq", 2, L.stream);
-        if (config().bwd_sh_run)
+        if (!config().bwd_sh_tab)
         hipLaunchKernelGGL((k_bwd_sh<B>), dim3(list_blocks(Q, 8)), dim3(kBlock), 0, L.stream, L.g, G,
                            L.o.no_surf_grad_from_sh ? 0 : 1, rays->dirs, Q, S);
         else   // (the same number of waves: its blocks are half as large)
@@ -1429,7 +1433,22 @@ int asurf_volume_render_surf_trav_fused(const asurf_grid* grid, const asurf_rays
     const unsigned* perm = nullptr;
     bool probe_after = false;
     const asurf_rays* rays_given = rays;
-    if (rays->n_rays >= kOrderMinRays && fused->order_rays != 1) {
+    const bool tiles = rays->n_rays >= kOrderMinRays && fused->order_rays != 1 && fused->image_width >= 16 &&
+                       rays->n_rays % fused->image_width == 0 && rays->n_rays / fused->image_width >= 16 && config().tiles;
+    if (tiles) {   // an image batch: 8 x 8 pixel tiles (asurf_order.hip, k_tile_scatter)
+        unsigned* pm = reinterpret_cast<unsigned*>(L.ws + L.ML.off_ord_perm);
+        float* o_s = reinterpret_cast<float*>(L.ws + L.ML.off_ord_o);
+        float* d_s = reinterpret_cast<float*>(L.ws + L.ML.off_ord_d);
+        float* gt_s = reinterpret_cast<float*>(L.ws + L.ML.off_ord_gt);
+        asurf_order::tile_order(rays->origins, rays->dirs, fused->rgb_gt, rays->n_rays, fused->image_width, pm, o_s, d_s, gt_s,
+                                L.stream);
+        prof_after("ray_order", 1, L.stream);
+        rays_ord.origins = o_s;
+        rays_ord.dirs = d_s;
+        rgb_gt_use = gt_s;
+        rgb_use = reinterpret_cast<float*>(L.ws + L.ML.off_ord_rgb);
+        perm = pm;
+    } else if (rays->n_rays >= kOrderMinRays && fused->order_rays != 1) {
         hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
         const bool capturing = hipStreamIsCapturing(L.stream, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone;
         int* d_probe = reinterpret_cast<int*>(L.ws + L.ML.off_ord_probe);

@@ -23,6 +23,7 @@
 #pragma once
 #include "asurf_kernels.h"
 #include "asurf_pipeline.h"
+#include "asurf_sweep.h"   // wave_incl_scan
 
 namespace asurf {
 
@@ -475,25 +476,32 @@ k_bwd_sh(KGrid g, KGrads G, int want_dpos, const float* __restrict__ dirs, long 
 }
 
 // ------------------------------------------------------------------------------------
-// k_bwd_sh with the SH gradient rows of a whole chunk summed in LDS before they leave (round 4).
+// k_bwd_sh with the SH gradient rows of a whole chunk merged before they leave (round 4; ASURF_BWD_SH=tab -- measured
+// slower than k_bwd_sh at its present occupancy and left off, see the end of this comment).
 //
 // k_bwd_sh merges along the list only: the sums of a run of samples in ONE voxel stay in registers, a face shared with
 // the next run's voxel is carried over, everything else is written out -- 3.0 rows of 27 floats a sample on the bench
-// scene (WRITE_SIZE 148 MB a launch), at 0.67 of the chip's float-atomic rate.  But the 64 samples of a chunk are
-// neighbouring rays of an image, they fall into a patch of a few dozen voxels, and the vertices of that patch are shared
-// in every direction: a row that comes back five entries later was written out and is written again.  Here a wave keeps
-// a table of kTabRows gradient rows in LDS, keyed by row number (slot = row mod kTabRows, linear probing: rows numbered
-// one after the other -- the two corners of a voxel along z, where links are in grid order -- stay neighbours in the
-// table), every sample adds its 8 x D terms there with LDS atomics (ds_add_f32: no return value, the lanes of an
-// instruction hit 8 different rows), and the chunk's rows leave once, CPR rows an instruction.  A sample one of whose
-// corners finds no place within kTabProbes probes (an incoherent batch: 512 different rows) adds to memory directly, as
-// before.  Phase A (the colour's d/dpos through the SH rows held in registers) is k_bwd_sh's.
+// scene (WRITE_SIZE 148 MB a launch).  But the 64 samples of a chunk are neighbouring rays of an image, they fall into a
+// patch of a few dozen voxels, and the vertices of that patch are shared in every direction: 2.1 distinct rows a sample
+// in image order, 1.07 when the rays come as 8 x 8 pixel tiles (asurf_fused_params::image_width; counted on the bench
+// scene).  So a wave first finds the DISTINCT rows of its chunk -- a hash table of row numbers in LDS (slot = row mod
+// kTabRows, linear probing) --, sorts the chunk's 512 (sample, corner) terms by row with a counting sort, and then walks
+// the rows, 21 at a time, lane = (row, channel): the row's terms are summed in B registers, the row's SH values are
+// loaded ONCE for the colour's d/dpos (k_bwd_sh gathers the 8 rows of every sample, pair after pair), and a row leaves
+// once.  A sample one of whose corners finds no place within kTabProbes probes (an incoherent batch: 512 different
+// rows) adds to memory directly and takes k_bwd_sh's d/dpos.
+// Measured (MI355X, config 2, wave timelines of variants/timeline.py): a chunk takes a wave 50 us here against 87-150 us
+// in k_bwd_sh, with 0.36 of the atomics -- but the tables are 14.5 KB of LDS a wave, 8 waves share a CU where k_bwd_sh
+// has 20, and the launch is four rounds of waves: 0.25 ms in tile order (0.33 in image order, where the table of 256
+// rows overflows) against k_bwd_sh's 0.17.  Forms on the way here: the row sums themselves in LDS (ds_add_f32 into a
+// 13.8 KB table, 6 waves a CU: 0.49 ms); lane = (row, coefficient), two rows a turn, every lane recomputing the term's
+// weight (188 VALU instructions a sample: 0.30 ms).  What it needs to pay: half the LDS (links reloaded for the rare
+// direct sample, 128 rows, counters aliased with the staging buffer) and k_bwd_geo merged the same way.
 template <int B>
 struct BwdShTab {
-    using C = Coop<B>;
-    static constexpr int kWaves = 2;                         // waves a block (the table is 13.8 KB a wave at B = 9)
+    static constexpr int kWaves = 4;
     static constexpr int kThreads = 64 * kWaves;
-    static constexpr int kTabRows = (C::D > 27) ? 64 : 128;  // power of two
+    static constexpr int kTabRows = 256;   // power of two (136 distinct rows a chunk of 64 in image order, 68 in tile order)
     static constexpr int kTabProbes = 8;
 };
 
@@ -504,15 +512,19 @@ k_bwd_sh_tab(KGrid g, KGrads G, int want_dpos, const float* __restrict__ dirs, l
     using C = Coop<B>;
     using T = BwdShTab<B>;
     constexpr int NT = T::kThreads, H = T::kTabRows;
-    constexpr int SP = B | 1;  // odd LDS row stride of the per-sample SH basis
+    constexpr int SP = (B + 3) & ~3;  // LDS row stride of the per-sample SH basis: rows are read whole (16-byte pieces)
     __shared__ float s_sph[NT * SP];
     __shared__ LaneRec s_rec[NT];
-    __shared__ float4 s_smp[NT];  // position in the voxel | real sample?   (in), d/dpos (out)
+    __shared__ float4 s_smp[NT];  // position in the voxel | real sample?
     __shared__ float4 s_gch[NT];  // d(loss)/d(colour channel) | packed voxel
-    __shared__ float s_tab[T::kWaves][H * C::D];
-    __shared__ int s_key[T::kWaves][H];
-    __shared__ unsigned char s_slot[NT][8];   // table slot of the sample's corner; 255: none (adds go to memory)
-    __shared__ unsigned char s_used[T::kWaves][H];
+    __shared__ float4 s_dpos[NT]; // d/dpos (out)
+    __shared__ int s_key[T::kWaves][H];             // row number of the slot (-1: free)
+    __shared__ int s_cnt32[T::kWaves][H];           // terms of the slot still to be placed (0 between chunks)
+    __shared__ unsigned short s_off[T::kWaves][H];  // first term of the slot in s_list
+    __shared__ unsigned char s_len[T::kWaves][H];   // terms of the slot (<= 64: a sample's 8 rows are different)
+    __shared__ unsigned short s_used[T::kWaves][H];
+    __shared__ unsigned short s_list[T::kWaves][512];   // sample << 3 | corner, sorted by slot
+    __shared__ float s_stage[T::kWaves][21 * C::D];     // a turn's row sums on their way to the (row, coefficient) layout
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     RecList RL;
@@ -520,13 +532,17 @@ k_bwd_sh_tab(KGrid g, KGrads G, int want_dpos, const float* __restrict__ dirs, l
     const int n_list = RL.n;
     const int wave_id = blockIdx.x * T::kWaves + (tid >> 6);
     const int wbase = tid & ~63;
-    const float* sph_wave = s_sph + wbase * SP;
     const LaneRec* rec_wave = s_rec + wbase;
-    float* const tab = s_tab[tid >> 6];
     int* const key = s_key[tid >> 6];
-    unsigned char* const used = s_used[tid >> 6];
-    for (int i = lane; i < H * C::D; i += 64) tab[i] = 0.f;
-    for (int i = lane; i < H; i += 64) key[i] = -1;
+    unsigned short* const off = s_off[tid >> 6];
+    unsigned char* const len = s_len[tid >> 6];
+    unsigned short* const used = s_used[tid >> 6];
+    unsigned short* const list = s_list[tid >> 6];
+    int* const cnt32 = s_cnt32[tid >> 6];
+    for (int i = lane; i < H; i += 64) {
+        key[i] = -1;
+        cnt32[i] = 0;
+    }
     const int half = lane >> 5, chA = (lane >> 3) & 3, cA = lane & 7;
     const int cs = lane / C::D;
     const int e = lane - cs * C::D;
@@ -539,9 +555,12 @@ k_bwd_sh_tab(KGrid g, KGrads G, int want_dpos, const float* __restrict__ dirs, l
     const unsigned cell = mine ? RL.cell(S, base + lane) : 0u;
     const long long q = (long long)(cell & ((1u << kRecRayBits) - 1u));
     const int r = (int)(cell >> kRecRayBits);
-    const unsigned long long need0 = __ballot(mine);
     const size_t idx = (size_t)r * Q + q;
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // the previous turn's readers are done
+    constexpr int kNone = 0xffff;
+    int sl8[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) sl8[c] = kNone;
     if (mine) {
         const int pv = S.v[idx];
         const int vx = pv >> 20, vy = (pv >> 10) & 1023, vz = pv & 1023;
@@ -563,8 +582,8 @@ k_bwd_sh_tab(KGrid g, KGrads G, int want_dpos, const float* __restrict__ dirs, l
         // fake samples carry no d/dpos (surf_trav.cu:2722)
         s_smp[tid] = make_float4(S.px[idx], S.py[idx], S.pz[idx], (S.m[idx] & 1) ? 0.f : 1.f);
         s_gch[tid] = make_float4(S.g0[idx], S.g1[idx], S.g2[idx], __builtin_bit_cast(float, pv));
+        s_dpos[tid] = make_float4(0.f, 0.f, 0.f, 0.f);
         // the sample's 8 rows take their places in the table
-        unsigned char sl8[8];
         bool all_in = G.grad_sh != nullptr;
 #pragma unroll
         for (int c = 0; c < 8; ++c) {
@@ -578,35 +597,166 @@ k_bwd_sh_tab(KGrid g, KGrads G, int want_dpos, const float* __restrict__ dirs, l
                 }
                 h = (h + 1) & (H - 1);
             }
-            sl8[c] = (unsigned char)(got < 0 ? 255 : got);
+            sl8[c] = got < 0 ? kNone : got;
             all_in = all_in && got >= 0;
         }
 #pragma unroll
-        for (int c = 0; c < 8; ++c) s_slot[tid][c] = all_in ? sl8[c] : (unsigned char)255;
+        for (int c = 0; c < 8; ++c) {
+            sl8[c] = all_in ? sl8[c] : kNone;
+            if (all_in) atomicAdd(&cnt32[sl8[c]], 1);
+        }
+    }
+    const unsigned long long direct = __ballot(mine && sl8[0] == kNone);   // samples that add to memory themselves
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    // ---- counting sort of the (sample, corner) terms by slot ----
+    int n_used = 0, n_terms = 0;   // (wave-uniform)
+#pragma unroll
+    for (int h0 = 0; h0 < H; h0 += 64) {
+        const int c = cnt32[h0 + lane];
+        const int incl = wave_incl_scan(c);
+        off[h0 + lane] = (unsigned short)(n_terms + incl - c);
+        len[h0 + lane] = (unsigned char)c;
+        const unsigned long long mu = __ballot(c > 0);
+        if (c > 0) used[n_used + __popcll(mu & ((1ull << lane) - 1ull))] = (unsigned short)(h0 + lane);
+        n_used += __popcll(mu);
+        n_terms += bcast_i(incl, 63);
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    unsigned long long need = need0;
-    int held = -1;  // voxel whose SH rows this lane holds (phase A, per half)
-    float val[B];
+    if (mine && sl8[0] != kNone) {
 #pragma unroll
-    for (int kk = 0; kk < B; ++kk) val[kk] = 0.f;
-    while (need) {
-        int r0, r1;
-        bool two;
-        next_pair(need, &r0, &r1, &two);
-        // ---- phase A: per lane (channel, corner): A = w_c * gout[ch]; d/dpos through the colour ----
-        const int rr = wbase + (half ? r1 : r0);
-        const bool mineA = chA < 3 && (half == 0 || two);
-        const float4 sp = s_smp[rr];
-        const float4 sg = s_gch[rr];
-        const float gch = chA == 0 ? sg.x : chA == 1 ? sg.y : sg.z;
-        const float wx = (cA & 4) ? sp.x : 1.f - sp.x;
-        const float wy = (cA & 2) ? sp.y : 1.f - sp.y;
-        const float wz = (cA & 1) ? sp.z : 1.f - sp.z;
-        const float A = mineA ? (wx * wy * wz) * gch : 0.f;
-        if (want_dpos) {  // :2249-2264
+        for (int c = 0; c < 8; ++c) {
+            const int at = atomicSub(&cnt32[sl8[c]], 1) - 1;   // (the counters are 0 again when every term is placed)
+            list[off[sl8[c]] + at] = (unsigned short)((lane << 3) | c);
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    // ---- the chunk's rows, 21 at a time: lane (row, channel) ----
+    //   gradient:  row[ch*B + k] += (w_c * gout[ch]) * sph[k] over the row's terms (:2120-2122), w_c the corner's
+    //              trilinear weight, summed in B registers; the sums go through LDS to the (row, coefficient) layout
+    //              and leave row-contiguous, CPR rows an instruction.  (A first form had lane = (row, coefficient), two
+    //              rows a turn: every lane of a row recomputed the term's weight -- 188 VALU instructions a sample.)
+    //   d/dpos of the colour (:2249-2264): a term's share is gout[ch] * <sph, row[ch]> * d(w_c)/dpos -- the row's SH
+    //              values are loaded ONCE a row, all rows of a turn together, and the shares are added to the sample's
+    //              three sums in LDS.  k_bwd_sh gathers the 8 rows of every sample, pair after pair: 32 dependent
+    //              round trips a chunk, which is what that kernel lasts (63 % of its wave cycles wait).
+    if (G.grad_sh != nullptr || want_dpos) {
+        constexpr int RPT = 21;   // rows a turn: 21 x 3 channels = 63 lanes
+        float* const stage = s_stage[tid >> 6];
+        const int rg = lane / 3, chl = lane - rg * 3;
+        for (int i0 = 0; i0 < n_used; i0 += RPT) {
+            const bool act = rg < RPT && i0 + rg < n_used;
+            const int slot = act ? used[i0 + rg] : 0;
+            const int lo = off[slot], n = act ? len[slot] : 0;
+            float acc[B], shr[B];
+#pragma unroll
+            for (int kk = 0; kk < B; ++kk) {
+                acc[kk] = 0.f;
+                shr[kk] = 0.f;
+            }
+            if (want_dpos && act) {
+                const float* row = g.sh + ((size_t)key[slot] * C::D + chl * B);
+#pragma unroll
+                for (int kk = 0; kk < B; ++kk) shr[kk] = row[kk];
+            }
+            for (int j = 0; __any(j < n); ++j) {
+                if (j < n) {
+                    const int ent = list[lo + j];
+                    const int sm = wbase + (ent >> 3), c = ent & 7;
+                    const float4 sp = s_smp[sm];
+                    const float4 sg = s_gch[sm];
+                    const float wx = (c & 4) ? sp.x : 1.f - sp.x;
+                    const float wy = (c & 2) ? sp.y : 1.f - sp.y;
+                    const float wz = (c & 1) ? sp.z : 1.f - sp.z;
+                    const float gch = chl == 0 ? sg.x : chl == 1 ? sg.y : sg.z;
+                    const float A = (wx * wy * wz) * gch;
+                    float dsh = 0.f;
+#pragma unroll
+                    for (int kk = 0; kk < B; ++kk) {
+                        const float sk = s_sph[sm * SP + kk];
+                        acc[kk] = fmaf(A, sk, acc[kk]);
+                        dsh = fmaf(sk, shr[kk], dsh);
+                    }
+                    if (want_dpos) {
+                        const float t = gch * dsh * sp.w;
+                        const float t1 = __shfl_down(t, 1), t2 = __shfl_down(t, 2);   // (the row's other two channels)
+                        const float ts = (t + t1) + t2;
+                        if (chl == 0 && ts != 0.f) {
+                            atomicAdd(&s_dpos[sm].x, ts * (((c & 4) ? wy : -wy) * wz));
+                            atomicAdd(&s_dpos[sm].y, ts * (((c & 2) ? wx : -wx) * wz));
+                            atomicAdd(&s_dpos[sm].z, ts * (((c & 1) ? wx : -wx) * wy));
+                        }
+                    }
+                }
+            }
+            if (G.grad_sh != nullptr) {
+                if (rg < RPT) {
+#pragma unroll
+                    for (int kk = 0; kk < B; ++kk) stage[rg * C::D + chl * B + kk] = acc[kk];
+                }
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                const int n_rows = min(RPT, n_used - i0);
+                for (int r0 = 0; r0 < n_rows; r0 += C::CPR) {
+                    if (on && r0 + cs < n_rows) {
+                        const float v = stage[(r0 + cs) * C::D + e];
+                        if (v != 0.f) atomicAdd(&G.grad_sh[(size_t)key[used[i0 + r0 + cs]] * C::D + e], v);
+                    }
+                }
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            }
+        }
+    }
+    if (G.grad_sh != nullptr) {
+        // samples without a place in the table: their 8 rows one after the other
+        unsigned long long dm = direct;
+        while (dm) {
+            const int sl = __ffsll((long long)dm) - 1;
+            dm &= dm - 1ull;
+            const float4 sp = s_smp[wbase + sl];
+            const float4 sg = s_gch[wbase + sl];
+            const float gch = ch == 0 ? sg.x : ch == 1 ? sg.y : sg.z;
+            const float sphk = on ? s_sph[(wbase + sl) * SP + k] : 0.f;
+#pragma unroll
+            for (int rd = 0; rd < C::ROUNDS; ++rd) {
+                const int c = rd * C::CPR + cs;
+                if (on && c < 8) {
+                    const float wx = (c & 4) ? sp.x : 1.f - sp.x;
+                    const float wy = (c & 2) ? sp.y : 1.f - sp.y;
+                    const float wz = (c & 1) ? sp.z : 1.f - sp.z;
+                    const float v = ((wx * wy * wz) * gch) * sphk;
+                    const int link = rec_wave[sl].link[c];
+                    if (v != 0.f && link >= 0) atomicAdd(&G.grad_sh[(size_t)link * C::D + e], v);
+                }
+            }
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    for (int i = lane; i < n_used; i += 64) key[used[i]] = -1;
+    // (slots claimed by a sample that then went direct hold a key and no terms: they are freed here)
+    if (direct != 0ull) {
+#pragma unroll
+        for (int h0 = 0; h0 < H; h0 += 64) key[h0 + lane] = -1;
+    }
+    // ---- phase A: d/dpos of the colour through the SH rows (k_bwd_sh's), two samples at a time ----
+    if (want_dpos && direct != 0ull) {   // (the samples without a place in the table only)
+        unsigned long long need = direct;
+        int held = -1;  // voxel whose SH rows this lane holds (per half)
+        float val[B];
+#pragma unroll
+        for (int kk = 0; kk < B; ++kk) val[kk] = 0.f;
+        while (need) {
+            int r0, r1;
+            bool two;
+            next_pair(need, &r0, &r1, &two);
+            const int rr = wbase + (half ? r1 : r0);
+            const bool mineA = chA < 3 && (half == 0 || two);
+            const float4 sp = s_smp[rr];
+            const float4 sg = s_gch[rr];
+            const float gch = chA == 0 ? sg.x : chA == 1 ? sg.y : sg.z;
+            const float wx = (cA & 4) ? sp.x : 1.f - sp.x;
+            const float wy = (cA & 2) ? sp.y : 1.f - sp.y;
+            const float wz = (cA & 1) ? sp.z : 1.f - sp.z;
             const int pvA = __builtin_bit_cast(int, sg.w);
-            if (mineA && pvA != held) {
+            if (mineA && pvA != held) {   // :2249-2264
                 held = pvA;
                 const float* row = g.sh + ((size_t)s_rec[rr].link[cA] * C::D + chA * B);
 #pragma unroll
@@ -619,59 +769,13 @@ k_bwd_sh_tab(KGrid g, KGrads G, int want_dpos, const float* __restrict__ dirs, l
             const float gx = dpp_sum32(cgd * (((cA & 4) ? wy : -wy) * wz));
             const float gy = dpp_sum32(cgd * (((cA & 2) ? wx : -wx) * wz));
             const float gz = dpp_sum32(cgd * (((cA & 1) ? wx : -wx) * wy));
-            if ((lane & 31) == 31 && (half == 0 || two)) s_smp[rr] = make_float4(gx, gy, gz, 0.f);
+            if ((lane & 31) == 31 && (half == 0 || two)) s_dpos[rr] = make_float4(gx, gy, gz, 0.f);
         }
-        // ---- phase B: row[c][e] += A[ch(e)][c] * sph[k(e)], into the table ----
-        if (G.grad_sh != nullptr) {
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                if (h == 0 || two) {
-                    const int sl = h ? r1 : r0;
-                    const float sphk = on ? sph_wave[sl * SP + k] : 0.f;  // :2120-2122
-#pragma unroll
-                    for (int rd = 0; rd < C::ROUNDS; ++rd) {
-                        const int c = rd * C::CPR + cs;
-                        const float Av = __builtin_bit_cast(
-                            float, __builtin_amdgcn_ds_bpermute((h * 32 + ch * 8 + (c & 7)) << 2, __builtin_bit_cast(int, A)));
-                        if (on && c < 8) {
-                            const float v = Av * sphk;
-                            const int slot = s_slot[wbase + sl][c];
-                            if (v != 0.f) {
-                                if (slot != 255) atomicAdd(&tab[slot * C::D + e], v);
-                                else atomicAdd(&G.grad_sh[(size_t)rec_wave[sl].link[c] * C::D + e], v);
-                            }
-                        }
-                    }
-                }
-            }
-        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    // ---- the chunk's rows leave: the used slots in table order, CPR rows an instruction ----
-    if (G.grad_sh != nullptr) {
-        int n_used = 0;
-#pragma unroll
-        for (int h0 = 0; h0 < H; h0 += 64) {
-            const bool u = key[h0 + lane] >= 0;
-            const unsigned long long mu = __ballot(u);
-            if (u) used[n_used + __popcll(mu & ((1ull << lane) - 1ull))] = (unsigned char)(h0 + lane);
-            n_used += __popcll(mu);
-        }
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        for (int i0 = 0; i0 < n_used; i0 += C::CPR) {
-            if (on && i0 + cs < n_used) {
-                const int slot = used[i0 + cs];
-                const float v = tab[slot * C::D + e];
-                tab[slot * C::D + e] = 0.f;
-                if (v != 0.f) atomicAdd(&G.grad_sh[(size_t)key[slot] * C::D + e], v);
-            }
-        }
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-#pragma unroll
-        for (int h0 = 0; h0 < H; h0 += 64) key[h0 + lane] = -1;
-    }
     if (mine) {
-        const float4 go = want_dpos ? s_smp[tid] : make_float4(0.f, 0.f, 0.f, 0.f);
+        const float4 go = want_dpos ? s_dpos[tid] : make_float4(0.f, 0.f, 0.f, 0.f);
         S.gx[idx] = go.x;
         S.gy[idx] = go.y;
         S.gz[idx] = go.z;

@@ -18,6 +18,10 @@ int order_strips(const float* origins, const float* dirs, const float* gt, long 
 void gather(const float* origins, const float* dirs, const float* gt, const unsigned* perm, long long n, float* o_s,
             float* d_s, float* gt_s, hipStream_t s);
 void scatter_rgb(const float* rgb_s, const unsigned* perm, long long n, float* rgb, hipStream_t s);
+// the rays of a row-major image of `width` pixels a row (n a multiple of it) in the order of their 8 x 8 pixel tiles:
+// perm and the rays / targets in that order
+void tile_order(const float* origins, const float* dirs, const float* gt, long long n, int width, unsigned* perm, float* o_s,
+                float* d_s, float* gt_s, hipStream_t s);
 // out3[0] = coherent pairs, out3[1] = pairs looked at, out3[2] = pairs with different origins (a sample of 8192
 // consecutive pairs)
 void probe(const float* origins, const float* dirs, long long n, int* out2, hipStream_t s);

@@ -492,6 +492,37 @@ void scatter_rgb(const float* rgb_s, const unsigned* perm, long long n, float* r
     hipLaunchKernelGGL(k_order_scatter, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, rgb_s, perm, n, rgb);
 }
 
+// Tile order of an image batch (asurf_fused_params::image_width): the n = H x W rays of a row-major image go to where
+// their 8 x 8 pixel tile comes, tiles row by row, pixels row by row inside a tile (edge tiles are narrower / lower).  The
+// 64 samples a wave of the backward kernels takes then fall into a PATCH of the surface instead of a line across it --
+// 1.07 distinct gradient rows a sample instead of 2.13 (bench scene) -- and the 16 rays of a wave of k_sweep are 2 x 8
+// pixels.  One thread a source pixel (coalesced reads; the writes are runs of 8 pixels).
+__global__ void __launch_bounds__(256)
+k_tile_scatter(const float* __restrict__ origins, const float* __restrict__ dirs, const float* __restrict__ gt, long long n,
+               int W, unsigned* __restrict__ perm, float* __restrict__ o_s, float* __restrict__ d_s, float* __restrict__ gt_s) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int H = (int)(n / W);
+    const int y = (int)(i / W), x = (int)(i - (long long)y * W);
+    const int ty = y >> 3, tx = x >> 3;
+    const int th = min(8, H - 8 * ty), tw = min(8, W - 8 * tx);
+    const long long dst = (long long)8 * ty * W + (long long)8 * tx * th + (y & 7) * tw + (x & 7);
+    perm[dst] = (unsigned)i;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        o_s[3 * dst + k] = origins[3 * i + k];
+        d_s[3 * dst + k] = dirs[3 * i + k];
+        gt_s[3 * dst + k] = gt[3 * i + k];
+    }
+}
+
+void tile_order(const float* origins, const float* dirs, const float* gt, long long n, int width, unsigned* perm, float* o_s,
+                float* d_s, float* gt_s, hipStream_t s) {
+    if (n <= 0) return;
+    hipLaunchKernelGGL(k_tile_scatter, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, origins, dirs, gt, n, width, perm,
+                       o_s, d_s, gt_s);
+}
+
 void probe(const float* origins, const float* dirs, long long n, int* out2, hipStream_t s) {
     if (n < 2) return;
     const int per_thread = 8;

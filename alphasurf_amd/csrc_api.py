@@ -318,9 +318,9 @@ def volume_render_surf_trav_fused(grid, rays, opt, rgb_gt, beta_loss, sparsity_l
                                   lambda_l_di, l_di_alpha_thresh, surf_sparse_alpha_thresh,
                                   lambda_inplace_surf_sparse, lambda_inwards_norm_loss,
                                   lambda_conv_mode_samp, l_dist_max_sample, rgb_out, grads,
-                                  global_n_rays=0, counters=None, order_rays=0, rec_depth=None):
+                                  global_n_rays=0, counters=None, order_rays=0, rec_depth=None, image_width=0):
     """void volume_render_surf_trav_fused(...) -- svox2.cpp:38-40; surf_trav.cu:3802-3942;
-    call site svox2/svox2.py:3594-3621.  `global_n_rays`, `counters` and `order_rays` (include/asurf.h,
+    call site svox2/svox2.py:3594-3621.  `global_n_rays`, `counters`, `order_rays` and `image_width` (include/asurf.h,
     asurf_fused_params) are extensions; `rec_depth`: sample records a ray the workspace is sized for (None: 32, or 128
     with fake samples; asurf_workspace_bytes_rec)."""
     g, r, o = _pack_grid(grid), _pack_rays(rays), _pack_opt(opt)
@@ -353,6 +353,7 @@ def volume_render_surf_trav_fused(grid, rays, opt, rgb_gt, beta_loss, sparsity_l
     f.l_dist_max_sample = int(l_dist_max_sample)
     f.global_n_rays = int(global_n_rays)
     f.order_rays = int(order_rays)
+    f.image_width = int(image_width)
     dev = grid.sh_data.device
     with torch.cuda.device(dev):
         # fake samples leave ten times the samples a ray: room for 128 records instead of 32, or a fifth of the rays

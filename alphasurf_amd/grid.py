@@ -572,8 +572,10 @@ class SparseGrid(nn.Module):
                             lambda_inplace_surf_sparse: float = 0.0, lambda_inwards_norm_loss: float = 0.0,
                             lambda_conv_mode_samp: float = 0.0, l_dist_max_sample: int = 64,
                             no_surface: bool = False, global_n_rays: int = 0,
-                            coherent_order: Optional[bool] = None):
+                            coherent_order: Optional[bool] = None, image_width: int = 0):
         """Render + fused loss gradients accumulated into the parameters' .grad (:3477-3638).
+        `image_width` (extension): the batch is a row-major image of that many rays a row (asurf_fused_params::image_width:
+        large batches are then rendered in the order of their 8 x 8 pixel tiles, transparently).
         `global_n_rays` (extension) = ray count of the whole data-parallel batch; `coherent_order` (extension): True
         renders a shuffled batch in a coherent order and returns the colours in the caller's order, False renders it as
         given, None leaves it to the library (asurf_fused_params::order_rays: surf_trav batches of 65 536 rays and
@@ -627,7 +629,7 @@ class SparseGrid(nn.Module):
             no_norm_weight_l_entropy, lambda_l_dist_a, lambda_l_entropy_a, lambda_l_samp_dist,
             lambda_l_di, l_di_alpha_thresh, surf_sparse_alpha_thresh, lambda_inplace_surf_sparse,
             lambda_inwards_norm_loss, lambda_conv_mode_samp, l_dist_max_sample, rgb_out, holder,
-            global_n_rays=global_n_rays, order_rays=order_rays)
+            global_n_rays=global_n_rays, order_rays=order_rays, image_width=image_width)
         self.sparse_sh_grad_indexer = self.sparse_grad_indexer.clone()
         return finish(rgb_out)
 

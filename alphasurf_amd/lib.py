@@ -77,7 +77,7 @@ FUSED_FIELDS = [
     ("surf_sparse_alpha_thresh", C.c_float), ("lambda_inplace_surf_sparse", C.c_float),
     ("lambda_inwards_norm_loss", C.c_float), ("lambda_conv_mode_samp", C.c_float),
     ("l_dist_max_sample", C.c_int32), ("global_n_rays", C.c_int64),
-    ("order_rays", C.c_int32), ("reserved_", C.c_int32),
+    ("order_rays", C.c_int32), ("image_width", C.c_int32),
 ]
 
 

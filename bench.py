@@ -40,6 +40,8 @@ def parse():
     ap.add_argument("--order-rays", type=int, default=0, choices=[0, 1, 2],
                     help="asurf_fused_params::order_rays: 0 = the library decides (orders a batch of >= 65 536 rays inside "
                          "the call when the last batch arrived shuffled), 1 = never, 2 = always")
+    ap.add_argument("--no-image-width", action="store_true",
+                    help="do not tell the call that the batch is an image (asurf_fused_params::image_width = 0)")
     ap.add_argument("--heavy", nargs="?", const="levels", default=None, choices=["levels", "fake"],
                     help="a heavier variant of the workload (never the driver's default line).  levels: three level sets "
                          "(-1, 0, 1 voxel), both crossings of each -- about 4 samples a ray instead of 0.7; fake: three level "
@@ -264,6 +266,9 @@ def main():
         o_np, d_np = o_np[perm], d_np[perm]
     Q = o_np.shape[0]
     gt_np = np.random.RandomState(7 + rank).rand(Q, 3).astype(np.float32)
+    # an image in image order is handed over as one (asurf_fused_params::image_width: large batches are then rendered in
+    # the order of their 8 x 8 pixel tiles inside the call); a shuffled batch is not an image
+    image_width = 0 if (args.shuffle or args.no_image_width) else args.width
 
     g = _C.SparseGridSpec()
     def to_dev(a):
@@ -338,7 +343,7 @@ def main():
             g, rays, opt, target, 0.0, 0.0, 0.0, True, False, F["lambda_l2"], F["lambda_l1"], 0.0,
             F["lambda_l_entropy"], False, 0.0, 0.0, 0.0, 0.0, F["l_di_alpha_thresh"],
             F["surf_sparse_alpha_thresh"], 0.0, 0.0, F["lambda_conv_mode_samp"], M, out, grads,
-            global_n_rays=Q_global, counters=counters, order_rays=args.order_rays)
+            global_n_rays=Q_global, counters=counters, order_rays=args.order_rays, image_width=image_width)
 
     def _step_pipelined():
         arena.zero_()
@@ -367,7 +372,7 @@ def main():
             g, r, opt, gt, 0.0, 0.0, 0.0, True, False, F["lambda_l2"], F["lambda_l1"], 0.0,
             F["lambda_l_entropy"], False, 0.0, 0.0, 0.0, 0.0, F["l_di_alpha_thresh"],
             F["surf_sparse_alpha_thresh"], 0.0, 0.0, F["lambda_conv_mode_samp"], M, rgb, gr,
-            global_n_rays=Q_global, counters=counters, order_rays=args.order_rays)
+            global_n_rays=Q_global, counters=counters, order_rays=args.order_rays, image_width=image_width)
         if world > 1 and exchange:
             # data-parallel exchange: sum of per-shard gradients == gradient of the global batch (alphasurf_amd/dist.py:
             # "dense" = one ring all-reduce of the whole arena, "sparse" = the rows of the union of the ranks' masks
@@ -437,7 +442,7 @@ def main():
                 g, r, opt, gt, 0.0, 0.0, 0.0, True, False, F["lambda_l2"], F["lambda_l1"], 0.0,
                 F["lambda_l_entropy"], False, 0.0, 0.0, 0.0, 0.0, F["l_di_alpha_thresh"],
                 F["surf_sparse_alpha_thresh"], 0.0, 0.0, F["lambda_conv_mode_samp"], M, rgb, gr,
-                global_n_rays=Q_global, order_rays=args.order_rays)
+                global_n_rays=Q_global, order_rays=args.order_rays, image_width=image_width)
             a, b, c = _lib.profile_read()
             t_mask.append(a), t_fwd.append(b), t_bwd.append(c)
             for name, ms in _lib.profile_read_spans():
@@ -453,7 +458,7 @@ def main():
         call_ms = t_mask + t_fwd + t_bwd
         cfg_key = dict(reso=R, basis_dim=B, width=args.width, band=args.band, shuffle=bool(args.shuffle),
                        sort=bool(args.sort), links_epoch=bool(args.links_epoch), rays=Q, heavy=args.heavy,
-                       order_rays=args.order_rays)
+                       order_rays=args.order_rays, image_width=image_width)
         roofline = build_roofline(spans, shares, dom_name, call_ms, b_f + b_b, cfg_key,
                                   args.counters or os.path.join(ROOT, "profiles", "counters.json"))
         roofline["groups_ms"] = dict(k_build_masks=round(t_mask, 4), forward=round(t_fwd, 4), backward=round(t_bwd, 4))

@@ -176,7 +176,16 @@ typedef struct asurf_fused_params {
      *      consecutive ray pairs, read back asynchronously: the first call renders as given);
      *   1: never;  2: always. */
     int32_t order_rays;
-    int32_t reserved_;
+    /* Image batches (extension): > 0 states that the batch is a row-major image (or a stack of images) of this many
+     * rays a row, n_rays a multiple of it.  With ASURF_TILES=1 (asurf_config_set) batches of 65 536 rays and more are
+     * then rendered in the order of their 8 x 8 pixel tiles (inside the call: the rays are copied in tile order, the
+     * colours scattered back; results are those of the given order): the 64 samples a wave of the backward kernels takes
+     * fall into a patch of the surface instead of a line across it -- 1.07 distinct gradient rows a sample instead of
+     * 2.13 on the bench scene.  Built for the chunk-wide merge of k_bwd_sh_tab (asurf_bwd_pipeline.h), measured on
+     * MI355X (config 2) and left OFF: the ordering costs 0.024 ms, k_sweep / k_comp / k_bwd_geo lose 0.007 / 0.013 /
+     * 0.007 ms to it, k_geom gains 0.010, and k_bwd_sh_tab at its present occupancy takes 0.25 ms where k_bwd_sh
+     * takes 0.17 in image order.  0: unknown.  (The field was `reserved_`, always 0, in ABI version 3: same layout.) */
+    int32_t image_width;
 } asurf_fused_params;
 
 /* Per-call counters (optional; pass NULL to skip).  Device buffer of
