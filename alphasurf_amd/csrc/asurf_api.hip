@@ -294,14 +294,35 @@ MaskLayout layout_for(const int32_t size[3], int64_t n_rays, int32_t M, int rec_
     L.off_ord_tmp = off;
     off = align_up(off + L.ord_tmp_bytes, 256);
     L.off_ord_probe = off;
-    off = align_up(off + (onr ? 256 : 0), 256);
+    off = align_up(off + (onr ? 3 * asurf_order::kProbeBlocks * sizeof(int) : 0), 256);
     L.total = off;
     return L;
 }
 
 // the layout of a workspace of `bytes` bytes: the deepest records that fit (kRecDepth when nothing does: the caller's size
 // check then fails as it always did)
+MaskLayout layout_fitting_uncached(const int32_t size[3], int64_t n_rays, int32_t M, size_t bytes);
+
+// (a call of a training loop asks for the layout it asked for the last time: up to three layouts, each with two rocPRIM
+// temp-size queries for batches that may be ordered, were recomputed on every call -- ADVICE r3)
 MaskLayout layout_fitting(const int32_t size[3], int64_t n_rays, int32_t M, size_t bytes) {
+    struct Key {
+        int32_t size[3];
+        int64_t n_rays;
+        int32_t M;
+        size_t bytes;
+    };
+    thread_local Key k_last = {{0, 0, 0}, -1, 0, 0};
+    thread_local MaskLayout l_last;
+    if (k_last.n_rays == n_rays && k_last.M == M && k_last.bytes == bytes && k_last.size[0] == size[0] &&
+        k_last.size[1] == size[1] && k_last.size[2] == size[2])
+        return l_last;
+    l_last = layout_fitting_uncached(size, n_rays, M, bytes);
+    k_last = Key{{size[0], size[1], size[2]}, n_rays, M, bytes};
+    return l_last;
+}
+
+MaskLayout layout_fitting_uncached(const int32_t size[3], int64_t n_rays, int32_t M, size_t bytes) {
     if (n_rays > 0)
         for (int d : kRecDepths) {
             if (d == kRecDepth) break;
@@ -597,7 +618,7 @@ int lazy_cache_lookup(void* ws, const asurf_grid* grid, bool capturing) {
 // pairs) in pinned memory, asynchronously; the next call reads it if it has arrived.  Unknown means "as given".
 struct OrderState {
     void* ws = nullptr;
-    int* h_probe = nullptr;   // pinned: coherent pairs, pairs looked at, pairs with different origins
+    int* h_probe = nullptr;   // pinned: coherent pairs, pairs looked at, pairs with different origins, per probe block
     hipEvent_t ev = nullptr;
     bool pending = false;
     int coherent = -1;        // -1 unknown, 0 shuffled, 1 coherent
@@ -620,6 +641,12 @@ int order_probe(void* ws, const float* origins, const float* dirs, long long n, 
     for (OrderState& e : g_order)
         if (e.ws == ws) slot = &e;
     if (!slot) {
+        // (a workspace the table has not met, during a capture: nothing is known, and no slot is evicted -- waiting for
+        // its probe's copy would be a synchronisation inside the capture)
+        if (capturing) {
+            *one_origin = 0;
+            return -1;
+        }
         slot = &g_order[0];
         for (OrderState& e : g_order)
             if (e.ws == nullptr || e.used < slot->used) {
@@ -639,16 +666,22 @@ int order_probe(void* ws, const float* origins, const float* dirs, long long n, 
     if (may_probe && slot->pending) {
         if (hipEventQuery(slot->ev) == hipSuccess) {
             slot->pending = false;
-            if (slot->h_probe[1] > 0) {
-                slot->coherent = (2 * slot->h_probe[0] >= slot->h_probe[1]) ? 1 : 0;
-                slot->one_origin = slot->h_probe[2] == 0 ? 1 : 0;
+            int ok = 0, seen = 0, diff = 0;
+            for (int b = 0; b < asurf_order::kProbeBlocks; ++b) {
+                ok += slot->h_probe[3 * b];
+                seen += slot->h_probe[3 * b + 1];
+                diff += slot->h_probe[3 * b + 2];
+            }
+            if (seen > 0) {
+                slot->coherent = (2 * ok >= seen) ? 1 : 0;
+                slot->one_origin = diff == 0 ? 1 : 0;
             }
         } else {
             (void)hipGetLastError();  // "not ready" is no error of this call
             may_probe = false;
         }
     }
-    if (may_probe && !slot->h_probe && hipHostMalloc(reinterpret_cast<void**>(&slot->h_probe), 3 * sizeof(int)) != hipSuccess) {
+    if (may_probe && !slot->h_probe && hipHostMalloc(reinterpret_cast<void**>(&slot->h_probe), 3 * asurf_order::kProbeBlocks * sizeof(int)) != hipSuccess) {
         slot->h_probe = nullptr;
         may_probe = false;
     }
@@ -658,7 +691,8 @@ int order_probe(void* ws, const float* origins, const float* dirs, long long n, 
     }
     if (may_probe && launch) {
         asurf_order::probe(origins, dirs, n, d_probe, stream);
-        if (hipMemcpyAsync(slot->h_probe, d_probe, 3 * sizeof(int), hipMemcpyDeviceToHost, stream) == hipSuccess &&
+        prof_after("k_order_probe", 2, stream);
+        if (hipMemcpyAsync(slot->h_probe, d_probe, 3 * asurf_order::kProbeBlocks * sizeof(int), hipMemcpyDeviceToHost, stream) == hipSuccess &&
             hipEventRecord(slot->ev, stream) == hipSuccess)
             slot->pending = true;
     }
@@ -1454,10 +1488,12 @@ int asurf_volume_render_surf_trav_fused(const asurf_grid* grid, const asurf_rays
         int* d_probe = reinterpret_cast<int*>(L.ws + L.ML.off_ord_probe);
         bool order = fused->order_rays == 2;
         int one_origin = 0;
-        if (fused->order_rays == 0) {
+        if (fused->order_rays == 0 && !capturing) {
+            // (a call that is being captured into a graph renders as given: what its replays do must not depend on
+            // what happened to be known when it was captured -- ADVICE r3; order_rays = 2 orders them)
             order = order_probe(workspace, rays->origins, rays->dirs, rays->n_rays, d_probe, L.stream, capturing,
                                 &one_origin, false) == 0;
-            probe_after = !capturing;
+            probe_after = true;
         }
         if (order) {
             unsigned* pm = reinterpret_cast<unsigned*>(L.ws + L.ML.off_ord_perm);

@@ -22,7 +22,8 @@ void scatter_rgb(const float* rgb_s, const unsigned* perm, long long n, float* r
 // perm and the rays / targets in that order
 void tile_order(const float* origins, const float* dirs, const float* gt, long long n, int width, unsigned* perm, float* o_s,
                 float* d_s, float* gt_s, hipStream_t s);
-// out3[0] = coherent pairs, out3[1] = pairs looked at, out3[2] = pairs with different origins (a sample of 8192
-// consecutive pairs)
-void probe(const float* origins, const float* dirs, long long n, int* out2, hipStream_t s);
+// out[3 b + 0 / 1 / 2], b < kProbeBlocks: coherent pairs, pairs looked at, pairs with different origins among block b's
+// share of a sample of 8192 consecutive-ray pairs (the caller adds the blocks up)
+constexpr int kProbeBlocks = 32;
+void probe(const float* origins, const float* dirs, long long n, int* out, hipStream_t s);
 }  // namespace asurf_order

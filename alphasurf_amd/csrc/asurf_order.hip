@@ -4,6 +4,7 @@
 // and one radix sort give a permutation that groups the rays of a camera (equal origins hash alike) and
 // orders each group along a Morton curve of the unit direction; the caller gathers the rays with it, renders,
 // and scatters the colours back.
+#include "asurf_order.h"
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <string.h>
@@ -111,29 +112,31 @@ k_order_scatter(const float* __restrict__ rgb_s, const unsigned* __restrict__ pe
 // point within a few pixels of each other: out[0] = such pairs, out[1] = pairs looked at, out[2] = pairs whose origins
 // differ.  One block, no atomics, no
 // buffer to clear.
-__global__ void __launch_bounds__(1024)
+// kProbeBlocks blocks of 256 threads, one pair a thread; every block leaves its three counts (the host adds them up).
+// (Round 3 ran the 8 192 pairs through ONE block of 1 024 threads, eight pairs a thread: 32 k scattered line requests
+// from a single CU -- 78 us a launch in profiles/r3_kernel_stats.csv, where the profiler's synchronisation made every
+// call launch one; a loop that runs ahead of the device skips most of them, which is why the timed steps never showed it.)
+__global__ void __launch_bounds__(256)
 k_order_probe(const float* __restrict__ origins, const float* __restrict__ dirs, long long n, long long stride,
-              int per_thread, int* __restrict__ out) {
-    __shared__ int s_ok[16], s_seen[16], s_diff[16];
+              int* __restrict__ out) {
+    __shared__ int s_ok[4], s_seen[4], s_diff[4];
     int ok = 0, seen = 0, diff = 0;
-    for (int j = 0; j < per_thread; ++j) {
-        const long long i = ((long long)j * blockDim.x + threadIdx.x) * stride;
-        if (i + 1 < n) {
-            ++seen;
-            bool same = true;
-            float dot = 0.f, na = 0.f, nb = 0.f;
+    const long long i = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * stride;
+    if (i + 1 < n) {
+        seen = 1;
+        bool same = true;
+        float dot = 0.f, na = 0.f, nb = 0.f;
 #pragma unroll
-            for (int k = 0; k < 3; ++k) {
-                same = same && (origins[3 * i + k] == origins[3 * (i + 1) + k]);
-                const float a = dirs[3 * i + k], b = dirs[3 * (i + 1) + k];
-                dot += a * b;
-                na += a * a;
-                nb += b * b;
-            }
-            // within 0.6 degrees (8 pixels of an 800-pixel, 40-degree view): cos^2 > 0.99989
-            ok += (same && dot > 0.f && dot * dot > 0.99989f * na * nb) ? 1 : 0;
-            diff += same ? 0 : 1;
+        for (int k = 0; k < 3; ++k) {
+            same = same && (origins[3 * i + k] == origins[3 * (i + 1) + k]);
+            const float a = dirs[3 * i + k], b = dirs[3 * (i + 1) + k];
+            dot += a * b;
+            na += a * a;
+            nb += b * b;
         }
+        // within 0.6 degrees (8 pixels of an 800-pixel, 40-degree view): cos^2 > 0.99989
+        ok = (same && dot > 0.f && dot * dot > 0.99989f * na * nb) ? 1 : 0;
+        diff = same ? 0 : 1;
     }
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) {
@@ -148,15 +151,9 @@ k_order_probe(const float* __restrict__ origins, const float* __restrict__ dirs,
     }
     __syncthreads();
     if (threadIdx.x == 0) {
-        int a = 0, b2 = 0, c2 = 0;
-        for (int w = 0; w < (int)(blockDim.x >> 6); ++w) {
-            a += s_ok[w];
-            b2 += s_seen[w];
-            c2 += s_diff[w];
-        }
-        out[0] = a;
-        out[1] = b2;
-        out[2] = c2;
+        out[3 * blockIdx.x + 0] = s_ok[0] + s_ok[1] + s_ok[2] + s_ok[3];
+        out[3 * blockIdx.x + 1] = s_seen[0] + s_seen[1] + s_seen[2] + s_seen[3];
+        out[3 * blockIdx.x + 2] = s_diff[0] + s_diff[1] + s_diff[2] + s_diff[3];
     }
 }
 
@@ -523,11 +520,10 @@ void tile_order(const float* origins, const float* dirs, const float* gt, long l
                        o_s, d_s, gt_s);
 }
 
-void probe(const float* origins, const float* dirs, long long n, int* out2, hipStream_t s) {
+void probe(const float* origins, const float* dirs, long long n, int* out, hipStream_t s) {
     if (n < 2) return;
-    const int per_thread = 8;
-    const long long pairs = 1024 * per_thread, stride = (n / pairs) > 1 ? (n / pairs) : 1;
-    hipLaunchKernelGGL(k_order_probe, dim3(1), dim3(1024), 0, s, origins, dirs, n, stride, per_thread, out2);
+    const long long pairs = (long long)kProbeBlocks * 256, stride = (n / pairs) > 1 ? (n / pairs) : 1;
+    hipLaunchKernelGGL(k_order_probe, dim3(kProbeBlocks), dim3(256), 0, s, origins, dirs, n, stride, out);
 }
 
 }  // namespace asurf_order

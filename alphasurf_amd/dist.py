@@ -56,7 +56,7 @@ def _union_rows(mask, group):
     return rows, int(rows.numel())
 
 
-def all_reduce_sparse(tensors, mask, group=None, extra=None, dense_above=None):
+def all_reduce_sparse(tensors, mask, group=None, extra=None, dense_above=None, dense_flat=None):
     """Sum keyed by the UNION of the ranks' touched rows (`mask_out`, render_util.cuh:138-142).
 
     One small all-reduce (max) of the masks gives every rank the same union mask and therefore the same ordered row
@@ -65,14 +65,23 @@ def all_reduce_sparse(tensors, mask, group=None, extra=None, dense_above=None):
     device: include/asurf.h).  Per rank the ring moves 2 (N-1)/N * U * row_bytes instead of ... * all_rows * row_bytes,
     with one host read (U, the buffer's size) instead of the four of a variable-size all-to-all.
     `extra`: a tensor of a few floats (grad_fake_sample_std) summed in the same collective.
-    `dense_above`: when the union exceeds this fraction of the rows the buffers are all-reduced as they are.
+    `dense_above`: when the union exceeds this fraction of the rows the buffers are all-reduced as they are --
+    `dense_flat`, when given, is the one allocation that holds them all (GradArena.flat) and is reduced instead.
     Returns "sparse" or "dense"."""
     if _world(group) == 1:
         return "single"
+    if len(tensors) != 3 or tensors[0] is None or tensors[1] is None or tensors[0].dim() != 2:
+        raise ValueError("all_reduce_sparse: tensors = [grad_sh [n, D], grad_density [n, 1], grad_surface [n, 1] or None] "
+                         f"(got {[None if t is None else tuple(t.shape) for t in tensors]}); all_reduce_dense takes any list")
     grad_sh, grad_density, grad_surface = tensors
     n, D = grad_sh.shape[0], grad_sh.shape[1]
+    if grad_density.numel() != n or (grad_surface is not None and grad_surface.numel() != n) or mask.numel() != n:
+        raise ValueError("all_reduce_sparse: grad_density, grad_surface and mask must have one entry per row of grad_sh")
     rows, U = _union_rows(mask, group)
     if dense_above is not None and U > dense_above * n:
+        if dense_flat is not None:     # the arena's buffers are ONE allocation: one ring instead of four
+            _reduce(dense_flat, dist.ReduceOp.SUM, group)
+            return "dense"
         for t in (grad_sh, grad_density, grad_surface, extra):
             if t is not None:
                 _reduce(t, dist.ReduceOp.SUM, group)
@@ -152,8 +161,10 @@ class GradArena:
             _reduce(self.flat, dist.ReduceOp.SUM, group)
             torch.gt(self.touched, 0, out=self.mask)
             return "dense"
+        # (auto beyond DENSE_ABOVE: the mask is the union already -- the flat buffer goes round in one ring)
         return all_reduce_sparse([self.grad_sh, self.grad_density, self.grad_surface], self.mask, group=group,
-                                 extra=self.grad_fake_sample_std, dense_above=DENSE_ABOVE if mode == "auto" else None)
+                                 extra=self.grad_fake_sample_std, dense_above=DENSE_ABOVE if mode == "auto" else None,
+                                 dense_flat=self.flat)
 
 
 def _pack_rows(rows, U, grad_sh, grad_density, grad_surface, packed):
@@ -210,10 +221,35 @@ class PipelinedReduce:
     collectives in the same order (mask 0, rows 0, mask 1, rows 1).  With gloo (tests, rehearsals; CPU tensors too) the
     collectives are synchronous host round trips: same results, no overlap."""
 
-    def __init__(self, device, group=None):
+    def __init__(self, device, group=None, max_parts=2, timed=False):
         self.device, self.group = torch.device(device), group
         self.side = torch.cuda.Stream(self.device) if self.device.type == "cuda" else None
         self.parts = []
+        # per part slot, allocated once (VERDICT r3 #7b: no allocation inside a step): the pinned word the row count
+        # lands in, and the packed buffer, sized on first use for EVERY row of the arena (the union can be no larger)
+        self._hosts = [torch.empty(1, dtype=torch.int32, pin_memory=True) if self.side is not None else None
+                       for _ in range(max_parts)]
+        self._packed = [None] * max_parts
+        # `timed`: events on the side stream around every part's collectives (bench.py's exchange_ms); bytes a rank
+        # hands to the collectives of a step
+        self.timed = timed and self.side is not None
+        self._ev = []
+        self.last_bytes = 0
+
+    def _packed_for(self, slot, arena, n_floats):
+        buf = self._packed[slot]
+        cap = arena.grad_sh.shape[0] * (arena.grad_sh.shape[1] + 2) + arena.grad_fake_sample_std.numel()
+        if buf is None or buf.numel() < cap or buf.device != arena.grad_sh.device:
+            buf = torch.empty(cap, dtype=arena.grad_sh.dtype, device=arena.grad_sh.device)
+            self._packed[slot] = buf
+        return buf[:n_floats]
+
+    def exchange_ms(self):
+        """Device time of the last step's collectives and their pack / list kernels on the side stream (timed=True; call
+        after a synchronisation)."""
+        ms = sum(a.elapsed_time(b) for a, b in self._ev)
+        self._ev = []
+        return ms
 
     def _on_side(self):
         import contextlib
@@ -230,17 +266,28 @@ class PipelinedReduce:
             self.parts.append(dict(arena=arena, rows=rows, U=U))
             return
         from . import csrc_api as _C
+        slot = len(self.parts)
+        if slot >= len(self._hosts):
+            raise RuntimeError(f"PipelinedReduce(max_parts={len(self._hosts)}): a step of {slot + 1} parts")
+        if slot == 0:
+            self.last_bytes = 0
         done = torch.cuda.Event()
         done.record(torch.cuda.current_stream(self.device))
         with self._on_side():
             self.side.wait_event(done)
+            if self.timed:
+                e0 = torch.cuda.Event(enable_timing=True)
+                e0.record(self.side)
             _reduce(arena.mask.view(torch.uint8), dist.ReduceOp.MAX, self.group)
             rows, count = _C.rows_list(arena.mask)
-            host = torch.empty(1, dtype=torch.int32, pin_memory=True)
+            host = self._hosts[slot]
             host.copy_(count, non_blocking=True)
-            known = torch.cuda.Event()
+            known = torch.cuda.Event(enable_timing=self.timed)
             known.record(self.side)
-        self.parts.append(dict(arena=arena, rows=rows, count=count, host=host, known=known))
+            if self.timed:
+                self._ev.append((e0, known))
+        self.last_bytes += arena.mask.numel()
+        self.parts.append(dict(arena=arena, rows=rows, count=count, host=host, known=known, slot=slot))
 
     def progress(self):
         """Host side of every submitted part that has not been packed yet: wait for its row count (the side stream
@@ -253,11 +300,23 @@ class PipelinedReduce:
                 p["U"] = int(p["host"][0])
             U, a = p["U"], p["arena"]
             W = a.grad_sh.shape[1] + 2
+            n_tail = a.grad_fake_sample_std.numel()
             with self._on_side():
-                packed = torch.empty(U * W + 1, dtype=a.grad_sh.dtype, device=a.grad_sh.device)
+                if self.timed:
+                    e0 = torch.cuda.Event(enable_timing=True)
+                    e0.record(self.side)
+                if "slot" in p:
+                    packed = self._packed_for(p["slot"], a, U * W + n_tail)
+                else:   # (CPU tensors)
+                    packed = torch.empty(U * W + n_tail, dtype=a.grad_sh.dtype, device=a.grad_sh.device)
                 _pack_rows(p["rows"], U, a.grad_sh, a.grad_density, a.grad_surface, packed)
                 packed[U * W:].copy_(a.grad_fake_sample_std.view(-1))
                 _reduce(packed, dist.ReduceOp.SUM, self.group)
+                if self.timed:
+                    e1 = torch.cuda.Event(enable_timing=True)
+                    e1.record(self.side)
+                    self._ev.append((e0, e1))
+            self.last_bytes += packed.numel() * packed.element_size()
             p.update(W=W, packed=packed)
 
     def finish(self, into):

@@ -318,7 +318,9 @@ def _image_batch(batch_size):
     """Rays per call of the whole-image renders.  The reference's `batch_size` (default 5000) guards its [Q, 64] sample
     buffers; here rays are independent and every call pays for the occupancy pyramid of the whole grid once, so a
     caller that names no batch size gets up to _IMAGE_RAYS rays a call (ASURF_IMAGE_RAYS overrides) -- at about
-    1.8 KB of cached workspace per ray (tables, candidate pool, sample records: 2 GB per stream at 2^20 rays).
+    1.8 KB of cached workspace per ray for these forward renders (tables, candidate pool: 2 GB per stream at 2^20
+    rays).  (A FUSED call keeps sample records as well: 4.5 KB a ray with 32 records, 9.7 KB with the 128 the binding
+    asks for when `surf_fake_sample` is on -- 6.2 GB at 640 k rays, csrc_api.volume_render_surf_trav_fused.)
     A batch size the caller passes is a memory bound and is kept as it is."""
     if batch_size is not None:
         return max(1, int(batch_size))

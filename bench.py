@@ -60,7 +60,8 @@ def parse():
     ap.add_argument("--graph", action="store_true",
                     help="capture one step in a HIP graph after the warm-up and replay it in the timed region")
     ap.add_argument("--cpu-rays", type=int, default=40000)
-    ap.add_argument("--exchange", default="pipelined", choices=["dense", "sparse", "auto", "pipelined"],
+    ap.add_argument("--exchange", default=os.environ.get("ASURF_EXCHANGE", "pipelined"),
+                    choices=["dense", "sparse", "auto", "pipelined"],
                     help="gradient exchange for --gpus > 1 (alphasurf_amd/dist.py).  pipelined: the rank's view is rendered as "
                          "two half batches, the first half's touched rows are exchanged while the second half renders "
                          "(dist.PipelinedReduce); the others exchange after the whole view: one ring all-reduce of all "
@@ -237,7 +238,8 @@ def main():
         backend = os.environ.get("ASURF_DIST_BACKEND", "nccl")  # "nccl" is RCCL on ROCm
         local_rank = local_rank % torch.cuda.device_count() if backend != "nccl" else local_rank
         torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend)
+        import datetime
+        dist.init_process_group(backend, timeout=datetime.timedelta(seconds=int(os.environ.get("ASURF_DIST_TIMEOUT", "300"))))
     dev = torch.device("cuda", local_rank if world > 1 else 0)
     torch.cuda.set_device(dev)
 
@@ -335,7 +337,7 @@ def main():
         gr_b = _C.GridOutputGrads()
         gr_b.grad_density_out, gr_b.grad_sh_out, gr_b.grad_surface_out = arena_b.grad_density, arena_b.grad_sh, arena_b.grad_surface
         gr_b.mask_out = arena_b.mask
-        px = adist.PipelinedReduce(dev)
+        px = adist.PipelinedReduce(dev, timed=True)
         step_epochs = itertools.count(1000)
 
     def _render(rays, target, out, grads, counters=None):
@@ -377,24 +379,21 @@ def main():
             # data-parallel exchange: sum of per-shard gradients == gradient of the global batch (alphasurf_amd/dist.py:
             # "dense" = one ring all-reduce of the whole arena, "sparse" = the rows of the union of the ranks' masks
             # only, "auto" = sparse unless the union exceeds half of the rows)
-            arena.all_reduce(mode="auto" if args.exchange == "pipelined" else args.exchange)
+            xev[0].record()
+            xmode[0] = arena.all_reduce(mode="auto" if args.exchange == "pipelined" else args.exchange)
+            xev[1].record()
+
+    xev = [torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)]
+    xmode = [None]
 
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    if pipelined:
-        # (the pipelined exchange has run over gloo only -- tests/test_dist_gpu.py --: should its first step raise on this
-        # stack, every rank raises alike and the run goes on with the exchange after the whole view)
-        try:
-            step()
-            torch.cuda.synchronize()
-        except Exception as e:  # noqa: BLE001
-            print(f"bench.py: rank {rank}: pipelined exchange failed ({e!r}); falling back to --exchange auto", file=sys.stderr)
-            pipelined = False
-            args.exchange = "auto"
-            g.links_epoch = 1 if args.links_epoch else 0
+    # (VERDICT r3 #7c: which exchange runs is decided HERE, by --exchange / ASURF_EXCHANGE, identically on every rank and
+    # before the first collective; a collective that fails raises on its rank, the process group's timeout ends the
+    # others, and the job exits non-zero -- nothing retries on a communicator that has failed)
     for _ in range(args.warmup):
         step()
     barrier()
@@ -424,6 +423,55 @@ def main():
         dt = float(tt.item())
     ms_per_step = dt / args.steps * 1e3
     value = Q_global / (dt / args.steps) / 1e6
+
+    exchange = None
+    if world > 1:
+        # ---- one more exchanged step, outside the timed region: what the exchange costs, and whether it is right ----
+        step()
+        barrier()
+        if pipelined:
+            x_ms, x_bytes, x_mode = px.exchange_ms(), px.last_bytes, "pipelined"
+        else:
+            x_ms = xev[0].elapsed_time(xev[1])
+            x_mode = xmode[0]
+            n_rows_, W_ = g.density_data.shape[0], g.sh_data.shape[1] + 2
+            x_bytes = arena.flat.numel() * 4 if x_mode == "dense" else int(arena.mask.sum().item()) * W_ * 4 + n_rows_
+        tx = torch.tensor([x_ms], device=dev, dtype=torch.float64)
+        adist._reduce(tx, dist.ReduceOp.MAX, None)
+        exchange = dict(mode=x_mode, exchange_ms=round(float(tx.item()), 4), bytes_per_rank=int(x_bytes),
+                        note="device time of the step's collectives and their list / pack kernels (max over ranks; pipelined: "
+                             "on the side stream, partly hidden behind the second half's render); bytes a rank hands to them")
+        if not args.no_verify:
+            # the arena now holds the sum over the ranks.  Rank 0 renders EVERY rank's rays alone, with the same global
+            # normaliser, into a fresh arena: sum of the shards' gradients == gradient of the whole batch
+            if rank == 0:
+                ref = adist.GradArena(g.density_data.shape[0], g.sh_data.shape[1], dev)
+                gref = _C.GridOutputGrads()
+                gref.grad_density_out, gref.grad_sh_out, gref.grad_surface_out = ref.grad_density, ref.grad_sh, ref.grad_surface
+                gref.mask_out = ref.mask
+                for rk in range(world):
+                    o_k, d_k = synth.pinhole_rays(synth.orbit_camera(rk % 8), args.width, args.width)
+                    if args.shuffle:
+                        pk = np.random.RandomState(11 + rk).permutation(o_k.shape[0])
+                        o_k, d_k = o_k[pk], d_k[pk]
+                    gt_k = torch.from_numpy(np.random.RandomState(7 + rk).rand(Q, 3).astype(np.float32)).to(dev)
+                    r_k = _C.RaysSpec()
+                    r_k.origins, r_k.dirs = torch.from_numpy(o_k).to(dev), torch.from_numpy(d_k).to(dev)
+                    r_k.masks = torch.ones(Q, dtype=torch.bool, device=dev)
+                    _render(r_k, gt_k, torch.zeros_like(gt_k), gref)
+                torch.cuda.synchronize()
+                e_x = {}
+                for k, a_, b_ in (("sh", arena.grad_sh, ref.grad_sh), ("density", arena.grad_density, ref.grad_density),
+                                  ("surface", arena.grad_surface, ref.grad_surface)):
+                    e_x[k] = float((a_ - b_).abs().max().item()) / max(float(b_.abs().max().item()), 1e-30)
+                m_ok = bool((arena.mask == ref.mask).all().item())
+                x_ok = max(e_x.values()) <= 2e-4 and m_ok and bool(ref.mask.any().item())
+                exchange["verify"] = dict(ok=x_ok, grad_rel={k: round(v, 8) for k, v in e_x.items()}, masks_equal=m_ok,
+                                          rows_touched=int(ref.mask.sum().item()), bound=2e-4,
+                                          checker=f"rank 0 alone: the {world} ranks' views rendered one after the other "
+                                                  "with the global normaliser, against the exchanged arena")
+                del ref, gref
+        barrier()
 
     out = None
     if rank == 0:
@@ -554,6 +602,8 @@ def main():
                        if world > 1 else "single GPU"},
             "roofline": roofline, "cpu_baseline": cpu, "verify": verify,
         }
+        if exchange is not None:
+            out["exchange"] = exchange
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
@@ -561,6 +611,9 @@ def main():
         print(json.dumps(out))
         if out.get("verify") is not None and not out["verify"]["ok"]:
             sys.exit("bench.py: the timed batch does NOT match the oracle: " + json.dumps(out["verify"]))
+        xv = (out.get("exchange") or {}).get("verify")
+        if xv is not None and not xv["ok"]:
+            sys.exit("bench.py: the EXCHANGED gradients do not match the single-rank render of all shards: " + json.dumps(xv))
 
 
 if __name__ == "__main__":

@@ -173,7 +173,9 @@ typedef struct asurf_fused_params {
      * them, and scatter the colours back to where the caller's rays are: rgb_out, the gradients and the masks are
      * those of the given order (up to the order of float atomics, as always).
      *   0: automatic -- ordered when the LAST batch rendered through this workspace arrived shuffled (a probe of
-     *      consecutive ray pairs, read back asynchronously: the first call renders as given);
+     *      consecutive ray pairs, read back asynchronously: the first call renders as given, and so does a call that
+     *      is being captured into a graph -- its replays must not depend on when it was captured).  Which internal
+     *      order a call takes therefore depends on timing; the results differ by the order of float atomics only;
      *   1: never;  2: always. */
     int32_t order_rays;
     /* Image batches (extension): > 0 states that the batch is a row-major image (or a stack of images) of this many

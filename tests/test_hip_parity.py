@@ -515,10 +515,12 @@ def oracle_sensitivity(oracle, sc, o, d, opts, fused, gt, go):
     return moved
 
 
-def explained_by_sensitivity(g, go, moved, max_rows=64):
+def explained_by_sensitivity(g, go, moved, max_rows=64, max_frac=0.10):
     """Wherever the HIP path differs from the oracle by more than the usual bound, the oracle itself moves by as much
-    under the perturbations of oracle_sensitivity(), and it does so in a handful of rows (a sample's voxel and the
-    neighbours its loss terms read; one ray's samples).  Returns (ok, what)."""
+    under the perturbations of oracle_sensitivity(), it does so in a handful of rows (a sample's voxel and the
+    neighbours its loss terms read; one ray's samples), and the difference stays below `max_frac` of the plane's largest
+    element: the rule must not widen itself -- an unstable oracle excuses a sample on a knife edge, not a large error
+    (VERDICT r3, weak 1a).  Returns (ok, what)."""
     rows = set()
     for k in ("sh", "density", "surface"):
         scale = float(np.abs(go[k]).max())
@@ -527,6 +529,9 @@ def explained_by_sensitivity(g, go, moved, max_rows=64):
         rows |= set(np.nonzero(over.any(axis=1))[0].tolist())
         if not (err[over] <= 1.1 * moved[k][over] + 3e-4 * scale).all():
             return False, f"grad_{k}: differs from the oracle by {float(err[over].max()):.3e} where the oracle is stable"
+        if over.any() and float(err[over].max()) > max_frac * scale:
+            return False, (f"grad_{k}: differs from the oracle by {float(err[over].max()) / scale:.3f} of the plane's maximum "
+                           f"(an explained miss may be {max_frac} of it at most)")
     if len(rows) > max_rows:
         return False, f"{len(rows)} rows differ"
     return True, f"{len(rows)} rows on a knife edge"
