@@ -40,6 +40,13 @@ def parse():
     ap.add_argument("--order-rays", type=int, default=0, choices=[0, 1, 2],
                     help="asurf_fused_params::order_rays: 0 = the library decides (orders a batch of >= 65 536 rays inside "
                          "the call when the last batch arrived shuffled), 1 = never, 2 = always")
+    ap.add_argument("--eikonal", action="store_true",
+                    help="BASELINE config 3 as stated: the step also takes the eikonal loss's gradient over all non-empty "
+                         "cells (surface_eikonal_grad_sparse; opt/opt.py:1002-1009)")
+    ap.add_argument("--no-also", action="store_true",
+                    help="the headline run (default flags, one GPU) also measures the training script's batch size, a whole "
+                         "training iteration and the two heavy scenes as child processes and reports them in `also`; "
+                         "this switches that off")
     ap.add_argument("--no-image-width", action="store_true",
                     help="do not tell the call that the batch is an image (asurf_fused_params::image_width = 0)")
     ap.add_argument("--heavy", nargs="?", const="levels", default=None, choices=["levels", "fake"],
@@ -202,6 +209,53 @@ def build_roofline(spans, shares, dom_name, call_ms, model_bytes, cfg_key, count
                 reference_model=ref_model)
 
 
+def also_lines(args):
+    """The configurations VERDICT r3 asked to see beside the headline, measured by THIS run so that the driver times
+    them: each is a child process (this script again, or variants/bench_iteration.py) that checks its own batch against
+    the oracle; a failed check or a crashed child is reported as such (`ok: false`), never dropped."""
+    import subprocess
+    here = os.path.abspath(__file__)
+    it_py = os.path.join(ROOT, "variants", "bench_iteration.py")
+    common = ["--no-cpu-baseline", "--no-also"]
+    jobs = [
+        ("rays_5184_shuffled", "opt/opt.py's batch (config_util.py:340: 5000 rays; 72 x 72 here), shuffled, links_epoch = 0",
+         [here, "--width", "72", "--shuffle", "--steps", "50", "--warmup", "10"] + common),
+        ("rays_5184_shuffled_links_epoch", "the same with the caller's promise that `links` is unchanged (what the SparseGrid mirror passes)",
+         [here, "--width", "72", "--shuffle", "--links-epoch", "--steps", "50", "--warmup", "10"] + common),
+        ("training_iteration_5184", "one iteration of surface_cuda_syn.yaml through the SparseGrid mirror at that batch size: fused "
+         "render, TV on alpha, surface TV, normal loss, alpha sparsify, three RMSprop steps (variants/bench_iteration.py)",
+         [it_py, "--rays", "5184", "--verify"]),
+        ("heavy_levels", "config 2 with three level sets (-1, 0, 1), both crossings: 4.2 samples a ray",
+         [here, "--heavy", "levels", "--steps", "10", "--warmup", "3"] + common),
+        ("heavy_fake", "config 2 with three level sets and limited fake samples: 11 samples a ray",
+         [here, "--heavy", "fake", "--steps", "10", "--warmup", "3"] + common),
+    ]
+    res = {}
+    for name, what, cmd in jobs:
+        t0 = time.perf_counter()
+        entry = dict(what=what)
+        try:
+            p = subprocess.run([sys.executable] + cmd, capture_output=True, text=True, timeout=240, cwd=ROOT)
+            line = [ln for ln in p.stdout.strip().splitlines() if ln.startswith("{")]
+            d = json.loads(line[-1]) if line else None
+            if p.returncode != 0 or d is None:
+                entry.update(ok=False, rc=p.returncode, stderr_tail=p.stderr.strip().splitlines()[-3:])
+            elif "ms_per_iteration" in d:
+                entry.update(ok=bool((d.get("verify") or {}).get("ok", False)), rays=d["rays"],
+                             ms_per_iteration=d["ms_per_iteration"], wall_ms_per_iteration=d["wall_ms_per_iteration"],
+                             Mrays_per_s=d["Mrays_per_s"], verify=d.get("verify"))
+            else:
+                entry.update(ok=bool((d.get("verify") or {}).get("ok", False)), value=d["value"], unit=d["unit"],
+                             ms_per_step=d["ms_per_step"], rays_per_step=d["config"]["rays_per_step_per_gpu"],
+                             avg_per_ray=d["config"]["avg_per_ray"], per_kernel_ms=d["roofline"]["per_kernel_ms"],
+                             verify=d.get("verify"))
+        except Exception as e:  # noqa: BLE001
+            entry.update(ok=False, error=repr(e))
+        entry["child_s"] = round(time.perf_counter() - t0, 1)
+        res[name] = entry
+    return res
+
+
 def spawn_ranks(args):
     """`python bench.py --gpus N` without a launcher: start one rank per GPU as CHILD processes through
     torch.distributed.run (nothing in this process has touched the GPU yet), pass their output through
@@ -306,6 +360,7 @@ def main():
     M = F["l_dist_max_sample"]
     Q_global = Q * world
 
+    eik_cells = torch.nonzero(g.links.view(-1) >= 0).view(-1).to(torch.int32).contiguous() if args.eikonal else None
     r_in, gt_in, rgb_user = r, gt, rgb
     if args.sort:
         r = _C.RaysSpec()
@@ -375,6 +430,8 @@ def main():
             F["lambda_l_entropy"], False, 0.0, 0.0, 0.0, 0.0, F["l_di_alpha_thresh"],
             F["surf_sparse_alpha_thresh"], 0.0, 0.0, F["lambda_conv_mode_samp"], M, rgb, gr,
             global_n_rays=Q_global, counters=counters, order_rays=args.order_rays, image_width=image_width)
+        if args.eikonal:
+            _C.surface_eikonal_grad_sparse(g.links, g.surface_data, eik_cells, None, 1e-4, 2.0 / R, arena.grad_surface)
         if world > 1 and exchange:
             # data-parallel exchange: sum of per-shard gradients == gradient of the global batch (alphasurf_amd/dist.py:
             # "dense" = one ring all-reduce of the whole arena, "sparse" = the rows of the union of the ranks' masks
@@ -592,7 +649,8 @@ def main():
                                    + ({"levels": " -- HEAVY variant: level sets (-1, 0, 1), both crossings of each",
                                        "fake": " -- HEAVY variant: level sets (-1, 0, 1), limited fake samples on"}[args.heavy]
                                       if args.heavy else "")
-                                   + ("; links unchanged from step to step (links_epoch)" if args.links_epoch else ""),
+                                   + ("; links unchanged from step to step (links_epoch)" if args.links_epoch else "")
+                                   + ("; + eikonal loss gradient over all non-empty cells in every step" if args.eikonal else ""),
                        "rays_per_step_per_gpu": Q, "active_voxels": int(g.density_data.shape[0]),
                        "avg_per_ray": {"V_t": round(v_t / Q, 2), "V_a": round(v_a / Q, 2), "S": round(s_cnt / Q, 3),
                                        "rays_with_a_sample": round(float(((rgb_user if args.sort else rgb) != 1.0)
@@ -604,6 +662,10 @@ def main():
         }
         if exchange is not None:
             out["exchange"] = exchange
+        headline = (world == 1 and R == 256 and B == 9 and args.width == 800 and args.band == 3.0 and not args.shuffle and
+                    not args.sort and not args.heavy and not args.graph and not args.links_epoch and args.order_rays == 0)
+        if headline and not args.no_also:
+            out["also"] = also_lines(args)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -106,3 +106,33 @@ def test_full_size_config(oracle, name):
     grad_close(gr_s.grad_density_out.cpu().numpy(), go["density"], 2e-4, "grad_density")
     grad_close(gr_s.grad_surface_out.cpu().numpy(), go["surface"], 2e-4, "grad_surface")
     assert (gr_s.mask_out.cpu().numpy().astype(bool) == go["mask"].astype(bool)).all()
+    # (4) BASELINE config 3 as stated -- "512^3 ... with surface-intersection + eikonal loss" (opt/opt.py:1002-1009,
+    #     svox2.py:5433-5472): the eikonal gradient over ALL non-empty cells of the full-size grid.  The oracle takes a
+    #     sample of the cells (the loss is a mean over the cells it is given: the same sample goes to both); over all
+    #     cells, the gradient and the loss are the cell-count-weighted means of those of two halves.
+    if name == "cfg3_512_sh16":
+        links_t, surf_t = sc["links"], sc["surface"]
+        cells = torch.nonzero(links_t.view(-1) >= 0).view(-1).to(torch.int32)
+        n_c = int(cells.numel())
+        assert n_c >= cfg["min_active"]
+        h = 2.0 / R                     # SparseGrid._get_h(): radius 1, R cells across
+        scale = 1e-4
+
+        def eik(c):
+            grad = torch.zeros_like(surf_t)
+            loss = _C.surface_eikonal_grad_sparse(links_t, surf_t, c.contiguous(), None, scale, h, grad)
+            torch.cuda.synchronize()
+            return grad, float(loss.item())
+        g_all, l_all = eik(cells)
+        assert torch.isfinite(g_all).all() and g_all.abs().max().item() > 0 and l_all > 0
+        half = n_c // 2
+        g_a, l_a = eik(cells[:half])
+        g_b, l_b = eik(cells[half:])
+        mix = (g_a * half + g_b * (n_c - half)) / n_c
+        assert (g_all - mix).abs().max().item() <= 2e-5 * g_all.abs().max().item()
+        assert abs(l_all - (l_a * half + l_b * (n_c - half)) / n_c) <= 1e-4 * l_all
+        samp_c = cells[torch.linspace(0, n_c - 1, 200_000, device=dev).long()].contiguous()
+        g_s, l_s = eik(samp_c)
+        go_e, lo_e, _ = oracle.surface_eikonal_grad_sparse(host["links"], host["surface"], samp_c.cpu().numpy(), scale, h)
+        grad_close(g_s.cpu().numpy(), go_e, 2e-5, "eikonal at 512^3 vs oracle")
+        assert abs(l_s - lo_e) <= 1e-4 * abs(lo_e)

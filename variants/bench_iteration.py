@@ -13,6 +13,9 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--rays", type=int, default=0, help="0: the whole 800x800 view in image order; N: N shuffled rays of it")
 ap.add_argument("--iters", type=int, default=30)
 ap.add_argument("--eikonal", action="store_true", help="also the eikonal loss (off in surface_cuda_syn.yaml)")
+ap.add_argument("--verify", action="store_true",
+                help="before the timed iterations: the batch's colours, and the gradients and masks of a sample of its rays "
+                     "rendered on their own, against the oracle (CPU restatement)")
 ap.add_argument("--graph", action="store_true", help="capture the iteration into one HIP graph (SparseGrid.capture_iteration)")
 args = ap.parse_args()
 dev = torch.device("cuda:0")
@@ -62,6 +65,40 @@ def iteration(rays=rays, gt=gt):
     grid.optim_sh_step(1e-2, beta=0.95, optim="rmsprop")
 
 
+verify = None
+if args.verify:
+    # the parameters are still the scene's: one fused render of the batch through the mirror against the oracle
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+    from oracle import oracle as O
+    osc = O.make_scene(sc["links"], sc["density"], sc["surface"], sc["sh"], sc["level_set"], sc["offset"], sc["scaling"],
+                       9, sc["fake_sample_std"], 5.0)
+    n_v = min(1500, o.shape[0])
+    vidx = np.linspace(0, o.shape[0] - 1, n_v).astype(np.int64)
+    gt_np = gt.cpu().numpy()
+    fused_o = dict(lambda_l2=F["lambda_l2"], lambda_l1=F["lambda_l1"], lambda_l_entropy=F["lambda_l_entropy"],
+                   lambda_conv_mode_samp=F["lambda_conv_mode_samp"], l_dist_max_sample=F["l_dist_max_sample"],
+                   l_di_alpha_thresh=F["l_di_alpha_thresh"], surf_sparse_alpha_thresh=F["surf_sparse_alpha_thresh"])
+    rgb_o, go, st_o = O.render_fused(osc, o[vidx], d[vidx], synth.SYN_OPTS, gt_np[vidx], fused_o)
+    kw = dict(lambda_l2=F["lambda_l2"], lambda_l1=F["lambda_l1"], lambda_l_entropy=F["lambda_l_entropy"],
+              lambda_conv_mode_samp=F["lambda_conv_mode_samp"], l_dist_max_sample=F["l_dist_max_sample"],
+              l_di_alpha_thresh=F["l_di_alpha_thresh"], surf_sparse_alpha_thresh=F["surf_sparse_alpha_thresh"])
+    rgb_batch = grid.volume_render_fused(rays, gt, **kw)["rgb"][torch.from_numpy(vidx).to(dev)].cpu().numpy()
+    for prm in (grid.density_data, grid.surface_data, grid.sh_data):
+        prm.grad.zero_()
+    vt = torch.from_numpy(vidx).to(dev)
+    rv = svox2.Rays(rays.origins[vt].contiguous(), rays.dirs[vt].contiguous())
+    rgb_v = grid.volume_render_fused(rv, gt[vt].contiguous(), **kw)["rgb"].cpu().numpy()
+    e_grad = {}
+    for k, prm in (("sh", grid.sh_data), ("density", grid.density_data), ("surface", grid.surface_data)):
+        ref = go[k]
+        e_grad[k] = float(np.abs(prm.grad.cpu().numpy().reshape(ref.shape) - ref).max()) / max(float(np.abs(ref).max()), 1e-30)
+        prm.grad.zero_()
+    m_ok = bool((grid.sparse_grad_indexer.cpu().numpy().astype(bool) == go["mask"].astype(bool)).all())
+    e_b, e_v = float(np.abs(rgb_batch - rgb_o).max()), float(np.abs(rgb_v - rgb_o).max())
+    verify = dict(ok=bool(e_b <= 2e-5 and e_v <= 2e-5 and max(e_grad.values()) <= 2e-4 and m_ok and int(st_o["n_samples"].sum()) > 0),
+                  rays=n_v, samples=int(st_o["n_samples"].sum()), rgb_linf_batch=e_b, rgb_linf=e_v,
+                  grad_rel={k: round(v, 8) for k, v in e_grad.items()}, masks_equal=m_ok,
+                  checker="oracle (CPU restatement), before the timed iterations")
 for _ in range(5):
     iteration()
 # (a run of cells that wraps around the end of the volume -- one draw in a hundred -- takes other torch kernels than the
@@ -87,4 +124,6 @@ torch.cuda.synchronize()
 wall = (time.perf_counter() - t0) / args.iters * 1e3
 ms = a.elapsed_time(b) / args.iters
 print(json.dumps(dict(graph=bool(args.graph), rays=o.shape[0], ms_per_iteration=round(ms, 3), wall_ms_per_iteration=round(wall, 3),
-                      iterations_per_s=round(1e3 / wall, 1), Mrays_per_s=round(o.shape[0] / wall / 1e3, 2))))
+                      iterations_per_s=round(1e3 / wall, 1), Mrays_per_s=round(o.shape[0] / wall / 1e3, 2), verify=verify)))
+if verify is not None and not verify["ok"]:
+    sys.exit("bench_iteration.py: the batch does NOT match the oracle: " + json.dumps(verify))
