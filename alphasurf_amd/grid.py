@@ -1143,12 +1143,15 @@ class SparseGrid(nn.Module):
         finally:
             self.__dict__["_device_rng"] = False
 
-        def step(new_rays: Rays, new_gt: torch.Tensor):
-            s_rays.origins.copy_(new_rays.origins, non_blocking=True)
-            s_rays.dirs.copy_(new_rays.dirs, non_blocking=True)
-            s_gt.copy_(new_gt, non_blocking=True)
+        def step(new_rays: Rays = None, new_gt: torch.Tensor = None):
+            # (one multi-tensor copy instead of three launches; a caller that writes its batches into the captured
+            # buffers itself -- `step.buffers` -- passes nothing and pays the replay alone)
+            if new_rays is not None:
+                torch._foreach_copy_([s_rays.origins, s_rays.dirs, s_gt], [new_rays.origins, new_rays.dirs, new_gt],
+                                     non_blocking=True)
             graph.replay()
             return outputs
+        step.buffers = (s_rays, s_gt)
         return step, outputs
 
     def _get_data_to_links(self):

@@ -112,6 +112,14 @@ N_SIMD, CLOCK_HZ, VALU_CYCLES = 1024, 2.4e9, 2   # 256 CUs x 4 SIMD-32; a wave64
 ATOMIC_KERNELS = ("k_bwd_sh", "k_bwd_geo", "k_backward_fallback")
 
 
+def config_key(a):
+    """What identifies the workload of a run (the counters of profiles/counters.json are collected per workload)."""
+    image_width = 0 if (a.shuffle or a.no_image_width) else a.width
+    return dict(reso=a.reso, basis_dim=a.basis_dim, width=a.width, band=a.band, shuffle=bool(a.shuffle),
+                sort=bool(a.sort), links_epoch=bool(a.links_epoch), rays=a.width * a.width, heavy=a.heavy,
+                order_rays=a.order_rays, image_width=image_width, eikonal=bool(getattr(a, "eikonal", False)))
+
+
 def load_counters(path, cfg_key):
     """profiles/counters.json: per-kernel PMC counters of ONE configuration (collected by variants/pmc_profile.sh:
     rocprofv3 --pmc passes over this very script).  Counters of another configuration say nothing about this run:
@@ -120,9 +128,10 @@ def load_counters(path, cfg_key):
         cj = json.load(open(path))
     except Exception:
         return None
-    if cj.get("config") != cfg_key:
-        return None
-    return cj.get("kernels")
+    for one in ([cj] + list(cj.get("sets", []))):     # (the headline's set, then the sets of other workloads)
+        if one.get("config") == cfg_key:
+            return one.get("kernels")
+    return None
 
 
 def kernel_ceilings(ms, c):
@@ -561,9 +570,8 @@ def main():
         # the dominant kernel = the longest-running one of the call
         dom_name = max(spans, key=spans.get)
         call_ms = t_mask + t_fwd + t_bwd
-        cfg_key = dict(reso=R, basis_dim=B, width=args.width, band=args.band, shuffle=bool(args.shuffle),
-                       sort=bool(args.sort), links_epoch=bool(args.links_epoch), rays=Q, heavy=args.heavy,
-                       order_rays=args.order_rays, image_width=image_width)
+        cfg_key = config_key(args)
+        assert cfg_key["rays"] == Q
         roofline = build_roofline(spans, shares, dom_name, call_ms, b_f + b_b, cfg_key,
                                   args.counters or os.path.join(ROOT, "profiles", "counters.json"))
         roofline["groups_ms"] = dict(k_build_masks=round(t_mask, 4), forward=round(t_fwd, 4), backward=round(t_bwd, 4))

@@ -13,6 +13,8 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--rays", type=int, default=0, help="0: the whole 800x800 view in image order; N: N shuffled rays of it")
 ap.add_argument("--iters", type=int, default=30)
 ap.add_argument("--eikonal", action="store_true", help="also the eikonal loss (off in surface_cuda_syn.yaml)")
+ap.add_argument("--graph-static", action="store_true",
+                help="with --graph: replay without copying a batch into the captured buffers (what the copies cost)")
 ap.add_argument("--verify", action="store_true",
                 help="before the timed iterations: the batch's colours, and the gradients and masks of a sample of its rays "
                      "rendered on their own, against the oracle (CPU restatement)")
@@ -107,7 +109,7 @@ torch.arange(4, dtype=torch.int64, device=dev).add_(3).remainder_(5).to(torch.in
 torch.cuda.synchronize()
 if args.graph:
     step, _ = grid.capture_iteration(iteration, rays, gt)
-    run = lambda: step(rays, gt)
+    run = (lambda: step()) if args.graph_static else (lambda: step(rays, gt))
     for _ in range(3):
         run()
     torch.cuda.synchronize()
@@ -123,7 +125,7 @@ b.record()
 torch.cuda.synchronize()
 wall = (time.perf_counter() - t0) / args.iters * 1e3
 ms = a.elapsed_time(b) / args.iters
-print(json.dumps(dict(graph=bool(args.graph), rays=o.shape[0], ms_per_iteration=round(ms, 3), wall_ms_per_iteration=round(wall, 3),
+print(json.dumps(dict(graph=bool(args.graph), graph_static=bool(args.graph_static), rays=o.shape[0], ms_per_iteration=round(ms, 3), wall_ms_per_iteration=round(wall, 3),
                       iterations_per_s=round(1e3 / wall, 1), Mrays_per_s=round(o.shape[0] / wall / 1e3, 2), verify=verify)))
 if verify is not None and not verify["ok"]:
     sys.exit("bench_iteration.py: the batch does NOT match the oracle: " + json.dumps(verify))

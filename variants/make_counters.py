@@ -46,9 +46,7 @@ sys.argv = cmd
 sys.path.insert(0, os.getcwd())
 import bench  # noqa: E402
 a = bench.parse()
-Q = a.width * a.width
-cfg = dict(reso=a.reso, basis_dim=a.basis_dim, width=a.width, band=a.band, shuffle=bool(a.shuffle), sort=bool(a.sort),
-           links_epoch=bool(a.links_epoch), rays=Q, heavy=a.heavy, order_rays=a.order_rays)
+cfg = bench.config_key(a)
 
 kernels = {}
 names = sorted({k for k, _ in list(fetch) + list(write) + list(sq) if k.startswith("k_")})
@@ -76,7 +74,21 @@ out = dict(
          "k_backward_fallback: every launch of k_forward / k_backward of the run averaged (one k_forward launch is "
          "bench.py's counter pass over all rays).",
     calibration=calib, kernels=kernels)
-for p in (os.path.join("profiles", f"{tag}_counters.json"), os.path.join("profiles", "counters.json")):
-    json.dump(out, open(p, "w"), indent=1)
+json.dump(out, open(os.path.join("profiles", f"{tag}_counters.json"), "w"), indent=1)
+# profiles/counters.json: the headline's set at the top level, the sets of other workloads under "sets"
+main_p = os.path.join("profiles", "counters.json")
+try:
+    main = json.load(open(main_p))
+except Exception:  # noqa: BLE001
+    main = None
+is_headline = (cfg["reso"] == 256 and cfg["basis_dim"] == 9 and cfg["width"] == 800 and not cfg["shuffle"] and not cfg["heavy"]
+               and not cfg["links_epoch"] and not cfg["eikonal"] and cfg["band"] == 3.0)
+if is_headline or main is None:
+    sets = [] if main is None else [x for x in main.get("sets", []) if x.get("config") != cfg]
+    out_main = dict(out, sets=sets)
+else:
+    sets = [x for x in main.get("sets", []) if x.get("config") != cfg] + [out]
+    out_main = dict(main, sets=sets)
+json.dump(out_main, open(main_p, "w"), indent=1)
 print(json.dumps({k: dict(hbm_MB=round(v["hbm_bytes"] / 1e6, 1), valu_M=round(v.get("valu_insts", 0) / 1e6, 2),
                           ms=v.get("trace_avg_ms")) for k, v in kernels.items()}, indent=1))

@@ -19,7 +19,7 @@ shift || true
 OUT=gpurun_out/pmc_$TAG
 mkdir -p "$OUT" profiles
 cd /tmp && export TMPDIR=/tmp && cd - >/dev/null
-BENCH="bench.py --no-cpu-baseline --no-verify --steps 3 --warmup 1 $*"
+BENCH="bench.py --no-cpu-baseline --no-verify --no-also --steps 3 --warmup 1 $*"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- python3 $BENCH > "$OUT/trace.log" 2>&1
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/fetch" -- python3 $BENCH > "$OUT/fetch.log" 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/write" -- python3 $BENCH > "$OUT/write.log" 2>&1

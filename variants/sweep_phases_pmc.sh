@@ -10,7 +10,7 @@ export ASURF_LIB=$PWD/alphasurf_amd/csrc/libasurf_hip_tl.so
 for n in 0 1 2 3 4 5; do
     export ASURF_DEBUG=$((256 * n))
     rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_LDS SQ_INSTS_SMEM \
-        --output-format csv -d "$OUT/n$n" -- python3 bench.py --no-cpu-baseline --no-verify --steps 3 --warmup 1 > "$OUT/n$n.log" 2>&1
+        --output-format csv -d "$OUT/n$n" -- python3 bench.py --no-cpu-baseline --no-verify --no-also --steps 3 --warmup 1 > "$OUT/n$n.log" 2>&1
 done
 python3 - <<'PY'
 import csv, glob

@@ -13,7 +13,7 @@ import numpy as np
 import bench
 from alphasurf_amd import lib as _L
 
-sys.argv = ["bench.py", "--no-cpu-baseline", "--steps", "3", "--warmup", "2"] + sys.argv[2:]
+sys.argv = ["bench.py", "--no-cpu-baseline", "--no-also", "--steps", "3", "--warmup", "2"] + sys.argv[2:]
 bench.main()
 cap = 1 << 18
 buf = np.zeros(cap * 3, dtype=np.uint64)
