@@ -71,6 +71,10 @@ struct Config {
     int sweep_rpw = 0;     // ASURF_SWEEP_RPW = 2, 4, 8, 16: rays per wave of k_sweep_wave (0: by batch size)
     int bwd_sh_tab = 0;    // ASURF_BWD_SH=tab: the chunk-wide merge of the SH gradient rows (k_bwd_sh_tab) instead of k_bwd_sh's
                            // sums along runs of one voxel (measured slower: asurf_bwd_pipeline.h)
+    int bwd_no_sort = 0;   // ASURF_BWD_SORT=0: k_bwd_sh / k_bwd_geo take the chunks of the record list as they lie (round 3) instead
+                           // of sorted by voxel
+    int bwd_tile = 8;      // ASURF_BWD_TILE = 0 | 4 | 8 | 16 | 32: width of the pixel tile a wave of k_bwd_seq takes of an image batch
+                           // (0: a row of 64 pixels, as for any other batch; 8 x 8 measured best)
     int tiles = 0;         // ASURF_TILES=1: image batches (asurf_fused_params::image_width) are rendered in tile order
                            // (measured slower with the kernels as they are: include/asurf.h)
     int lazy_rays = -1;    // ASURF_LAZY = n: batches of up to n rays run over planes of `links` alone (asurf_masks2.h);
@@ -108,6 +112,8 @@ bool config_assign(Config& c, const char* name, const char* value) {
     else if (!strcmp(name, "ASURF_SWEEP_WPB")) c.sweep_wpb = (n == 1 || n == 2 || n == 4) ? n : 0;
     else if (!strcmp(name, "ASURF_SWEEP_RPW")) c.sweep_rpw = (n == 1 || n == 2 || n == 4 || n == 8 || n == 16) ? n : 0;
     else if (!strcmp(name, "ASURF_BWD_SH")) c.bwd_sh_tab = (value && !strcmp(value, "tab")) ? 1 : 0;
+    else if (!strcmp(name, "ASURF_BWD_SORT")) c.bwd_no_sort = (value && !strcmp(value, "0")) ? 1 : 0;
+    else if (!strcmp(name, "ASURF_BWD_TILE")) c.bwd_tile = (!value || !*value) ? 8 : (n == 4 || n == 8 || n == 16 || n == 32) ? n : 0;
     else if (!strcmp(name, "ASURF_TILES")) c.tiles = (value && !strcmp(value, "1")) ? 1 : 0;
     else if (!strcmp(name, "ASURF_LAZY")) c.lazy_rays = (value && *value) ? std::max(n, 0) : -1;
     else return false;
@@ -119,7 +125,7 @@ Config config() {  // a copy: a call works with one consistent set
         static const char* const names[] = {"ASURF_DEBUG", "ASURF_WALK_SEG", "ASURF_WALK", "ASURF_RPW", "ASURF_NO_PIPELINE",
                                             "ASURF_CUVOL_RPW", "ASURF_NO_REPLAY", "ASURF_NO_SPLIT_BWD", "ASURF_EVAL",
                                             "ASURF_TIMELINE", "ASURF_SWEEP", "ASURF_SWEEP_WPB", "ASURF_SWEEP_RPW", "ASURF_MASKS", "ASURF_SIDE_STREAM", "ASURF_ORDER",
-                                            "ASURF_LAZY", "ASURF_BWD_SH", "ASURF_TILES"};
+                                            "ASURF_LAZY", "ASURF_BWD_SH", "ASURF_TILES", "ASURF_BWD_SORT", "ASURF_BWD_TILE"};
         std::lock_guard<std::mutex> lock(g_cfg_mu);
         for (const char* nm : names)
             if (const char* v = getenv(nm)) config_assign(g_cfg, nm, v);
@@ -1100,7 +1106,7 @@ int run_forward(const Launch& L, const asurf_rays* rays, float* rgb_out, int M, 
 template <int B>
 int run_backward(const Launch& L, const asurf_rays* rays, const KLoss& loss, const KGrads& G,
                  const float* grad_in, const float* color_cache, int M, bool fused, int mode,
-                 bool counters_zeroed = false) {
+                 bool counters_zeroed = false, int image_width = 0) {
     const float* ca = reinterpret_cast<const float*>(L.ws + L.ML.off_cache_a);
     const float* cw = reinterpret_cast<const float*>(L.ws + L.ML.off_cache_w);
     const float* ct = reinterpret_cast<const float*>(L.ws + L.ML.off_cache_t);
@@ -1153,19 +1159,24 @@ int run_backward(const Launch& L, const asurf_rays* rays, const KLoss& loss, con
             hipMemsetAsync(S.n_list, 0, kRecShards * kCtrShardStride * sizeof(int), L.stream) != hipSuccess)
             return fail(ASURF_E_LAUNCH, "hipMemsetAsync failed");
         const int rpw = rays_per_wave(Q);
+        // an image batch in row order: the record list in 2-D tiles (k_bwd_seq)
+        const int ttw = config().bwd_tile;
+        const bool tiled = image_width > 0 && ttw > 0 && rpw == 64 && image_width % ttw == 0 && Q % image_width == 0 &&
+                           (Q / image_width) % (64 / ttw) == 0;
         hipLaunchKernelGGL(k_bwd_seq, dim3((unsigned)((Q + (kBlock / 64) * rpw - 1) / ((kBlock / 64) * rpw))), dim3(kBlock), 0,
-                           L.stream, L.o, loss, L.g.trunc_a, Q, grad_in, color_cache, M, ca, cw, ct, cn, S, rpw);
+                           L.stream, L.o, loss, L.g.trunc_a, Q, grad_in, color_cache, M, ca, cw, ct, cn, S, rpw,
+                           tiled ? image_width : 0, ttw);
         prof_after("k_bwd_seq", 2, L.stream);
         if (!config().bwd_sh_tab)
         hipLaunchKernelGGL((k_bwd_sh<B>), dim3(list_blocks(Q, 8)), dim3(kBlock), 0, L.stream, L.g, G,
-                           L.o.no_surf_grad_from_sh ? 0 : 1, rays->dirs, Q, S);
+                           L.o.no_surf_grad_from_sh ? 0 : 1, rays->dirs, Q, S, config().bwd_no_sort ? 0 : 1);
         else   // (the same number of waves: its blocks are half as large)
             hipLaunchKernelGGL((k_bwd_sh_tab<B>), dim3(list_blocks(Q, 8) * (kBlock / BwdShTab<B>::kThreads)),
                                dim3(BwdShTab<B>::kThreads), 0, L.stream, L.g, G, L.o.no_surf_grad_from_sh ? 0 : 1,
                                rays->dirs, Q, S);
         prof_after("k_bwd_sh", 2, L.stream);
         hipLaunchKernelGGL(k_bwd_geo, dim3(list_blocks(Q, 2)), dim3(kBlock), 0, L.stream, L.g, L.o, loss, G, rays->origins,
-                           rays->dirs, Q, S);
+                           rays->dirs, Q, S, config().bwd_no_sort ? 0 : 1);
         prof_after("k_bwd_geo", 2, L.stream);
     } else if (mode == 1) {
         ASURF_BWD(true, false, true);
@@ -1542,7 +1553,8 @@ int asurf_volume_render_surf_trav_fused(const asurf_grid* grid, const asurf_rays
     if (rc) return rc;
     if (replay) {
         ASURF_DISPATCH_B(grid->basis_dim,
-                         run_backward<B_>(L, rays, loss, G, rgb_gt_use, rgb_use, M, true, replay_mode, pipe));
+                         run_backward<B_>(L, rays, loss, G, rgb_gt_use, rgb_use, M, true, replay_mode, pipe,
+                                          perm == nullptr ? fused->image_width : 0));
         if (rc) return rc;
         ASURF_DISPATCH_B(grid->basis_dim,
                          run_backward<B_>(side != nullptr ? Lside : L, rays, loss, G, rgb_gt_use, rgb_use, M, true, 2));

@@ -257,9 +257,19 @@ __global__ void __launch_bounds__(kBlock)
 k_bwd_seq(KOpt o, KLoss L, float trunc_a, long long Q, const float* __restrict__ rgb_gt,
           const float* __restrict__ rgb_out, int M, const float* __restrict__ cache_a,
           const float* __restrict__ cache_w, const float* __restrict__ cache_t,
-          const int* __restrict__ cache_n, SampleRec S, int rpw) {
-    // (rpw rays a wave, as k_comp)
-    const long long q = ((long long)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6)) * rpw + (threadIdx.x & 63);
+          const int* __restrict__ cache_n, SampleRec S, int rpw, int tile_w, int tile_tw) {
+    // (rpw rays a wave, as k_comp).  tile_w > 0: the batch is an image of that width in row order and a wave takes a
+    // tile of tile_tw x (64 / tile_tw) pixels of it instead of 64 pixels of a row (rpw = 64; the host has checked that
+    // the tiles partition the image): the list below is record-major within the wave, so a chunk of k_bwd_sh /
+    // k_bwd_geo is then one depth of a 2-D patch of rays, which falls into fewer voxels than a row of 64 does
+    long long q = ((long long)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6)) * rpw + (threadIdx.x & 63);
+    if (tile_w > 0) {
+        const int wg = (int)blockIdx.x * (kBlock / 64) + (int)(threadIdx.x >> 6);
+        const int tiles_x = tile_w / tile_tw, lane = (int)(threadIdx.x & 63);
+        const int ty = wg / tiles_x, tx = wg - ty * tiles_x;
+        const int ly = lane / tile_tw, lx = lane - ly * tile_tw;
+        q = (long long)(ty * (64 / tile_tw) + ly) * tile_w + tx * tile_tw + lx;
+    }
     int nt = 0;
     if ((int)(threadIdx.x & 63) < rpw && q < Q) nt = bwd_seq_ray(o, L, trunc_a, Q, q, rgb_gt, rgb_out, M, cache_a, cache_w, cache_t, cache_n, S);
     // dense list of the (record, ray) cells the backward visits, record-major within the wave
@@ -292,9 +302,33 @@ k_bwd_seq(KOpt o, KLoss L, float trunc_a, long long Q, const float* __restrict__
 }
 
 // ------------------------------------------------------------------------------------
+// The 64 keys of a wave in ascending order (bitonic network: 21 compare-exchange steps, two ds_bpermute each).
+// k_bwd_sh and k_bwd_geo sort the samples of a chunk by voxel before they merge runs of one voxel: the chunk is one
+// depth of 64 neighbouring rays, its samples fall into ~29 voxels (bench scene) that come back again and again along
+// the list -- A B A B C B ... -- and every change of voxel writes rows out.  Sorted, a voxel is ONE run, and the
+// voxel after it in the order (z fastest in the packed number) mostly shares a face with it.
+__device__ __forceinline__ unsigned long long wave_sort64(unsigned long long key) {
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int k = 2; k <= 64; k <<= 1) {
+#pragma unroll
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            const unsigned lo = __shfl_xor((unsigned)key, j), hi = __shfl_xor((unsigned)(key >> 32), j);
+            const unsigned long long other = ((unsigned long long)hi << 32) | lo;
+            const bool up = (lane & k) == 0;          // this block of k lanes sorts ascending (k = 64: all of them)
+            const bool lower = (lane & j) == 0;       // this lane keeps the smaller key of the pair when ascending
+            const bool take_min = (up == lower);
+            const bool other_less = other < key;
+            key = (take_min == other_less) ? other : key;
+        }
+    }
+    return key;
+}
+
+// ------------------------------------------------------------------------------------
 template <int B>
 __global__ void __launch_bounds__(kBlock)
-k_bwd_sh(KGrid g, KGrads G, int want_dpos, const float* __restrict__ dirs, long long Q, SampleRec S) {
+k_bwd_sh(KGrid g, KGrads G, int want_dpos, const float* __restrict__ dirs, long long Q, SampleRec S, int sort_chunk) {
     const TlScope tl(6);
     using C = Coop<B>;
     constexpr int SP = B | 1;  // odd LDS row stride of the per-sample SH basis
@@ -325,15 +359,23 @@ k_bwd_sh(KGrid g, KGrads G, int want_dpos, const float* __restrict__ dirs, long 
   // batch size: 0.049 -> 0.02 ms), a long one into chunks of 64, whose runs of one voxel merge more atomics.
   const int chunk = n_list >= (1 << 18) ? 64 : n_list >= (1 << 17) ? 32 : n_list >= (1 << 16) ? 16 : 8;
   for (int base = wave_id * chunk; base < n_list; base += (int)gridDim.x * (kBlock / 64) * chunk) {
-    const bool mine = lane < chunk && base + lane < n_list;
-    const unsigned cell = mine ? RL.cell(S, base + lane) : 0u;
+    // the chunk's entries, sorted by voxel (then by record and ray: the order of the sums does not depend on timing)
+    unsigned long long ent = ~0ull;
+    if (lane < chunk && base + lane < n_list) {
+        const unsigned c0 = RL.cell(S, base + lane);
+        const int pv0 = S.v[(size_t)(c0 >> kRecRayBits) * Q + (c0 & ((1u << kRecRayBits) - 1u))];
+        ent = ((unsigned long long)(unsigned)pv0 << 32) | c0;
+    }
+    if (sort_chunk) ent = wave_sort64(ent);
+    const bool mine = ent != ~0ull;
+    const unsigned cell = mine ? (unsigned)ent : 0u;
     const long long q = (long long)(cell & ((1u << kRecRayBits) - 1u));
     const int r = (int)(cell >> kRecRayBits);
     const unsigned long long need0 = __ballot(mine);
     const size_t idx = (size_t)r * Q + q;
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // the previous turn's readers are done
     if (mine) {
-        const int pv = S.v[idx];
+        const int pv = (int)(ent >> 32);
         const int vx = pv >> 20, vy = (pv >> 10) & 1023, vz = pv & 1023;
         const int32_t* p = g.links + ((size_t)vx * g.offx + (size_t)vy * g.offy + vz);
         s_rec[tid].link[0] = p[0];
@@ -796,7 +838,7 @@ __device__ __forceinline__ void acc8(float* dst, const float* w) {
 #endif
 __global__ void __launch_bounds__(kBlock, ASURF_BGEO_WAVES)
 k_bwd_geo(KGrid g, KOpt o, KLoss L, KGrads G, const float* __restrict__ origins,
-          const float* __restrict__ dirs, long long Q, SampleRec S) {
+          const float* __restrict__ dirs, long long Q, SampleRec S, int sort_chunk) {
     const TlScope tl(7);
   __shared__ float s_head_d[kBlock / 64][64][9], s_head_s[kBlock / 64][64][9];  // per wave: the heads' rows (see the scatter)
   __shared__ int s_head_l[kBlock / 64][64][9];
@@ -806,15 +848,22 @@ k_bwd_geo(KGrid g, KOpt o, KLoss L, KGrads G, const float* __restrict__ origins,
   const int lane = threadIdx.x & 63;
   const int wave_id = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
   for (int base = wave_id * 64; base < n_list; base += (int)gridDim.x * kBlock) {
-    const int i = base + lane;
-    const bool mine = i < n_list;
+    // the chunk's entries, sorted by voxel (wave_sort64: a voxel is one run, and most runs follow a face neighbour)
+    unsigned long long ent = ~0ull;
+    if (base + lane < n_list) {
+        const unsigned c0 = RL.cell(S, base + lane);
+        const int pv0 = S.v[(size_t)(c0 >> kRecRayBits) * Q + (c0 & ((1u << kRecRayBits) - 1u))];
+        ent = ((unsigned long long)(unsigned)pv0 << 32) | c0;
+    }
+    if (sort_chunk) ent = wave_sort64(ent);
+    const bool mine = ent != ~0ull;
     // per-sample contributions to the 8 corner rows of the density and the surface gradient
     float gd[8] = {0, 0, 0, 0, 0, 0, 0, 0}, gs[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     int lk8[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     int key = -1 - lane;  // lanes without a sample never join a run
     float gstd_acc = 0.f;
     if (mine) {
-    const unsigned cell = RL.cell(S, i);
+    const unsigned cell = (unsigned)ent;
     const long long q = (long long)(cell & ((1u << kRecRayBits) - 1u));
     const int r_i = (int)(cell >> kRecRayBits);
     const size_t idx = (size_t)r_i * Q + q;
@@ -831,7 +880,7 @@ k_bwd_geo(KGrid g, KOpt o, KLoss L, KGrads G, const float* __restrict__ origins,
     }
     setup_ray(g, o, r);
     Vox v;
-    key = S.v[idx];
+    key = (int)(ent >> 32);
     load_voxel(g, r, key, v);
 #pragma unroll
     for (int c = 0; c < 8; ++c) lk8[c] = v.lk[c];

@@ -36,6 +36,26 @@ def test_chunk_wide_merge_of_sh_rows(hip, oracle, basis_dim, optname):
         assert float(np.abs(got[1][k] - go[k]).max()) / scale <= 2e-4, k
 
 
+@pytest.mark.parametrize("basis_dim", [1, 9, 16])
+@pytest.mark.parametrize("optname", ["syn_yaml", "fake_limited", "no_sh_dpos"])
+def test_chunks_sorted_by_voxel(hip, oracle, basis_dim, optname):
+    """k_bwd_sh / k_bwd_geo take the chunks of the record list sorted by voxel (wave_sort64; the default) or as they lie
+    (ASURF_BWD_SORT=0, round 3): the same sums in another order."""
+    from alphasurf_amd import lib
+    lv = (0.0,) if optname != "fake_limited" else (-0.3, 0.0, 0.4)
+    sc, o, d = sparse_case(basis_dim, level_set=lv, trunc_a=3.0, fake_sample_std=0.8)
+    gt = np.random.RandomState(3).rand(o.shape[0], 3).astype(np.float32)
+    fused = dict(lambda_l2=0.7, lambda_l1=0.3, lambda_l_entropy=1e-4)
+    got = hip.render_fused(sc, o, d, OPTION_SETS[optname], gt, fused)
+    lib.config_set("ASURF_BWD_SORT", "0")
+    ref = hip.render_fused(sc, o, d, OPTION_SETS[optname], gt, fused)
+    _close(ref, got, optname)
+    _, go, _ = oracle.render_fused(sc, o, d, OPTION_SETS[optname], gt, fused)
+    for k in ("sh", "density", "surface"):
+        scale = max(float(np.abs(go[k]).max()), 1e-12)
+        assert float(np.abs(got[1][k] - go[k]).max()) / scale <= 2e-4, k
+
+
 def test_image_batch_in_tile_order(hip):
     """A 320 x 264 image (edge tiles: 264 = 33 x 8, the width 320 = 40 x 8; and a second image 300 wide whose last tile
     column is 4 pixels) rendered as given and in tile order, with both backward forms."""
@@ -59,6 +79,19 @@ def test_image_batch_in_tile_order(hip):
             return rgb.cpu().numpy(), H.grads_np(gr)
 
         ref = call(0)
+        # the backward's record list alone in tiles (k_bwd_seq; the default for an image batch): every tile shape, the
+        # chunks sorted by voxel and as they lie, both forms of k_bwd_sh; shapes that do not partition the image fall
+        # back to rows
+        for tile in ("8", "16", "4", "32", "0"):
+            lib.config_set("ASURF_BWD_TILE", tile)
+            for srt in (None, "0"):
+                lib.config_set("ASURF_BWD_SORT", srt)
+                for form in (None, "tab"):
+                    lib.config_set("ASURF_BWD_SH", form)
+                    _close(ref, call(width), f"{width} list tiles {tile} sort {srt} {form}")
+        lib.config_set("ASURF_BWD_TILE", None)
+        lib.config_set("ASURF_BWD_SORT", None)
+        lib.config_set("ASURF_BWD_SH", None)
         lib.config_set("ASURF_TILES", "1")
         for form in (None, "tab"):
             lib.config_set("ASURF_BWD_SH", form)
