@@ -71,8 +71,8 @@ struct Config {
     int sweep_rpw = 0;     // ASURF_SWEEP_RPW = 2, 4, 8, 16: rays per wave of k_sweep_wave (0: by batch size)
     int bwd_sh_tab = 0;    // ASURF_BWD_SH=tab: the chunk-wide merge of the SH gradient rows (k_bwd_sh_tab) instead of k_bwd_sh's
                            // sums along runs of one voxel (measured slower: asurf_bwd_pipeline.h)
-    int bwd_no_sort = 0;   // ASURF_BWD_SORT=0: k_bwd_sh / k_bwd_geo take the chunks of the record list as they lie (round 3) instead
-                           // of sorted by voxel
+    int bwd_sort = 1;      // ASURF_BWD_SORT=0: k_bwd_sh / k_bwd_geo take the chunks of the record list as they lie (round 3) instead
+                           // of sorted by voxel; =wide: two chunks sorted together whatever the list's length (tests)
     int bwd_tile = 8;      // ASURF_BWD_TILE = 0 | 4 | 8 | 16 | 32: width of the pixel tile a wave of k_bwd_seq takes of an image batch
                            // (0: a row of 64 pixels, as for any other batch; 8 x 8 measured best)
     int tiles = 0;         // ASURF_TILES=1: image batches (asurf_fused_params::image_width) are rendered in tile order
@@ -112,7 +112,7 @@ bool config_assign(Config& c, const char* name, const char* value) {
     else if (!strcmp(name, "ASURF_SWEEP_WPB")) c.sweep_wpb = (n == 1 || n == 2 || n == 4) ? n : 0;
     else if (!strcmp(name, "ASURF_SWEEP_RPW")) c.sweep_rpw = (n == 1 || n == 2 || n == 4 || n == 8 || n == 16) ? n : 0;
     else if (!strcmp(name, "ASURF_BWD_SH")) c.bwd_sh_tab = (value && !strcmp(value, "tab")) ? 1 : 0;
-    else if (!strcmp(name, "ASURF_BWD_SORT")) c.bwd_no_sort = (value && !strcmp(value, "0")) ? 1 : 0;
+    else if (!strcmp(name, "ASURF_BWD_SORT")) c.bwd_sort = (value && !strcmp(value, "0")) ? 0 : (value && !strcmp(value, "wide")) ? 2 : 1;
     else if (!strcmp(name, "ASURF_BWD_TILE")) c.bwd_tile = (!value || !*value) ? 8 : (n == 4 || n == 8 || n == 16 || n == 32) ? n : 0;
     else if (!strcmp(name, "ASURF_TILES")) c.tiles = (value && !strcmp(value, "1")) ? 1 : 0;
     else if (!strcmp(name, "ASURF_LAZY")) c.lazy_rays = (value && *value) ? std::max(n, 0) : -1;
@@ -1169,14 +1169,14 @@ int run_backward(const Launch& L, const asurf_rays* rays, const KLoss& loss, con
         prof_after("k_bwd_seq", 2, L.stream);
         if (!config().bwd_sh_tab)
         hipLaunchKernelGGL((k_bwd_sh<B>), dim3(list_blocks(Q, 8)), dim3(kBlock), 0, L.stream, L.g, G,
-                           L.o.no_surf_grad_from_sh ? 0 : 1, rays->dirs, Q, S, config().bwd_no_sort ? 0 : 1);
+                           L.o.no_surf_grad_from_sh ? 0 : 1, rays->dirs, Q, S, config().bwd_sort);
         else   // (the same number of waves: its blocks are half as large)
             hipLaunchKernelGGL((k_bwd_sh_tab<B>), dim3(list_blocks(Q, 8) * (kBlock / BwdShTab<B>::kThreads)),
                                dim3(BwdShTab<B>::kThreads), 0, L.stream, L.g, G, L.o.no_surf_grad_from_sh ? 0 : 1,
                                rays->dirs, Q, S);
         prof_after("k_bwd_sh", 2, L.stream);
         hipLaunchKernelGGL(k_bwd_geo, dim3(list_blocks(Q, 2)), dim3(kBlock), 0, L.stream, L.g, L.o, loss, G, rays->origins,
-                           rays->dirs, Q, S, config().bwd_no_sort ? 0 : 1);
+                           rays->dirs, Q, S, config().bwd_sort);
         prof_after("k_bwd_geo", 2, L.stream);
     } else if (mode == 1) {
         ASURF_BWD(true, false, true);

@@ -50,6 +50,8 @@ def test_chunks_sorted_by_voxel(hip, oracle, basis_dim, optname):
     lib.config_set("ASURF_BWD_SORT", "0")
     ref = hip.render_fused(sc, o, d, OPTION_SETS[optname], gt, fused)
     _close(ref, got, optname)
+    lib.config_set("ASURF_BWD_SORT", "wide")   # two chunks sorted together (long lists take this form by themselves)
+    _close(ref, hip.render_fused(sc, o, d, OPTION_SETS[optname], gt, fused), optname + " wide")
     _, go, _ = oracle.render_fused(sc, o, d, OPTION_SETS[optname], gt, fused)
     for k in ("sh", "density", "surface"):
         scale = max(float(np.abs(go[k]).max()), 1e-12)
@@ -84,7 +86,7 @@ def test_image_batch_in_tile_order(hip):
         # back to rows
         for tile in ("8", "16", "4", "32", "0"):
             lib.config_set("ASURF_BWD_TILE", tile)
-            for srt in (None, "0"):
+            for srt in (None, "0", "wide"):
                 lib.config_set("ASURF_BWD_SORT", srt)
                 for form in (None, "tab"):
                     lib.config_set("ASURF_BWD_SH", form)
