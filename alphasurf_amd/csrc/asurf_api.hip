@@ -1635,7 +1635,11 @@ int asurf_sgd_step(float* data, float* grad, int64_t n_rows, int32_t n_cols, con
                         0.f, 0.f, lr_last, stream);
 }
 
-size_t asurf_optim_scratch_bytes(int64_t n_rows) { return (size_t)(n_rows > 0 ? n_rows : 0) * 8 + 256; }
+size_t asurf_optim_scratch_bytes(int64_t n_rows) {
+    const size_t n = (size_t)(n_rows > 0 ? n_rows : 0);
+    const size_t n_seg = (n + kSegRows - 1) / kSegRows;   // (the segmented list: whole segments of rows + a count each)
+    return std::max(n * 8, n_seg * kSegRows * 4 + n_seg * 4) + 256;
+}
 
 // mask -> row list on the device, then the index-list step over it (its length stays on the device)
 // The masked steps build the row list on the device (k_compact_rows) so that a sparse mask costs its rows only; a mask
@@ -1721,9 +1725,29 @@ static int optim_masked(bool rms_mode, float* data, float* rms, float* grad, int
     if (n_rows <= 0) return 0;
     if (!scratch || scratch_bytes < asurf_optim_scratch_bytes(n_rows))
         return fail(ASURF_E_WORKSPACE, "optim step: scratch of %zu bytes needed", asurf_optim_scratch_bytes(n_rows));
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (n_cols <= 64 && n_rows < (1ll << 31)) {
+        // the segmented list (asurf_optim.h): n_rows ints of rows, then a count per segment
+        if (!data || !grad || (rms_mode && !rms)) return fail(ASURF_E_INVALID, "optim step: NULL tensor");
+        if (lr_last < 0.f) lr_last = lr;  // optim_kernel.cu:169
+        const long long n_seg = (n_rows + kSegRows - 1) / kSegRows;
+        int* seg_rows = reinterpret_cast<int*>(static_cast<char*>(scratch) + 256);
+        int* seg_count = seg_rows + n_seg * kSegRows;
+        hipLaunchKernelGGL(k_compact_segments, dim3((unsigned)((n_rows + kSegBlockRows - 1) / kSegBlockRows)),
+                           dim3(256), 0, s, mask, (long long)n_rows, seg_rows, seg_count);
+        int cp_shift = 0;
+        while ((1 << cp_shift) < n_cols) ++cp_shift;
+        const unsigned blocks = (unsigned)std::min<long long>(n_seg, 2048);
+        if (rms_mode)
+            hipLaunchKernelGGL((k_optim_segments<true>), dim3(blocks), dim3(256), 0, s, data, rms, grad, n_cols, cp_shift,
+                               seg_rows, seg_count, (int)n_seg, beta, lr, epsilon, minval, lr_last);
+        else
+            hipLaunchKernelGGL((k_optim_segments<false>), dim3(blocks), dim3(256), 0, s, data, rms, grad, n_cols, cp_shift,
+                               seg_rows, seg_count, (int)n_seg, beta, lr, epsilon, minval, lr_last);
+        return launch_error("k_optim_segments");
+    }
     int* count = static_cast<int*>(scratch);
     long long* rows = reinterpret_cast<long long*>(static_cast<char*>(scratch) + 256);
-    hipStream_t s = static_cast<hipStream_t>(stream);
     MaskDensity* slot = nullptr;
     if (mask_density_skip(mask, n_rows, s, &slot))   // the mask itself (dense the last time it was listed)
         return optim_launch(rms_mode, data, rms, grad, n_rows, n_cols, mask, nullptr, 0, beta, lr, epsilon, minval, lr_last,

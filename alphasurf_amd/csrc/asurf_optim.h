@@ -95,6 +95,60 @@ k_optim_rows(float* __restrict__ data, float* __restrict__ rms, float* __restric
     }
 }
 
+// ---- the masked steps of a training iteration (round 4) --------------------------------------------------------------
+// k_compact_rows allocates a block's rows in ONE list with an atomic that returns its place: 320 blocks on one address,
+// 15 us for a 1.3 M-row mask -- as long as the step itself -- and a memset in front of it.  Here the list is cut into
+// segments of kSegRows rows of the mask: a block lists the rows of its four segments with ballots, writes each segment's
+// count, and nothing is shared between blocks; the step's blocks take segments in turn, a lane group a listed row.
+// A full mask costs the step what the mask walk cost it (a count a segment instead of a byte a row), a sparse one its
+// rows plus a count per segment -- no decision between list and mask, no read-back.
+constexpr int kSegRows = 256;
+constexpr int kSegBlockRows = 1024;   // rows a block of k_compact_segments lists (four segments: 1 280 blocks at 1.3 M rows)
+__global__ void __launch_bounds__(256)
+k_compact_segments(const uint8_t* __restrict__ mask, long long n_rows, int* __restrict__ seg_rows, int* __restrict__ seg_count) {
+    __shared__ int s_cnt[kSegBlockRows / kSegRows][4];
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+    const long long row0 = (long long)blockIdx.x * kSegBlockRows;
+    unsigned flags = 0;
+    int before[kSegBlockRows / kSegRows];   // set rows of this wave in front of this lane, per segment
+#pragma unroll
+    for (int j = 0; j < kSegBlockRows / kSegRows; ++j) {
+        const long long row = row0 + t + kSegRows * j;
+        const bool set = row < n_rows && mask[row] != 0;
+        const unsigned long long b = __ballot(set);
+        flags |= set ? 1u << j : 0u;
+        before[j] = __popcll(b & ((1ull << lane) - 1ull));
+        if (lane == 0) s_cnt[j][w] = __popcll(b);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < kSegBlockRows / kSegRows; ++j) {
+        const long long seg = (long long)blockIdx.x * (kSegBlockRows / kSegRows) + j;
+        if (seg * kSegRows >= n_rows) break;
+        int at = before[j];
+        for (int k = 0; k < w; ++k) at += s_cnt[j][k];
+        if (flags & (1u << j)) seg_rows[seg * kSegRows + at] = (int)(row0 + t + kSegRows * j);
+        if (t == 0) seg_count[seg] = s_cnt[j][0] + s_cnt[j][1] + s_cnt[j][2] + s_cnt[j][3];
+    }
+}
+
+template <bool RMS>
+__global__ void __launch_bounds__(256)
+k_optim_segments(float* __restrict__ data, float* __restrict__ rms, float* __restrict__ grad, int n_cols, int cp_shift,
+                 const int* __restrict__ seg_rows, const int* __restrict__ seg_count, int n_seg, float beta, float lr,
+                 float epsilon, float minval, float lr_last) {
+    const int chnl = (int)(threadIdx.x & ((1u << cp_shift) - 1u));
+    if (chnl >= n_cols) return;
+    const int gpb = (int)blockDim.x >> cp_shift;   // lane groups (rows at a time) a block
+    for (int seg = blockIdx.x; seg < n_seg; seg += gridDim.x) {
+        const int n = seg_count[seg];
+        for (int i = (int)threadIdx.x >> cp_shift; i < n; i += gpb) {
+            const long long row = seg_rows[(size_t)seg * kSegRows + i];
+            optim_once<RMS>(data, rms, grad, row * n_cols + chnl, chnl == n_cols - 1, beta, lr, epsilon, minval, lr_last);
+        }
+    }
+}
+
 template <bool RMS>
 __global__ void __launch_bounds__(256)
 k_optim_step(float* __restrict__ data, float* __restrict__ rms, float* __restrict__ grad,

@@ -52,7 +52,8 @@ def iteration(rays=rays, gt=gt):
     grid.volume_render_fused(rays, gt, lambda_l2=F["lambda_l2"], lambda_l1=F["lambda_l1"],
                              lambda_l_entropy=F["lambda_l_entropy"], lambda_conv_mode_samp=F["lambda_conv_mode_samp"],
                              l_dist_max_sample=F["l_dist_max_sample"], l_di_alpha_thresh=F["l_di_alpha_thresh"],
-                             surf_sparse_alpha_thresh=F["surf_sparse_alpha_thresh"])
+                             surf_sparse_alpha_thresh=F["surf_sparse_alpha_thresh"],
+                             image_width=0 if args.rays else 800)   # (the whole view comes in image order)
     grid.inplace_tv_grad(grid.density_data.grad, scaling=1e-5, sparse_frac=0.01, contiguous=True)
     grid.inplace_tv_surface_grad(grid.surface_data.grad, scaling=1e-3, sparse_frac=1, ignore_edge=True,
                                  edge_value=-1.0, alpha_dependency=True)
