@@ -75,6 +75,7 @@ struct Config {
                            // of sorted by voxel; =wide: two chunks sorted together whatever the list's length (tests)
     int bwd_tile = 8;      // ASURF_BWD_TILE = 0 | 4 | 8 | 16 | 32: width of the pixel tile a wave of k_bwd_seq takes of an image batch
                            // (0: a row of 64 pixels, as for any other batch; 8 x 8 measured best)
+    int optim_two_step = 0;   // ASURF_OPTIM=list: the masked optimizer steps as list kernel + step kernel (k_compact_segments)
     int tiles = 0;         // ASURF_TILES=1: image batches (asurf_fused_params::image_width) are rendered in tile order
                            // (measured slower with the kernels as they are: include/asurf.h)
     int lazy_rays = -1;    // ASURF_LAZY = n: batches of up to n rays run over planes of `links` alone (asurf_masks2.h);
@@ -114,6 +115,7 @@ bool config_assign(Config& c, const char* name, const char* value) {
     else if (!strcmp(name, "ASURF_BWD_SH")) c.bwd_sh_tab = (value && !strcmp(value, "tab")) ? 1 : 0;
     else if (!strcmp(name, "ASURF_BWD_SORT")) c.bwd_sort = (value && !strcmp(value, "0")) ? 0 : (value && !strcmp(value, "wide")) ? 2 : 1;
     else if (!strcmp(name, "ASURF_BWD_TILE")) c.bwd_tile = (!value || !*value) ? 8 : (n == 4 || n == 8 || n == 16 || n == 32) ? n : 0;
+    else if (!strcmp(name, "ASURF_OPTIM")) c.optim_two_step = (value && !strcmp(value, "list")) ? 1 : 0;
     else if (!strcmp(name, "ASURF_TILES")) c.tiles = (value && !strcmp(value, "1")) ? 1 : 0;
     else if (!strcmp(name, "ASURF_LAZY")) c.lazy_rays = (value && *value) ? std::max(n, 0) : -1;
     else return false;
@@ -125,7 +127,7 @@ Config config() {  // a copy: a call works with one consistent set
         static const char* const names[] = {"ASURF_DEBUG", "ASURF_WALK_SEG", "ASURF_WALK", "ASURF_RPW", "ASURF_NO_PIPELINE",
                                             "ASURF_CUVOL_RPW", "ASURF_NO_REPLAY", "ASURF_NO_SPLIT_BWD", "ASURF_EVAL",
                                             "ASURF_TIMELINE", "ASURF_SWEEP", "ASURF_SWEEP_WPB", "ASURF_SWEEP_RPW", "ASURF_MASKS", "ASURF_SIDE_STREAM", "ASURF_ORDER",
-                                            "ASURF_LAZY", "ASURF_BWD_SH", "ASURF_TILES", "ASURF_BWD_SORT", "ASURF_BWD_TILE"};
+                                            "ASURF_LAZY", "ASURF_BWD_SH", "ASURF_TILES", "ASURF_BWD_SORT", "ASURF_BWD_TILE", "ASURF_OPTIM"};
         std::lock_guard<std::mutex> lock(g_cfg_mu);
         for (const char* nm : names)
             if (const char* v = getenv(nm)) config_assign(g_cfg, nm, v);
@@ -1731,6 +1733,18 @@ static int optim_masked(bool rms_mode, float* data, float* rms, float* grad, int
         if (!data || !grad || (rms_mode && !rms)) return fail(ASURF_E_INVALID, "optim step: NULL tensor");
         if (lr_last < 0.f) lr_last = lr;  // optim_kernel.cu:169
         const long long n_seg = (n_rows + kSegRows - 1) / kSegRows;
+        if (!config().optim_two_step) {   // one kernel: the segment's rows listed in LDS
+            int cps = 0;
+            while ((1 << cps) < n_cols) ++cps;
+            const unsigned nblk = (unsigned)std::min<long long>(n_seg, 8192);
+            if (rms_mode)
+                hipLaunchKernelGGL((k_optim_masked<true>), dim3(nblk), dim3(256), 0, s, data, rms, grad, (long long)n_rows,
+                                   n_cols, cps, mask, (int)n_seg, beta, lr, epsilon, minval, lr_last);
+            else
+                hipLaunchKernelGGL((k_optim_masked<false>), dim3(nblk), dim3(256), 0, s, data, rms, grad, (long long)n_rows,
+                                   n_cols, cps, mask, (int)n_seg, beta, lr, epsilon, minval, lr_last);
+            return launch_error("k_optim_masked");
+        }
         int* seg_rows = reinterpret_cast<int*>(static_cast<char*>(scratch) + 256);
         int* seg_count = seg_rows + n_seg * kSegRows;
         hipLaunchKernelGGL(k_compact_segments, dim3((unsigned)((n_rows + kSegBlockRows - 1) / kSegBlockRows)),

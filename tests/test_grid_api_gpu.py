@@ -167,11 +167,19 @@ def _rmsprop_ref(data, rms, grad, rows, beta, lr, eps, minval, lr_last):
     return data, rms, grad
 
 
-@pytest.mark.parametrize("c", [27, 1])
+@pytest.mark.parametrize("form", ["one_kernel", "list"])
+@pytest.mark.parametrize("c", [27, 1, 3, 48])
 @pytest.mark.parametrize("kind", ["all", "mask", "mask_sparse", "mask_none", "mask_all", "index", "empty_index"])
-def test_optimizer_steps(env, kind, c):
+def test_optimizer_steps(env, kind, c, form):
+    """`form`: the masked steps as one kernel (a block lists its segment's rows in LDS: k_optim_masked, the default) or as
+    the segmented list in memory + the step over it (ASURF_OPTIM=list)."""
     torch, svox2 = env
     import svox2.csrc as _C
+    from alphasurf_amd import lib
+    if form == "list":
+        if not kind.startswith("mask"):
+            pytest.skip("only the masked steps have two forms")
+        lib.config_set("ASURF_OPTIM", "list")
     rs = np.random.RandomState(3)
     n = 13003  # (several blocks of the mask -> row-list pass)
     data = rs.randn(n, c).astype(np.float32)

@@ -107,7 +107,7 @@ def test_tv_kernels_vs_oracle(env, oracle, which):
     # rsqrtf vs 1/sqrtf, and the order of the float sums: row 0 stands for every neighbour outside the grid and takes
     # thousands of terms (loss_kernel.cu:765-770) -- the oracle adds them one after the other in float32, the kernel
     # per block first (RegAcc, asurf_reg.h): 2.7e-5 of the largest entry apart on this scene
-    grad_close(grad.cpu().numpy(), go, 4e-5 if which == "tv_density" else 2e-5, which)
+    grad_close(grad.cpu().numpy(), go, 4e-5 if which in ("tv_density", "tv_sh") else 2e-5, which)
     assert (mask.cpu().numpy() == (mo > 0)).all()
 
 
