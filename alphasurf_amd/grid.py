@@ -599,7 +599,8 @@ class SparseGrid(nn.Module):
             return {"rgb": rgb}
         backend = self._check_backend(no_surface)
         grad = self._get_data_grads()
-        rgb_out = torch.zeros_like(rgb_gt)
+        # (surf_trav writes every ray's colour -- k_comp or the one-kernel path, a miss gets the background: no fill)
+        rgb_out = torch.zeros_like(rgb_gt) if backend != "surf_trav" else torch.empty_like(rgb_gt)
         # (a fresh mask per call, :3535 -- zeroed as 8-byte words: torch's bool fill is seven times slower)
         n_rows = self.density_data.size(0)
         self.sparse_grad_indexer = torch.zeros(((n_rows + 7) // 8,), dtype=torch.int64,
@@ -1060,7 +1061,13 @@ class SparseGrid(nn.Module):
             first = (torch.rand(1, device=dev) * n_cells).long().clamp_(max=n_cells - 1)
             return (torch.arange(count, dtype=torch.int64, device=dev) + first).remainder_(n_cells).to(torch.int32)
         first = int(np.random.randint(0, n_cells))
-        if first + count <= n_cells:   # (no wrap: one kernel instead of four)
+        if first + count <= n_cells:   # (no wrap: a view of the cached 0 .. n_cells-1 -- no kernel at all; the callers only read it)
+            if n_cells <= (1 << 26):
+                ids = self.__dict__.get("_all_cell_ids")
+                if ids is None or ids.numel() != n_cells or ids.device != dev:
+                    ids = torch.arange(n_cells, dtype=torch.int32, device=dev)
+                    self.__dict__["_all_cell_ids"] = ids
+                return ids[first:first + count]
             return torch.arange(first, first + count, dtype=torch.int32, device=dev)
         run = torch.arange(count, dtype=torch.int64, device=dev).add_(first)
         return run.remainder_(n_cells).to(torch.int32)

@@ -119,11 +119,13 @@ def render_fused(sc, origins, dirs, opts, rgb_gt, fused=None, global_n_rays=0, c
     args = [fused.pop(k, dflt) for k, dflt in FUSED_ORDER]
     assert not fused, fused
     gt = torch.from_numpy(np.ascontiguousarray(rgb_gt, np.float32)).to(dev())
-    rgb = torch.zeros_like(gt)
+    # (NaN in front: the call owes every ray its colour -- the mirror hands it an uninitialised buffer, grid.py)
+    rgb = torch.full_like(gt, float("nan"))
     cnt = torch.zeros(4, dtype=torch.int64, device=dev()) if counters else None
     _C.volume_render_surf_trav_fused(g, r, o, gt, *args, rgb, gr, global_n_rays=global_n_rays,
                                      counters=cnt, rec_depth=rec_depth)
     torch.cuda.synchronize()
+    assert not bool(torch.isnan(rgb).any()), "a ray was left without a colour"
     out = (rgb.cpu().numpy(), grads_np(gr))
     return out + (cnt.cpu().numpy(),) if counters else out
 

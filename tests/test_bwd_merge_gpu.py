@@ -75,7 +75,7 @@ def test_image_batch_in_tile_order(hip):
         def call(image_width):
             gr = H.zero_grads(g)
             args = [dflt for _, dflt in H.FUSED_ORDER]
-            rgb = torch.zeros_like(gt_t)
+            rgb = torch.full_like(gt_t, float("nan"))   # (every ray is owed its colour)
             _C.volume_render_surf_trav_fused(g, r, op, gt_t, *args, rgb, gr, image_width=image_width, order_rays=0)
             torch.cuda.synchronize()
             return rgb.cpu().numpy(), H.grads_np(gr)
