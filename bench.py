@@ -107,7 +107,10 @@ def algorithmic_bytes_per_kernel(n_rays, v_t, v_a, s, D, stat_loss, M):
 
 
 HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec; 6.3 TB/s is what a streaming copy reaches)
-ATOMIC_PEAK_GBPS = 1300.0       # ... "Global float atomics": ~1.3 TB/s of added bytes chip-wide
+ATOMIC_PEAK_GBPS = 1300.0       # ... "Global float atomics": ~1.3 TB/s of added bytes chip-wide (aligned 64-byte pieces)
+ATOMIC_PEAK_GREQ = 21.0         # G atomic requests/s at the L2, one per 64-byte line an instruction touches, whatever the lanes
+                                # in it (variants/micro/atomics.hip, profiles/r4_micro_atomics.txt: scattered floats, rows of
+                                # 8 / 16 / 27 / 32 / 64 floats all run at 20.7-21.2 G lines/s; 21 G x 64 B = the 1.3 TB/s above)
 N_SIMD, CLOCK_HZ, VALU_CYCLES = 1024, 2.4e9, 2   # 256 CUs x 4 SIMD-32; a wave64 VALU instruction holds its SIMD 2 cycles
 ATOMIC_KERNELS = ("k_bwd_sh", "k_bwd_geo", "k_backward_fallback")
 
@@ -150,8 +153,11 @@ def kernel_ceilings(ms, c):
         out["hbm_frac"] = round(c["hbm_bytes"] / t / 1e9 / HBM_PEAK_GBPS, 4)
     if c.get("valu_insts") is not None:
         out["valu_issue_frac"] = round(c["valu_insts"] * VALU_CYCLES / (N_SIMD * CLOCK_HZ * t), 4)
-    if c.get("atomic_bytes") is not None:
-        out["atomic_frac"] = round(c["atomic_bytes"] / t / 1e9 / ATOMIC_PEAK_GBPS, 4)
+    if c.get("atomic_requests") is not None and c.get("atomic_bytes") is not None:   # (the scatter kernels only)
+        out["atomic_Greq_s"] = round(c["atomic_requests"] / t / 1e9, 2)
+        out["atomic_frac"] = round(c["atomic_requests"] / t / 1e9 / ATOMIC_PEAK_GREQ, 4)
+    elif c.get("atomic_bytes") is not None:   # (counters collected before round 4: bytes written against 1.3 TB/s -- an
+        out["atomic_frac"] = round(c["atomic_bytes"] / t / 1e9 / ATOMIC_PEAK_GBPS, 4)   # underestimate, L2 merges writes)
     if c.get("wave_cycles"):
         out["wait_frac"] = round(c.get("wait_any", 0.0) / c["wave_cycles"], 4)
     fr = {k: out[k + "_frac"] for k in ("hbm", "valu_issue", "atomic") if out[k + "_frac"] is not None}
@@ -204,7 +210,10 @@ def build_roofline(spans, shares, dom_name, call_ms, model_bytes, cfg_key, count
     if bound == "hbm":
         achieved, peak, unit = dom["hbm_GBps"], HBM_PEAK_GBPS, "GB/s"
     elif bound == "atomic":
-        achieved, peak, unit = round(dom["atomic_frac"] * ATOMIC_PEAK_GBPS, 1), ATOMIC_PEAK_GBPS, "GB/s (float atomics)"
+        if dom.get("atomic_Greq_s") is not None:
+            achieved, peak, unit = dom["atomic_Greq_s"], ATOMIC_PEAK_GREQ, "G atomic line requests/s (TCC_ATOMIC)"
+        else:
+            achieved, peak, unit = round(dom["atomic_frac"] * ATOMIC_PEAK_GBPS, 1), ATOMIC_PEAK_GBPS, "GB/s (float atomics)"
     else:
         peak = N_SIMD * CLOCK_HZ / VALU_CYCLES / 1e9
         achieved, unit = round(dom["valu_issue_frac"] * peak, 1), "G wave-instructions/s (VALU issue)"
@@ -214,7 +223,8 @@ def build_roofline(spans, shares, dom_name, call_ms, model_bytes, cfg_key, count
                 ceilings=ceil, whole_call=whole, counters_file=os.path.relpath(counters_path, ROOT),
                 note="frac = utilisation of the ceiling that binds the dominant kernel; ceilings: every kernel against "
                      "HBM bytes (PMC FETCH_SIZE x 2 + WRITE_SIZE), VALU issue (SQ_INSTS_VALU x 2 cycles / 1024 SIMDs / "
-                     "2.4 GHz) and float-atomic bytes (~1.3 TB/s); wait_frac = SQ_WAIT_ANY / SQ_WAVE_CYCLES",
+                     "2.4 GHz) and, for the scatter kernels, atomic requests at the L2 (TCC_ATOMIC_sum against the 21 G 64-byte "
+                     "line requests/s variants/micro/atomics.hip reaches); wait_frac = SQ_WAIT_ANY / SQ_WAVE_CYCLES",
                 reference_model=ref_model)
 
 
@@ -228,9 +238,9 @@ def also_lines(args):
     common = ["--no-cpu-baseline", "--no-also"]
     jobs = [
         ("rays_5184_shuffled", "opt/opt.py's batch (config_util.py:340: 5000 rays; 72 x 72 here), shuffled, links_epoch = 0",
-         [here, "--width", "72", "--shuffle", "--steps", "50", "--warmup", "10"] + common),
+         [here, "--width", "72", "--shuffle", "--steps", "200", "--warmup", "20"] + common),
         ("rays_5184_shuffled_links_epoch", "the same with the caller's promise that `links` is unchanged (what the SparseGrid mirror passes)",
-         [here, "--width", "72", "--shuffle", "--links-epoch", "--steps", "50", "--warmup", "10"] + common),
+         [here, "--width", "72", "--shuffle", "--links-epoch", "--steps", "200", "--warmup", "20"] + common),
         ("training_iteration_5184", "one iteration of surface_cuda_syn.yaml through the SparseGrid mirror at that batch size: fused "
          "render, TV on alpha, surface TV, normal loss, alpha sparsify, three RMSprop steps (variants/bench_iteration.py)",
          [it_py, "--rays", "5184", "--verify"]),

@@ -179,14 +179,15 @@ typedef struct asurf_fused_params {
      *   1: never;  2: always. */
     int32_t order_rays;
     /* Image batches (extension): > 0 states that the batch is a row-major image (or a stack of images) of this many
-     * rays a row, n_rays a multiple of it.  With ASURF_TILES=1 (asurf_config_set) batches of 65 536 rays and more are
-     * then rendered in the order of their 8 x 8 pixel tiles (inside the call: the rays are copied in tile order, the
-     * colours scattered back; results are those of the given order): the 64 samples a wave of the backward kernels takes
-     * fall into a patch of the surface instead of a line across it -- 1.07 distinct gradient rows a sample instead of
-     * 2.13 on the bench scene.  Built for the chunk-wide merge of k_bwd_sh_tab (asurf_bwd_pipeline.h), measured on
-     * MI355X (config 2) and left OFF: the ordering costs 0.024 ms, k_sweep / k_comp / k_bwd_geo lose 0.007 / 0.013 /
-     * 0.007 ms to it, k_geom gains 0.010, and k_bwd_sh_tab at its present occupancy takes 0.25 ms where k_bwd_sh
-     * takes 0.17 in image order.  0: unknown.  (The field was `reserved_`, always 0, in ABI version 3: same layout.) */
+     * rays a row, n_rays a multiple of it; 0: unknown.  The backward pass of batches that fill the chip (64 rays a
+     * wave) then lists the samples it replays by 8 x 8 PIXEL TILES instead of by runs of 64 pixels of a row
+     * (k_bwd_seq; the forward kernels and every result are untouched): a chunk of that list -- what a wave of
+     * k_bwd_sh / k_bwd_geo sorts by voxel and merges before it adds to memory -- is then a patch of the surface
+     * instead of a line across it, which falls into half as many voxels.  Measured on MI355X (config 2): k_bwd_sh
+     * 0.171 -> 0.124 ms, k_bwd_geo 0.107 -> 0.083 ms, the call 730 -> 800 Mrays/s; the tile's width is
+     * ASURF_BWD_TILE (4 / 8 / 16 / 32; 0: rows), images it does not partition are taken by rows.
+     * ASURF_TILES=1 (off: measured slower) renders the WHOLE call in tile order -- the rays copied inside the
+     * call, the colours scattered back.  (The field was `reserved_`, always 0, in ABI version 3: same layout.) */
     int32_t image_width;
 } asurf_fused_params;
 
@@ -492,8 +493,14 @@ int asurf_rows_unpack_add(const int32_t* rows, int64_t n_list, int32_t sh_dim, c
  * ASURF_RPW, ASURF_CUVOL_RPW, ASURF_NO_PIPELINE, ASURF_NO_REPLAY, ASURF_NO_SPLIT_BWD, ASURF_EVAL ("walk"),
  * ASURF_SWEEP ("block": the block-synchronous k_sweep), ASURF_SWEEP_WPB, ASURF_SWEEP_RPW, ASURF_MASKS ("row": the
  * per-voxel occupancy pass; "split" / "single": the full pass in three steps / as one kernel whatever the grid's size),
- * ASURF_ORDER ("radix": rocPRIM's sort instead of the strip sort), ASURF_SIDE_STREAM (the fused call's fallback kernels on a stream of the library's own).  The
- * environment variables of these names are read ONCE, by the first entry point that runs; afterwards only this
+ * ASURF_ORDER ("radix": rocPRIM's sort instead of the strip sort), ASURF_SIDE_STREAM (the fused call's fallback
+ * kernels on a stream of the library's own), and round 4's: ASURF_BWD_SORT ("0": the backward kernels take the chunks
+ * of the record list as they lie instead of sorted by voxel; "wide": two chunks sorted together whatever the list's
+ * length), ASURF_BWD_TILE (0 / 4 / 8 / 16 / 32: width of the pixel tile of an image batch's record list, default 8),
+ * ASURF_BWD_SH ("tab": the chunk-wide merge through an LDS hash table, measured slower), ASURF_TILES ("1": an image
+ * batch rendered in tile order throughout, measured slower), ASURF_LAZY (n: batches of up to n rays over planes of
+ * `links` alone, measured slower; default 0), ASURF_OPTIM ("list": the masked optimizer steps as list + step kernels).
+ * The environment variables of these names are read ONCE, by the first entry point that runs; afterwards only this
  * function changes a switch (value NULL = default).  Nothing on the call path reads the environment.  The
  * measurement aids that make results invalid (ASURF_DEBUG bits 1, 2, 4, 256 * n) exist in the instrumented build
  * only (`make -C alphasurf_amd/csrc timeline`); the shipped library ignores them.  Returns 0 or ASURF_E_INVALID. */

@@ -11,7 +11,8 @@ from alphasurf_amd import synth
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--rays", type=int, default=0, help="0: the whole 800x800 view in image order; N: N shuffled rays of it")
-ap.add_argument("--iters", type=int, default=30)
+ap.add_argument("--iters", type=int, default=200,
+                help="timed iterations (the first few dozen run behind an empty queue: 30 read 8 % slower than 200)")
 ap.add_argument("--eikonal", action="store_true", help="also the eikonal loss (off in surface_cuda_syn.yaml)")
 ap.add_argument("--graph-static", action="store_true",
                 help="with --graph: replay without copying a batch into the captured buffers (what the copies cost)")

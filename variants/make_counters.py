@@ -26,7 +26,7 @@ def fold(sub):
     return {k: (tot / n, n) for k, (tot, n) in acc.items()}
 
 
-fetch, write, sq = fold("fetch"), fold("write"), fold("sq")
+fetch, write, sq, atomic = fold("fetch"), fold("write"), fold("sq"), fold("atomic")
 cf, cw = fold("calib_fetch"), fold("calib_write")
 calib = {}
 for (k, c), (avg, n) in list(cf.items()) + list(cw.items()):
@@ -60,6 +60,8 @@ for k in names:
                    ("SQ_WAIT_ANY", "wait_any"), ("SQ_ACTIVE_INST_VALU", "active_inst_valu")):
         if (k, c) in sq:
             e[key] = round(sq[(k, c)][0], 1)
+    if (k, "TCC_ATOMIC_sum") in atomic:
+        e["atomic_requests"] = round(atomic[(k, "TCC_ATOMIC_sum")][0], 1)
     if k in dur:
         e["trace_avg_ms"], e["trace_calls"] = round(dur[k][0], 5), dur[k][1]
     kernels[RENAME.get(k, k)] = e
