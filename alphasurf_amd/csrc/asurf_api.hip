@@ -76,6 +76,7 @@ struct Config {
     int bwd_tile = 8;      // ASURF_BWD_TILE = 0 | 4 | 8 | 16 | 32: width of the pixel tile a wave of k_bwd_seq takes of an image batch
                            // (0: a row of 64 pixels, as for any other batch; 8 x 8 measured best)
     int optim_two_step = 0;   // ASURF_OPTIM=list: the masked optimizer steps as list kernel + step kernel (k_compact_segments)
+    int relaxed_rays = -1;    // ASURF_RELAXED = n: batches of up to n rays take k_geom / k_bwd_geo without an occupancy bound
     int tiles = 0;         // ASURF_TILES=1: image batches (asurf_fused_params::image_width) are rendered in tile order
                            // (measured slower with the kernels as they are: include/asurf.h)
     int lazy_rays = -1;    // ASURF_LAZY = n: batches of up to n rays run over planes of `links` alone (asurf_masks2.h);
@@ -116,6 +117,7 @@ bool config_assign(Config& c, const char* name, const char* value) {
     else if (!strcmp(name, "ASURF_BWD_SORT")) c.bwd_sort = (value && !strcmp(value, "0")) ? 0 : (value && !strcmp(value, "wide")) ? 2 : 1;
     else if (!strcmp(name, "ASURF_BWD_TILE")) c.bwd_tile = (!value || !*value) ? 8 : (n == 4 || n == 8 || n == 16 || n == 32) ? n : 0;
     else if (!strcmp(name, "ASURF_OPTIM")) c.optim_two_step = (value && !strcmp(value, "list")) ? 1 : 0;
+    else if (!strcmp(name, "ASURF_RELAXED")) c.relaxed_rays = (value && *value) ? std::max(n, 0) : -1;
     else if (!strcmp(name, "ASURF_TILES")) c.tiles = (value && !strcmp(value, "1")) ? 1 : 0;
     else if (!strcmp(name, "ASURF_LAZY")) c.lazy_rays = (value && *value) ? std::max(n, 0) : -1;
     else return false;
@@ -127,7 +129,7 @@ Config config() {  // a copy: a call works with one consistent set
         static const char* const names[] = {"ASURF_DEBUG", "ASURF_WALK_SEG", "ASURF_WALK", "ASURF_RPW", "ASURF_NO_PIPELINE",
                                             "ASURF_CUVOL_RPW", "ASURF_NO_REPLAY", "ASURF_NO_SPLIT_BWD", "ASURF_EVAL",
                                             "ASURF_TIMELINE", "ASURF_SWEEP", "ASURF_SWEEP_WPB", "ASURF_SWEEP_RPW", "ASURF_MASKS", "ASURF_SIDE_STREAM", "ASURF_ORDER",
-                                            "ASURF_LAZY", "ASURF_BWD_SH", "ASURF_TILES", "ASURF_BWD_SORT", "ASURF_BWD_TILE", "ASURF_OPTIM"};
+                                            "ASURF_LAZY", "ASURF_BWD_SH", "ASURF_TILES", "ASURF_BWD_SORT", "ASURF_BWD_TILE", "ASURF_OPTIM", "ASURF_RELAXED"};
         std::lock_guard<std::mutex> lock(g_cfg_mu);
         for (const char* nm : names)
             if (const char* v = getenv(nm)) config_assign(g_cfg, nm, v);
@@ -864,6 +866,14 @@ int prepare(const asurf_grid* grid, const asurf_rays* rays, const asurf_render_o
 // is most of these kernels' time at the training script's batch size.  (Grids of exactly the blocks the device keeps
 // resident -- every wave starts at once and strides the same number of turns -- change nothing: these kernels run at
 // the rate of their memory requests, not of their wave slots; variants/timeline.py.)
+// Batches up to this size take the forms of k_geom / k_bwd_geo that are compiled without an occupancy bound (more
+// registers, no scratch): below it the chip holds a wave or two a SIMD and a wave's own chain is what a kernel lasts.
+constexpr long long kRelaxedMaxRays = 196608;   // (measured: a gain up to 160 k rays, even at 262 k, a loss at 640 k)
+long long relaxed_max_rays() {
+    const int n = config().relaxed_rays;   // ASURF_RELAXED = n (measurement; 0: never)
+    return n < 0 ? kRelaxedMaxRays : (long long)n;
+}
+
 unsigned list_blocks(long long n_rays, int per_ray) {
     const long long want = (n_rays * per_ray + kBlock - 1) / kBlock;
     return (unsigned)std::min<long long>((std::max<long long>(want, 64) + 7) & ~7ll, kListBlocks);  // (k_geom: 8 groups)
@@ -992,8 +1002,12 @@ int find_candidates(const Launch& L, const asurf_rays* rays, bool record, PipeBu
             hipLaunchKernelGGL((k_walk<false>), L.ray_grid, dim3(kBlock), 0, L.stream, L.g, L.o,
                                rays->origins, rays->dirs, Q, P, record ? 1 : 0);
         prof_after(L.sweep ? "k_sweep" : "k_walk", 1, L.stream);
-        hipLaunchKernelGGL(k_geom, dim3(list_blocks(Q, 16)), dim3(kBlock), 0, L.stream, L.g, L.o, rays->origins,
-                           rays->dirs, Q, P);
+        if (Q <= relaxed_max_rays())
+            hipLaunchKernelGGL(k_geom<true>, dim3(list_blocks(Q, 16)), dim3(kBlock), 0, L.stream, L.g, L.o, rays->origins,
+                               rays->dirs, Q, P);
+        else
+            hipLaunchKernelGGL(k_geom<false>, dim3(list_blocks(Q, 16)), dim3(kBlock), 0, L.stream, L.g, L.o, rays->origins,
+                               rays->dirs, Q, P);
         prof_after("k_geom", 1, L.stream);
     }
     return launch_error("forward pipeline");
@@ -1177,8 +1191,12 @@ int run_backward(const Launch& L, const asurf_rays* rays, const KLoss& loss, con
                                dim3(BwdShTab<B>::kThreads), 0, L.stream, L.g, G, L.o.no_surf_grad_from_sh ? 0 : 1,
                                rays->dirs, Q, S);
         prof_after("k_bwd_sh", 2, L.stream);
-        hipLaunchKernelGGL(k_bwd_geo, dim3(list_blocks(Q, 2)), dim3(kBlock), 0, L.stream, L.g, L.o, loss, G, rays->origins,
-                           rays->dirs, Q, S, config().bwd_sort);
+        if (Q <= relaxed_max_rays())
+            hipLaunchKernelGGL(k_bwd_geo<true>, dim3(list_blocks(Q, 2)), dim3(kBlock), 0, L.stream, L.g, L.o, loss, G,
+                               rays->origins, rays->dirs, Q, S, config().bwd_sort);
+        else
+            hipLaunchKernelGGL(k_bwd_geo<false>, dim3(list_blocks(Q, 2)), dim3(kBlock), 0, L.stream, L.g, L.o, loss, G,
+                               rays->origins, rays->dirs, Q, S, config().bwd_sort);
         prof_after("k_bwd_geo", 2, L.stream);
     } else if (mode == 1) {
         ASURF_BWD(true, false, true);

@@ -453,7 +453,12 @@ k_walk_seg(KGrid g, KOpt o, const float* __restrict__ origins, const float* __re
 #ifndef ASURF_GEOM_WAVES
 #define ASURF_GEOM_WAVES 3
 #endif
-__global__ void __launch_bounds__(kBlock, ASURF_GEOM_WAVES)
+// RELAXED: no occupancy bound -- 204 registers, no scratch, two waves a SIMD.  A batch of a few thousand rays puts a wave
+// or less on a SIMD: the waves' own chains are the kernel's time, and the 76 bytes of scratch of the three-wave form sit
+// in them (5 184 rays: 0.0172 -> 0.0147 ms, 40 000: 0.0448 -> 0.0372; 640 000: 0.164 -> 0.171, so the full batch keeps
+// the three-wave form).
+template <bool RELAXED>
+__global__ void __launch_bounds__(kBlock, RELAXED ? 1 : ASURF_GEOM_WAVES)
 k_geom(KGrid g, KOpt o, const float* __restrict__ origins, const float* __restrict__ dirs,
        long long Q, PipeBuf P) {
     const TlScope tl(3);

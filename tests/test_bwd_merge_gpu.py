@@ -58,6 +58,22 @@ def test_chunks_sorted_by_voxel(hip, oracle, basis_dim, optname):
         assert float(np.abs(got[1][k] - go[k]).max()) / scale <= 2e-4, k
 
 
+@pytest.mark.parametrize("optname", ["syn_yaml", "fake_limited"])
+def test_kernels_without_an_occupancy_bound(hip, optname):
+    """Small batches take k_geom / k_bwd_geo compiled without an occupancy bound (more registers, no scratch;
+    ASURF_RELAXED=0: never): the same arithmetic, the same colours bit for bit."""
+    from alphasurf_amd import lib
+    lv = (0.0,) if optname != "fake_limited" else (-0.3, 0.0, 0.4)
+    sc, o, d = sparse_case(9, level_set=lv, trunc_a=3.0, fake_sample_std=0.8)
+    gt = np.random.RandomState(3).rand(o.shape[0], 3).astype(np.float32)
+    fused = dict(lambda_l2=0.7, lambda_l1=0.3, lambda_l_entropy=1e-4)
+    got = hip.render_fused(sc, o, d, OPTION_SETS[optname], gt, fused)
+    lib.config_set("ASURF_RELAXED", "0")
+    ref = hip.render_fused(sc, o, d, OPTION_SETS[optname], gt, fused)
+    assert (got[0] == ref[0]).all()
+    _close(ref, got, optname)
+
+
 def test_image_batch_in_tile_order(hip):
     """A 320 x 264 image (edge tiles: 264 = 33 x 8, the width 320 = 40 x 8; and a second image 300 wide whose last tile
     column is 4 pixels) rendered as given and in tile order, with both backward forms."""
