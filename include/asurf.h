@@ -499,7 +499,8 @@ int asurf_rows_unpack_add(const int32_t* rows, int64_t n_list, int32_t sh_dim, c
  * length), ASURF_BWD_TILE (0 / 4 / 8 / 16 / 32: width of the pixel tile of an image batch's record list, default 8),
  * ASURF_BWD_SH ("tab": the chunk-wide merge through an LDS hash table, measured slower), ASURF_TILES ("1": an image
  * batch rendered in tile order throughout, measured slower), ASURF_LAZY (n: batches of up to n rays over planes of
- * `links` alone, measured slower; default 0), ASURF_OPTIM ("list": the masked optimizer steps as list + step kernels).
+ * `links` alone, measured slower; default 0), ASURF_OPTIM ("list": the masked optimizer steps as list + step kernels),
+ * ASURF_RELAXED (n: batches of up to n rays take k_geom / k_bwd_geo compiled without an occupancy bound; default 196608).
  * The environment variables of these names are read ONCE, by the first entry point that runs; afterwards only this
  * function changes a switch (value NULL = default).  Nothing on the call path reads the environment.  The
  * measurement aids that make results invalid (ASURF_DEBUG bits 1, 2, 4, 256 * n) exist in the instrumented build
