@@ -1228,6 +1228,7 @@ KGrads make_grads(const asurf_grads* g) {
     k.grad_surface = g->grad_surface_out;
     k.grad_fake_sample_std = g->grad_fake_sample_std_out;
     k.mask = g->mask_out;
+    k.mask2 = g->mask_sh_out;
     return k;
 }
 

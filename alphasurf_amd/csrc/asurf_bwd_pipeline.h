@@ -1141,6 +1141,7 @@ k_bwd_geo(KGrid g, KOpt o, KLoss L, KGrads G, const float* __restrict__ origins,
                     if (G.grad_density != nullptr) atomicAdd(&G.grad_density[lk], s_head_d[threadIdx.x >> 6][hh][c]);
                     if (G.grad_surface != nullptr) atomicAdd(&G.grad_surface[lk], s_head_s[threadIdx.x >> 6][hh][c]);
                     if (G.mask != nullptr) G.mask[lk] = 1;
+                    if (G.mask2 != nullptr) G.mask2[lk] = 1;
                 }
             }
         }

@@ -545,7 +545,10 @@ k_cuvol_bwd(KGrid g, KOpt o, int last_sample_opaque, int rpw, KGrads G, const fl
             if (G.mask != nullptr && e == 0) {  // every corner row of a served cell is touched (:120-135)
 #pragma unroll
                 for (int rd = 0; rd < C::ROUNDS; ++rd)
-                    if (link_h[rd] >= 0) G.mask[link_h[rd]] = 1;
+                    if (link_h[rd] >= 0) {
+                        G.mask[link_h[rd]] = 1;
+                        if (G.mask2 != nullptr) G.mask2[link_h[rd]] = 1;
+                    }
             }
             if (G.grad_sh != nullptr) {
 #pragma unroll
@@ -609,7 +612,10 @@ k_cuvol_bwd(KGrid g, KOpt o, int last_sample_opaque, int rpw, KGrads G, const fl
                                 if (onB && cb < 8) {
                                     const bool shared = ((cb & b) != 0) == high;
                                     if (!shared && link_h[rd] >= 0) {
-                                        if (G.mask != nullptr && e == 0) G.mask[link_h[rd]] = 1;
+                                        if (G.mask != nullptr && e == 0) {
+                                            G.mask[link_h[rd]] = 1;
+                                            if (G.mask2 != nullptr) G.mask2[link_h[rd]] = 1;
+                                        }
                                         if (G.grad_sh != nullptr && gacc[rd] != 0.f)
                                             atomicAdd(&G.grad_sh[(size_t)link_h[rd] * C::D + e], gacc[rd]);
                                     }

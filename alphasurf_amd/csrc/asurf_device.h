@@ -85,6 +85,7 @@ struct KGrads {
     float* grad_surface;
     float* grad_fake_sample_std;
     uint8_t* mask;
+    uint8_t* mask2;   // asurf_grads::mask_sh_out: the same marks once more
 };
 
 struct KLoss {  // already scaled by the launcher (surf_trav.cu:3896-3915)

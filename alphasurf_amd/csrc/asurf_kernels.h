@@ -1113,12 +1113,13 @@ __device__ __forceinline__ void write_rec_floats(float* rec_f, int R, int slot, 
 }
 
 // per-lane scatter of 8 corner contributions into a [N,1] gradient plane + touched mask
-__device__ __forceinline__ void scatter8(float* out, uint8_t* mask, const int* lk, const float* w) {
+__device__ __forceinline__ void scatter8(float* out, uint8_t* mask, uint8_t* mask2, const int* lk, const float* w) {
     if (out == nullptr) return;
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
         atomicAdd(&out[lk[i]], w[i]);
         if (mask != nullptr) mask[lk[i]] = 1;
+        if (mask2 != nullptr) mask2[lk[i]] = 1;
     }
 }
 
@@ -1672,7 +1673,7 @@ k_backward(KGrid g, KOpt o, KLoss L, KGrads G, const float* __restrict__ origins
                 {
                     float cw[8];
                     corner_weights(pos, curr_grad_raw_alpha, cw);
-                    scatter8(G.grad_density, G.mask, v.lk, cw);
+                    scatter8(G.grad_density, G.mask, G.mask2, v.lk, cw);
                 }
                 if (L.lambda_l_di > 0.f && alpha < L.l_di_alpha_thresh)
                     curr_grad_raw_alpha += L.lambda_l_di * (-1.f) * alpha_act_grad(alpha, o.alpha_activation_type);
@@ -1706,11 +1707,11 @@ k_backward(KGrid g, KOpt o, KLoss L, KGrads G, const float* __restrict__ origins
                                       (float)((double)v.new_origin[1] - (double)v.vy),
                                       (float)((double)v.new_origin[2] - (double)v.vz)};
                 surface_cubic_grad(nof, r.d, grad_fs, gsurf);
-                scatter8(G.grad_surface, G.mask, v.lk, gsurf);
+                scatter8(G.grad_surface, G.mask, G.mask2, v.lk, gsurf);
                 if (alpha < L.surf_sparse_alpha_thresh) {  // :2436-2445
                     float cw[8];
                     corner_weights(pos, L.lambda_inplace_surf_sparse, cw);
-                    scatter8(G.grad_surface, G.mask, v.lk, cw);
+                    scatter8(G.grad_surface, G.mask, G.mask2, v.lk, cw);
                 }
                 if (sample_i < M - 1) sample_i += 1;
             }
@@ -1788,7 +1789,7 @@ k_backward(KGrid g, KOpt o, KLoss L, KGrads G, const float* __restrict__ origins
                     {
                         float cw[8];
                         corner_weights(pos, curr_grad_raw_alpha, cw);
-                        scatter8(G.grad_density, G.mask, v.lk, cw);
+                        scatter8(G.grad_density, G.mask, G.mask2, v.lk, cw);
                     }
                     // surface gradient through the gaussian re-weighting (:2792-2851)
                     const float grad_fake_dist =
@@ -1811,7 +1812,7 @@ k_backward(KGrid g, KOpt o, KLoss L, KGrads G, const float* __restrict__ origins
                             }
                         }
                     }
-                    scatter8(G.grad_surface, G.mask, v.lk, gsurf);
+                    scatter8(G.grad_surface, G.mask, G.mask2, v.lk, gsurf);
                     if (G.grad_fake_sample_std != nullptr) {
                         const float gstd = curr_grad_rwalpha * alpha * sqrf(dist) * reweight * trunc_reweight /
                                            (g.fake_sample_std * g.fake_sample_std * g.fake_sample_std);

@@ -489,7 +489,7 @@ k_surface_bwd(KGrid g, KOpt o, KGrads G, const float* __restrict__ origins, cons
             {
                 float cw[8];
                 corner_weights(pos, curr_grad_raw_alpha, cw);
-                scatter8(G.grad_density, G.mask, c.v.lk, cw);
+                scatter8(G.grad_density, G.mask, G.mask2, c.v.lk, cw);
             }
             trilerp_dpos(dens, pos, curr_grad_raw_alpha, grad_xyz);
             const float grad_st = grad_xyz[0] * r.d[0] + grad_xyz[1] * r.d[1] + grad_xyz[2] * r.d[2];
@@ -500,7 +500,7 @@ k_surface_bwd(KGrid g, KOpt o, KGrads G, const float* __restrict__ origins, cons
             for (int k = 0; k < 3; ++k) lc[k] = min(c.v.l[k], g.size[k] - 2);
             float gs[8];
             surface_cubic_global_grad(r.o, r.d, lc, grad_fs, gs);
-            scatter8(G.grad_surface, G.mask, c.v.lk, gs);
+            scatter8(G.grad_surface, G.mask, G.mask2, c.v.lk, gs);
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     }

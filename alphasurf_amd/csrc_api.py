@@ -104,6 +104,7 @@ class GridOutputGrads:
         self.grad_basis_out = None
         self.grad_background_out = None
         self.mask_out = None
+        self.mask_sh_out = None      # extension (asurf_grads::mask_sh_out): a second mask that receives the same marks
         self.mask_background_out = None
 
 
@@ -228,6 +229,7 @@ def _pack_grads(grads, grid):
         _check_input(grads.grad_fake_sample_std_out, "grad_fake_sample_std_out", torch.float32)
         g.grad_fake_sample_std_out = _ptr(grads.grad_fake_sample_std_out)
     g.mask_out = chk(grads.mask_out, "mask_out", (n,), torch.bool)
+    g.mask_sh_out = chk(getattr(grads, "mask_sh_out", None), "mask_sh_out", (n,), torch.bool)
     if _defined(grads.grad_basis_out) or _defined(grads.grad_background_out) or \
             _defined(grads.mask_background_out):
         raise NotImplementedError("basis / background gradients are outside this build's scope")

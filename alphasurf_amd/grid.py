@@ -603,14 +603,21 @@ class SparseGrid(nn.Module):
         rgb_out = torch.zeros_like(rgb_gt) if backend != "surf_trav" else torch.empty_like(rgb_gt)
         # (a fresh mask per call, :3535 -- zeroed as 8-byte words: torch's bool fill is seven times slower)
         n_rows = self.density_data.size(0)
-        self.sparse_grad_indexer = torch.zeros(((n_rows + 7) // 8,), dtype=torch.int64,
-                                               device=self.density_data.device).view(torch.bool)[:n_rows]
+        # (surf_trav: the mask of the SH step -- the reference's clone of this one, taken before the regularisers add
+        # their rows, :3655 -- is a second fresh mask the call marks as well (asurf_grads::mask_sh_out): both come out of
+        # ONE fill, and the copy's launch is gone)
+        words = (n_rows + 7) // 8
+        both = torch.zeros(((2 if backend == "surf_trav" else 1) * words,), dtype=torch.int64,
+                           device=self.density_data.device)
+        self.sparse_grad_indexer = both[:words].view(torch.bool)[:n_rows]
+        sh_indexer = both[words:].view(torch.bool)[:n_rows] if backend == "surf_trav" else None
         holder = _C.GridOutputGrads()
         holder.grad_density_out = grad["density_data"]
         if "surface_data" in grad:
             holder.grad_surface_out = grad["surface_data"]
         holder.grad_sh_out = grad["sh_data"]
         holder.mask_out = self.sparse_grad_indexer
+        holder.mask_sh_out = sh_indexer
         if backend == "cuvol":  # :3625-3634
             _C.volume_render_cuvol_fused(self._to_cpp(), rays._to_cpp(), self.opt._to_cpp(randomize=randomize),
                                          rgb_gt, beta_loss, sparsity_loss, rgb_out, holder)
@@ -633,7 +640,7 @@ class SparseGrid(nn.Module):
             lambda_l_di, l_di_alpha_thresh, surf_sparse_alpha_thresh, lambda_inplace_surf_sparse,
             lambda_inwards_norm_loss, lambda_conv_mode_samp, l_dist_max_sample, rgb_out, holder,
             global_n_rays=global_n_rays, order_rays=order_rays, image_width=image_width)
-        self.sparse_sh_grad_indexer = self.sparse_grad_indexer.clone()
+        self.sparse_sh_grad_indexer = sh_indexer
         return finish(rgb_out)
 
     def volume_render_image(self, camera: Camera, use_kernel: bool = True, randomize: bool = False,

@@ -63,7 +63,7 @@ class AsurfRenderOptions(C.Structure):
 class AsurfGrads(C.Structure):
     _fields_ = [("grad_density_out", C.c_void_p), ("grad_sh_out", C.c_void_p),
                 ("grad_surface_out", C.c_void_p), ("grad_fake_sample_std_out", C.c_void_p),
-                ("mask_out", C.c_void_p)]
+                ("mask_out", C.c_void_p), ("mask_sh_out", C.c_void_p)]
 
 
 FUSED_FIELDS = [
@@ -183,7 +183,7 @@ def lib():
         L.asurf_rows_pack.argtypes = [vp, C.c_int64, C.c_int32, vp, vp, vp, vp, vp]
         L.asurf_rows_unpack.argtypes = [vp, C.c_int64, C.c_int32, vp, vp, vp, vp, vp, vp]
         L.asurf_rows_unpack_add.argtypes = [vp, C.c_int64, C.c_int32, vp, vp, vp, vp, vp, vp]
-        if L.asurf_abi_version() != 3:
+        if L.asurf_abi_version() != 4:
             raise RuntimeError("libasurf_hip.so ABI version mismatch")
         _lib = L
     return _lib

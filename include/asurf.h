@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define ASURF_ABI_VERSION 3
+#define ASURF_ABI_VERSION 4
 
 /* error codes */
 #define ASURF_OK 0
@@ -136,6 +136,11 @@ typedef struct asurf_grads {
     float* grad_surface_out;         /* [capacity,1] */
     float* grad_fake_sample_std_out; /* [1] */
     uint8_t* mask_out;               /* [capacity] bool */
+    /* extension (ABI 4; NULL: none): a second mask that receives the same marks.  The reference's training loop copies
+     * the render's mask for the SH step before the regularisers add their rows to it (svox2.py: sparse_sh_grad_indexer
+     * = sparse_grad_indexer.clone()): a launch of its own in front of them, 5 us of a 0.25 ms iteration -- with two
+     * fresh masks handed to the fused call the copy is gone. */
+    uint8_t* mask_sh_out;
 } asurf_grads;
 
 /* The 20 scalars + rgb_gt of volume_render_surf_trav_fused

@@ -82,10 +82,13 @@ def zero_grads(g, with_std=True):
     if with_std:
         gr.grad_fake_sample_std_out = torch.zeros(1, 1, device=dev())
     gr.mask_out = torch.zeros(g.density_data.shape[0], dtype=torch.bool, device=dev())
+    gr.mask_sh_out = torch.zeros_like(gr.mask_out)   # (asurf_grads::mask_sh_out: must come back equal, grads_np)
     return gr
 
 
 def grads_np(gr):
+    if getattr(gr, "mask_sh_out", None) is not None:
+        assert bool((gr.mask_sh_out == gr.mask_out).all()), "the second mask differs from the first"
     out = dict(density=gr.grad_density_out.cpu().numpy(), sh=gr.grad_sh_out.cpu().numpy(),
                surface=gr.grad_surface_out.cpu().numpy(), mask=gr.mask_out.cpu().numpy())
     if gr.grad_fake_sample_std_out is not None:
@@ -180,6 +183,7 @@ def _cuvol_grads(g):
     gr.grad_density_out = torch.zeros_like(g.density_data)
     gr.grad_sh_out = torch.zeros_like(g.sh_data)
     gr.mask_out = torch.zeros(g.density_data.shape[0], dtype=torch.bool, device=dev())
+    gr.mask_sh_out = torch.zeros_like(gr.mask_out)   # (asurf_grads::mask_sh_out: must come back equal, grads_np)
     return gr
 
 

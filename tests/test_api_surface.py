@@ -25,7 +25,7 @@ def test_c_abi_exports_every_declared_symbol():
     for name in sorted(declared):
         assert hasattr(L, name), f"libasurf_hip.so does not export {name}"
     assert set(lib.EXPORTS) <= declared
-    assert L.asurf_abi_version() == 3
+    assert L.asurf_abi_version() == 4
     # sizes only -- no device work
     assert lib.workspace_bytes((256, 256, 256), 640000, 64) > 3 * 64 * 640000 * 4
 
