@@ -168,7 +168,7 @@ def _rmsprop_ref(data, rms, grad, rows, beta, lr, eps, minval, lr_last):
 
 
 @pytest.mark.parametrize("form", ["one_kernel", "list"])
-@pytest.mark.parametrize("c", [27, 1, 3, 48])
+@pytest.mark.parametrize("c", [27, 1, 3, 48, 75])
 @pytest.mark.parametrize("kind", ["all", "mask", "mask_sparse", "mask_none", "mask_all", "index", "empty_index"])
 def test_optimizer_steps(env, kind, c, form):
     """`form`: the masked steps as one kernel (a block lists its segment's rows in LDS: k_optim_masked, the default) or as
