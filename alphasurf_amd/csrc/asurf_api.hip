@@ -77,6 +77,8 @@ struct Config {
                            // (0: a row of 64 pixels, as for any other batch; 8 x 8 measured best)
     int optim_two_step = 0;   // ASURF_OPTIM=list: the masked optimizer steps as list kernel + step kernel (k_compact_segments)
     int relaxed_rays = -1;    // ASURF_RELAXED = n: batches of up to n rays take k_geom / k_bwd_geo without an occupancy bound
+    int sum_list = -1;     // ASURF_SUM_LIST=0: the default call (links_epoch = 0) takes the full occupancy pass every time;
+                           // =1: the checksum-validated list whatever the grid's size (tests; by default from 128^3 up)
     int tiles = 0;         // ASURF_TILES=1: image batches (asurf_fused_params::image_width) are rendered in tile order
                            // (measured slower with the kernels as they are: include/asurf.h)
     int lazy_rays = -1;    // ASURF_LAZY = n: batches of up to n rays run over planes of `links` alone (asurf_masks2.h);
@@ -118,6 +120,7 @@ bool config_assign(Config& c, const char* name, const char* value) {
     else if (!strcmp(name, "ASURF_BWD_TILE")) c.bwd_tile = (!value || !*value) ? 8 : (n == 4 || n == 8 || n == 16 || n == 32) ? n : 0;
     else if (!strcmp(name, "ASURF_OPTIM")) c.optim_two_step = (value && !strcmp(value, "list")) ? 1 : 0;
     else if (!strcmp(name, "ASURF_RELAXED")) c.relaxed_rays = (value && *value) ? std::max(n, 0) : -1;
+    else if (!strcmp(name, "ASURF_SUM_LIST")) c.sum_list = (value && !strcmp(value, "0")) ? 0 : (value && !strcmp(value, "1")) ? 1 : -1;
     else if (!strcmp(name, "ASURF_TILES")) c.tiles = (value && !strcmp(value, "1")) ? 1 : 0;
     else if (!strcmp(name, "ASURF_LAZY")) c.lazy_rays = (value && *value) ? std::max(n, 0) : -1;
     else return false;
@@ -129,7 +132,7 @@ Config config() {  // a copy: a call works with one consistent set
         static const char* const names[] = {"ASURF_DEBUG", "ASURF_WALK_SEG", "ASURF_WALK", "ASURF_RPW", "ASURF_NO_PIPELINE",
                                             "ASURF_CUVOL_RPW", "ASURF_NO_REPLAY", "ASURF_NO_SPLIT_BWD", "ASURF_EVAL",
                                             "ASURF_TIMELINE", "ASURF_SWEEP", "ASURF_SWEEP_WPB", "ASURF_SWEEP_RPW", "ASURF_MASKS", "ASURF_SIDE_STREAM", "ASURF_ORDER",
-                                            "ASURF_LAZY", "ASURF_BWD_SH", "ASURF_TILES", "ASURF_BWD_SORT", "ASURF_BWD_TILE", "ASURF_OPTIM", "ASURF_RELAXED"};
+                                            "ASURF_LAZY", "ASURF_BWD_SH", "ASURF_TILES", "ASURF_BWD_SORT", "ASURF_BWD_TILE", "ASURF_OPTIM", "ASURF_RELAXED", "ASURF_SUM_LIST"};
         std::lock_guard<std::mutex> lock(g_cfg_mu);
         for (const char* nm : names)
             if (const char* v = getenv(nm)) config_assign(g_cfg, nm, v);
@@ -511,7 +514,10 @@ struct MaskCacheEntry {
     bool pending = false;
     int count = -1;
     unsigned long long used = 0;
-    int kind = 0;   // 0: the list of live rows beside per-call planes; 1: planes of `links` alone (k_links_planes)
+    int kind = 0;   // 0: the list of live rows beside per-call planes; 1: planes of `links` alone (k_links_planes);
+                    // 2: the list of live rows vouched for by a checksum of `links` the call takes itself
+    int parity = 0;           // (2) the set of checksum slots the NEXT call adds into
+    int* h_invalid = nullptr; // (2) pinned: set by the device when a call's checksum did not match the list's
 };
 constexpr int kMaskCacheEntries = 8;
 std::mutex g_mask_cache_mu;
@@ -553,7 +559,8 @@ int mask_cache_lookup(void* ws, unsigned long long epoch, const asurf_grid* grid
     return epoch == 0ull ? -1 : 0;
 }
 
-void mask_cache_store(void* ws, unsigned long long epoch, const asurf_grid* grid, const int* d_count, hipStream_t stream) {
+void mask_cache_store(void* ws, unsigned long long epoch, const asurf_grid* grid, const int* d_count, hipStream_t stream,
+                      int kind = 0) {
     std::lock_guard<std::mutex> lock(g_mask_cache_mu);
     MaskCacheEntry* slot = nullptr;
     for (MaskCacheEntry& e : g_mask_cache)
@@ -573,7 +580,13 @@ void mask_cache_store(void* ws, unsigned long long epoch, const asurf_grid* grid
     for (int i = 0; i < 3; ++i) slot->size[i] = grid->size[i];
     slot->count = -1;
     slot->pending = false;
-    slot->kind = 0;
+    slot->kind = kind;
+    slot->parity = 1;   // (the building call used set 0)
+    if (kind == 2) {
+        if (!slot->h_invalid && hipHostMalloc(reinterpret_cast<void**>(&slot->h_invalid), sizeof(int)) != hipSuccess)
+            slot->h_invalid = nullptr;   // (without the word a broken list costs every call the long way; still correct)
+        if (slot->h_invalid) *slot->h_invalid = 0;
+    }
     slot->used = ++g_mask_cache_clock;
     if (!slot->h_count && hipHostMalloc(reinterpret_cast<void**>(&slot->h_count), sizeof(int)) != hipSuccess) {
         slot->h_count = nullptr;
@@ -586,6 +599,34 @@ void mask_cache_store(void* ws, unsigned long long epoch, const asurf_grid* grid
     if (hipMemcpyAsync(slot->h_count, d_count, sizeof(int), hipMemcpyDeviceToHost, stream) == hipSuccess &&
         hipEventRecord(slot->ev, stream) == hipSuccess)
         slot->pending = true;
+}
+
+// The default call (links_epoch = 0): does this workspace hold a list of live rows built under a checksum of these
+// `links`?  1: yes (live_blocks, the parity of this call's checksum slots and the device's "did not match" word are
+// returned; the entry's parity flips); 0: no, or the device has reported a mismatch since: the caller rebuilds.
+int sum_cache_lookup(void* ws, const asurf_grid* grid, int n_rows, int* live_blocks, int* parity, int** h_invalid) {
+    std::lock_guard<std::mutex> lock(g_mask_cache_mu);
+    for (MaskCacheEntry& e : g_mask_cache) {
+        if (e.ws != ws) continue;
+        if (e.kind != 2 || e.links != grid->links || e.size[0] != grid->size[0] || e.size[1] != grid->size[1] ||
+            e.size[2] != grid->size[2] || (e.h_invalid != nullptr && *e.h_invalid != 0))
+            return 0;
+        if (e.pending) {
+            if (hipEventQuery(e.ev) == hipSuccess) {
+                e.pending = false;
+                e.count = *e.h_count;
+            } else {
+                (void)hipGetLastError();
+            }
+        }
+        e.used = ++g_mask_cache_clock;
+        *live_blocks = (e.pending || e.count < 0) ? n_rows : std::max(1, std::min(e.count, n_rows));
+        *parity = e.parity;
+        e.parity ^= 1;
+        *h_invalid = e.h_invalid;
+        return 1;
+    }
+    return 0;
 }
 
 // Planes of `links` alone (small batches): has this workspace's header been initialised for these links?  The header on
@@ -772,7 +813,7 @@ int prepare(const asurf_grid* grid, const asurf_rays* rays, const asurf_render_o
                     // enough 16-byte pieces in flight to stream: 8 blocks of 256 a CU at most, 8 pieces a thread at least
                     const long long pieces = (n_links + 3) / 4;
                     const unsigned blocks = (unsigned)std::min<long long>(std::max<long long>(pieces / (256 * 8), 1), 2048);
-                    hipLaunchKernelGGL(k_links_checksum, dim3(blocks), dim3(256), 0, L.stream, grid->links, n_links, hdr);
+                    hipLaunchKernelGGL(k_links_checksum, dim3(blocks), dim3(256), 0, L.stream, grid->links, n_links, hdr, 0);
                     prof_after("k_links_checksum", 0, L.stream);
                 }
                 hipLaunchKernelGGL(k_links_planes, dim3((unsigned)std::min(L.ML.n_rows, kLinksPlanesBlocks)), dim3(512), 0, L.stream, L.g, fw, fl,
@@ -785,6 +826,50 @@ int prepare(const asurf_grid* grid, const asurf_rays* rays, const asurf_render_o
         }
     }
     int live_blocks = 0;
+    // ---- the default call, nothing promised about `links`: a list of live rows the call vouches for ITSELF -- it sums
+    // all of `links` (k_links_checksum: 64 MiB in 0.017 ms) and the pass over the listed rows (0.034 ms) checks on the
+    // device that this is the sum the list was built under; 0.052 ms instead of the full pass's 0.063.  A mismatch (links
+    // rewritten in place) makes that launch take every row and tells the host, which rebuilds list and sum with the
+    // next call.  Grids the full pass takes in three steps (512^3 and up: their checksum alone is what the split pass
+    // costs), captured calls (a replay cannot flip the parity of the slots) and the per-voxel forms keep the full pass.
+    {
+        const long long n_links = (long long)grid->size[0] * grid->size[1] * grid->size[2];
+        const bool fast_sum = !cuvol && !(need_surf && grid->level_set_num > kMaskFastSets) && !config().masks_row;
+        const int want_sum = config().sum_list;
+        if (epoch == 0ull && fast_sum && !capturing && want_sum != 0 && L.ML.n_rows < kMaskSplitRows &&
+            !config().masks_split && !config().masks_single && (want_sum == 1 || n_links >= (1ll << 21))) {
+            const int n_sets_s = need_surf ? grid->level_set_num : 0;
+            const long long pieces = (n_links + 3) / 4;
+            const unsigned cblocks = (unsigned)std::min<long long>(std::max<long long>(pieces / (256 * 8), 1), 2048);
+            int parity = 0;
+            int* h_invalid = nullptr;
+            if (sum_cache_lookup(workspace, grid, L.ML.n_rows, &live_blocks, &parity, &h_invalid) == 1) {
+                hipLaunchKernelGGL(k_links_checksum, dim3(cblocks), dim3(256), 0, L.stream, grid->links, n_links, hdr, parity);
+                MaskRows R{hdr, live_rows, 0ull, L.ML.n_rows, 3, parity, h_invalid};
+                hipLaunchKernelGGL(k_build_masks2, dim3((unsigned)live_blocks), dim3(512), 0, L.stream, L.g, opt->sigma_thresh,
+                                   need_surf ? 1 : 0, n_sets_s, fw, fl, cw, cl, L.sweep ? fy : nullptr, L.sweep ? fz : nullptr,
+                                   use_live ? 1 : 0, nzg, R, static_cast<MaskHdr*>(nullptr), static_cast<int*>(nullptr), zero_ptr,
+                                   zero_n);
+            } else {
+                {   // (whatever the table held for this workspace is void: the planes are rewritten in full)
+                    std::lock_guard<std::mutex> lock(g_mask_cache_mu);
+                    for (MaskCacheEntry& e : g_mask_cache)
+                        if (e.ws == workspace) e.ws = nullptr;
+                }
+                if (hipMemsetAsync(hdr, 0, hdr_and_counters, L.stream) != hipSuccess)
+                    return fail(ASURF_E_LAUNCH, "hipMemsetAsync(mask header, pipeline counters) failed");
+                hipLaunchKernelGGL(k_links_checksum, dim3(cblocks), dim3(256), 0, L.stream, grid->links, n_links, hdr, 0);
+                const MaskRows R{hdr, live_rows, 0ull, L.ML.n_rows, 0};
+                hipLaunchKernelGGL(k_build_masks2, dim3((unsigned)L.ML.n_rows), dim3(512), 0, L.stream, L.g, opt->sigma_thresh,
+                                   need_surf ? 1 : 0, n_sets_s, fw, fl, cw, cl, fy, fz, use_live ? 1 : 0, nzg, R, hdr, live_rows,
+                                   static_cast<int*>(nullptr), 0);
+                hipLaunchKernelGGL(k_mask_seal_sum, dim3(1), dim3(64), 0, L.stream, hdr, 0);
+                mask_cache_store(workspace, 0ull, grid, &hdr->n_live, L.stream, 2);
+            }
+            prof_after("k_build_masks2", 0, L.stream);
+            return launch_error("k_build_masks");
+        }
+    }
     int cached = mask_cache_lookup(workspace, epoch, grid, L.ML.n_rows, &live_blocks, capturing);
     // building the list allocates pinned memory and reads a counter back: not while a graph is being captured
     if (cached == 0 && capturing) cached = -1;

@@ -197,7 +197,7 @@ struct MaskHdr {
     unsigned long long sum[2];
     unsigned int ticket;
     int sum_known;
-    unsigned long long acc[kSumSlots][2];
+    unsigned long long acc[2][kSumSlots][2];   // [parity]: a call adds into one set while it clears the other for the next call
 };
 constexpr unsigned long long kMaskMagic = 0x61737572666d736bull;
 
@@ -222,6 +222,25 @@ k_build_masks(KGrid g, float sigma_thresh, int need_surf, unsigned long long* fi
 __global__ void k_mask_seal(MaskHdr* hdr, unsigned long long epoch) {
     hdr->magic = kMaskMagic;
     hdr->epoch = epoch;
+}
+
+// the list was built under the checksum of `links` this call has added up in acc[parity] (one wave)
+__global__ void __launch_bounds__(64)
+k_mask_seal_sum(MaskHdr* hdr, int parity) {
+    unsigned long long a = threadIdx.x < kSumSlots ? hdr->acc[parity][threadIdx.x][0] : 0ull;
+    unsigned long long b = threadIdx.x < kSumSlots ? hdr->acc[parity][threadIdx.x][1] : 0ull;
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) {
+        a += __shfl_xor(a, m);
+        b += __shfl_xor(b, m);
+    }
+    if (threadIdx.x == 0) {
+        hdr->sum[0] = a;
+        hdr->sum[1] = b;
+        hdr->sum_known = 1;
+        hdr->epoch = 0ull;
+        hdr->magic = kMaskMagic;
+    }
 }
 
 // The same pass over the rows of the list only.  (Its waves are all resident from the start and each is a chain of

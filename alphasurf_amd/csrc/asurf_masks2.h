@@ -36,11 +36,14 @@ constexpr int kMaskPlanes = 2 + 2 * kMaskFastSets;
 // rows of the pass: all of them (blockIdx), or the listed ones (stride over the list the header vouches for; a header
 // that is not what the host table says -- asurf_api.hip, mask_cache_lookup -- makes the pass take every row)
 struct MaskRows {
-    const MaskHdr* hdr;
+    MaskHdr* hdr;
     const int* live_rows;
     unsigned long long epoch;
     int n_rows;
-    int use_list;
+    int use_list;      // 0: every row; 1: the list, if the header carries `epoch`; 2: the list k_rows_alive has just left;
+                       // 3: the list, if the header carries the checksum of `links` THIS call has taken (hdr->acc[parity])
+    int parity;        // (3) which set of slots this call's checksum was added up in
+    int* h_invalid;    // (3) pinned host word, set when the checksum did not match: the host then drops the list
 };
 
 struct MaskTables2 {
@@ -270,7 +273,38 @@ k_build_masks2(KGrid g, float sigma_thresh, int need_surf, int n_sets, unsigned 
     if (blockIdx.x == 0 && zero_ptr != nullptr)
         for (int i = threadIdx.x; i < zero_n; i += blockDim.x) zero_ptr[i] = 0;
     // use_list 2: the list was left by k_rows_alive in front of this very launch (the split full pass): no header to check
-    const bool listed = R.use_list == 2 || (R.use_list && R.hdr->magic == kMaskMagic && R.hdr->epoch == R.epoch);
+    bool listed = R.use_list == 2 || (R.use_list == 1 && R.hdr->magic == kMaskMagic && R.hdr->epoch == R.epoch);
+    if (R.use_list == 3) {
+        // The default call (no promise about `links`): k_links_checksum has just summed ALL of `links` into the slots of
+        // this call's parity; the list stands if that is the checksum it was built under.  Every block reaches the same
+        // verdict from the same words (the header's sum is written by the sealing kernel of an earlier call only).
+        __shared__ int s_ok;
+        if (threadIdx.x < 64) {
+            unsigned long long a = 0ull, b = 0ull;
+            if (threadIdx.x < kSumSlots) {
+                a = __hip_atomic_load(&R.hdr->acc[R.parity][threadIdx.x][0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                b = __hip_atomic_load(&R.hdr->acc[R.parity][threadIdx.x][1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+#pragma unroll
+            for (int m = 32; m >= 1; m >>= 1) {
+                a += __shfl_xor(a, m);
+                b += __shfl_xor(b, m);
+            }
+            if (threadIdx.x == 0)
+                s_ok = (R.hdr->magic == kMaskMagic && R.hdr->sum_known != 0 && R.hdr->epoch == 0ull && R.hdr->sum[0] == a &&
+                        R.hdr->sum[1] == b) ? 1 : 0;
+        }
+        __syncthreads();
+        listed = s_ok != 0;
+        if (blockIdx.x == 0) {
+            // the other parity's slots belong to the next call: cleared here, where nobody adds to them
+            if (threadIdx.x < kSumSlots) {
+                R.hdr->acc[1 - R.parity][threadIdx.x][0] = 0ull;
+                R.hdr->acc[1 - R.parity][threadIdx.x][1] = 0ull;
+            }
+            if (!listed && threadIdx.x == 0 && R.h_invalid != nullptr) *R.h_invalid = 1;   // (the host drops the list)
+        }
+    }
     const int n = listed ? min(R.hdr->n_live, R.n_rows) : R.n_rows;
     for (int i = blockIdx.x; i < n; i += gridDim.x) {
         const int row = listed ? R.live_rows[i] : i;
@@ -345,7 +379,7 @@ __device__ __forceinline__ void sum_piece(unsigned p, int4 v, unsigned long long
 }
 
 __global__ void __launch_bounds__(256)
-k_links_checksum(const int32_t* __restrict__ links, long long n, MaskHdr* hdr) {
+k_links_checksum(const int32_t* __restrict__ links, long long n, MaskHdr* hdr, int parity) {
     unsigned long long s1 = 0ull, s2 = 0ull;
     const long long tid = (long long)blockIdx.x * blockDim.x + threadIdx.x, nth = (long long)gridDim.x * blockDim.x;
     if ((reinterpret_cast<uintptr_t>(links) & 15) == 0) {
@@ -378,8 +412,8 @@ k_links_checksum(const int32_t* __restrict__ links, long long n, MaskHdr* hdr) {
     __syncthreads();
     if (threadIdx.x == 0) {
         const int slot = blockIdx.x % kSumSlots;
-        atomicAdd(&hdr->acc[slot][0], sh[0][0] + sh[0][1] + sh[0][2] + sh[0][3]);
-        atomicAdd(&hdr->acc[slot][1], sh[1][0] + sh[1][1] + sh[1][2] + sh[1][3]);
+        atomicAdd(&hdr->acc[parity][slot][0], sh[0][0] + sh[0][1] + sh[0][2] + sh[0][3]);
+        atomicAdd(&hdr->acc[parity][slot][1], sh[1][0] + sh[1][1] + sh[1][2] + sh[1][3]);
     }
 }
 
@@ -397,8 +431,8 @@ k_links_planes(KGrid g, unsigned long long* fine_work, unsigned long long* fine_
     if (threadIdx.x < 64) {   // wave 0: this call's checksum = the sum of the slots; the verdict
         unsigned long long a = 0ull, b = 0ull;
         if (use_sum && threadIdx.x < kSumSlots) {
-            a = __hip_atomic_load(&hdr->acc[threadIdx.x][0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            b = __hip_atomic_load(&hdr->acc[threadIdx.x][1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            a = __hip_atomic_load(&hdr->acc[0][threadIdx.x][0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            b = __hip_atomic_load(&hdr->acc[0][threadIdx.x][1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
 #pragma unroll
         for (int m = 32; m >= 1; m >>= 1) {
@@ -430,8 +464,8 @@ k_links_planes(KGrid g, unsigned long long* fine_work, unsigned long long* fine_
     __syncthreads();
     if (s_valid) {
         if (threadIdx.x < kSumSlots) {
-            hdr->acc[threadIdx.x][0] = 0ull;
-            hdr->acc[threadIdx.x][1] = 0ull;
+            hdr->acc[0][threadIdx.x][0] = 0ull;
+            hdr->acc[0][threadIdx.x][1] = 0ull;
         }
         if (threadIdx.x == 0) {
             hdr->ticket = 0u;
