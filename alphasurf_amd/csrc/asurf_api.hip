@@ -845,6 +845,7 @@ int prepare(const asurf_grid* grid, const asurf_rays* rays, const asurf_render_o
             int* h_invalid = nullptr;
             if (sum_cache_lookup(workspace, grid, L.ML.n_rows, &live_blocks, &parity, &h_invalid) == 1) {
                 hipLaunchKernelGGL(k_links_checksum, dim3(cblocks), dim3(256), 0, L.stream, grid->links, n_links, hdr, parity);
+                prof_after("k_links_checksum", 0, L.stream);
                 MaskRows R{hdr, live_rows, 0ull, L.ML.n_rows, 3, parity, h_invalid};
                 hipLaunchKernelGGL(k_build_masks2, dim3((unsigned)live_blocks), dim3(512), 0, L.stream, L.g, opt->sigma_thresh,
                                    need_surf ? 1 : 0, n_sets_s, fw, fl, cw, cl, L.sweep ? fy : nullptr, L.sweep ? fz : nullptr,
