@@ -79,6 +79,7 @@ struct Config {
     int relaxed_rays = -1;    // ASURF_RELAXED = n: batches of up to n rays take k_geom / k_bwd_geo without an occupancy bound
     int sum_list = -1;     // ASURF_SUM_LIST=0: the default call (links_epoch = 0) takes the full occupancy pass every time;
                            // =1: the checksum-validated list whatever the grid's size (tests; by default from 128^3 up)
+    int no_cuvol_tile = 0; // ASURF_CUVOL_TILE=0: the cuvol kernels take an image batch (asurf_rays::image_width) by rows
     int tiles = 0;         // ASURF_TILES=1: image batches (asurf_fused_params::image_width) are rendered in tile order
                            // (measured slower with the kernels as they are: include/asurf.h)
     int lazy_rays = -1;    // ASURF_LAZY = n: batches of up to n rays run over planes of `links` alone (asurf_masks2.h);
@@ -121,6 +122,7 @@ bool config_assign(Config& c, const char* name, const char* value) {
     else if (!strcmp(name, "ASURF_OPTIM")) c.optim_two_step = (value && !strcmp(value, "list")) ? 1 : 0;
     else if (!strcmp(name, "ASURF_RELAXED")) c.relaxed_rays = (value && *value) ? std::max(n, 0) : -1;
     else if (!strcmp(name, "ASURF_SUM_LIST")) c.sum_list = (value && !strcmp(value, "0")) ? 0 : (value && !strcmp(value, "1")) ? 1 : -1;
+    else if (!strcmp(name, "ASURF_CUVOL_TILE")) c.no_cuvol_tile = (value && !strcmp(value, "0")) ? 1 : 0;
     else if (!strcmp(name, "ASURF_TILES")) c.tiles = (value && !strcmp(value, "1")) ? 1 : 0;
     else if (!strcmp(name, "ASURF_LAZY")) c.lazy_rays = (value && *value) ? std::max(n, 0) : -1;
     else return false;
@@ -132,7 +134,7 @@ Config config() {  // a copy: a call works with one consistent set
         static const char* const names[] = {"ASURF_DEBUG", "ASURF_WALK_SEG", "ASURF_WALK", "ASURF_RPW", "ASURF_NO_PIPELINE",
                                             "ASURF_CUVOL_RPW", "ASURF_NO_REPLAY", "ASURF_NO_SPLIT_BWD", "ASURF_EVAL",
                                             "ASURF_TIMELINE", "ASURF_SWEEP", "ASURF_SWEEP_WPB", "ASURF_SWEEP_RPW", "ASURF_MASKS", "ASURF_SIDE_STREAM", "ASURF_ORDER",
-                                            "ASURF_LAZY", "ASURF_BWD_SH", "ASURF_TILES", "ASURF_BWD_SORT", "ASURF_BWD_TILE", "ASURF_OPTIM", "ASURF_RELAXED", "ASURF_SUM_LIST"};
+                                            "ASURF_LAZY", "ASURF_BWD_SH", "ASURF_TILES", "ASURF_BWD_SORT", "ASURF_BWD_TILE", "ASURF_OPTIM", "ASURF_RELAXED", "ASURF_SUM_LIST", "ASURF_CUVOL_TILE"};
         std::lock_guard<std::mutex> lock(g_cfg_mu);
         for (const char* nm : names)
             if (const char* v = getenv(nm)) config_assign(g_cfg, nm, v);
@@ -1421,6 +1423,14 @@ static int cuvol_rays_per_wave(long long n_rays) {
     return 64;
 }
 
+// asurf_rays::image_width: 8 x 8 pixel tiles a wave instead of 64 pixels of a row (asurf_cuvol.h), where they partition
+// the image and the batch fills the chip
+static int cuvol_tile_width(const asurf_rays* rays, int rpw) {
+    const long long W = rays->image_width, Q = rays->n_rays;
+    if (W <= 0 || rpw != 64 || config().no_cuvol_tile || (W & 7) != 0 || Q % W != 0 || ((Q / W) & 7) != 0) return 0;
+    return (int)W;
+}
+
 static dim3 cuvol_grid(long long n_rays, int rpw) {
     const long long per_block = (long long)rpw * (kBlock / 64);
     return dim3((unsigned)((n_rays + per_block - 1) / per_block));
@@ -1432,10 +1442,12 @@ int cuvol_fwd(const Launch& L, const asurf_rays* rays, int last_opaque, float* r
     const dim3 grid = cuvol_grid(rays->n_rays, rpw);
     if (L.coarse_in_lds)
         hipLaunchKernelGGL((k_cuvol_fwd<B, true>), grid, dim3(kBlock), L.dyn_lds, L.stream, L.g, L.o,
-                           last_opaque, rpw, rays->origins, rays->dirs, (long long)rays->n_rays, rgb_out, log_t);
+                           last_opaque, rpw, rays->origins, rays->dirs, (long long)rays->n_rays, rgb_out, log_t,
+                           cuvol_tile_width(rays, rpw));
     else
         hipLaunchKernelGGL((k_cuvol_fwd<B, false>), grid, dim3(kBlock), 0, L.stream, L.g, L.o,
-                           last_opaque, rpw, rays->origins, rays->dirs, (long long)rays->n_rays, rgb_out, log_t);
+                           last_opaque, rpw, rays->origins, rays->dirs, (long long)rays->n_rays, rgb_out, log_t,
+                           cuvol_tile_width(rays, rpw));
     prof_after("k_cuvol_fwd", 1, L.stream);
     return launch_error("k_cuvol_fwd");
 }
@@ -1448,11 +1460,11 @@ int cuvol_bwd(const Launch& L, const asurf_rays* rays, int last_opaque, const KG
     if (L.coarse_in_lds)
         hipLaunchKernelGGL((k_cuvol_bwd<B, true>), grid, dim3(kBlock), L.dyn_lds, L.stream, L.g, L.o,
                            last_opaque, rpw, G, rays->origins, rays->dirs, (long long)rays->n_rays, grad_in,
-                           color_cache, is_rgb, log_t, beta_loss, sparsity_loss);
+                           color_cache, is_rgb, log_t, beta_loss, sparsity_loss, cuvol_tile_width(rays, rpw));
     else
         hipLaunchKernelGGL((k_cuvol_bwd<B, false>), grid, dim3(kBlock), 0, L.stream, L.g, L.o,
                            last_opaque, rpw, G, rays->origins, rays->dirs, (long long)rays->n_rays, grad_in,
-                           color_cache, is_rgb, log_t, beta_loss, sparsity_loss);
+                           color_cache, is_rgb, log_t, beta_loss, sparsity_loss, cuvol_tile_width(rays, rpw));
     prof_after("k_cuvol_bwd", 2, L.stream);
     return launch_error("k_cuvol_bwd");
 }
@@ -1663,7 +1675,7 @@ int asurf_volume_render_surf_trav_fused(const asurf_grid* grid, const asurf_rays
     if (replay) {
         ASURF_DISPATCH_B(grid->basis_dim,
                          run_backward<B_>(L, rays, loss, G, rgb_gt_use, rgb_use, M, true, replay_mode, pipe,
-                                          perm == nullptr ? fused->image_width : 0));
+                                          perm == nullptr ? (fused->image_width ? fused->image_width : rays_given->image_width) : 0));
         if (rc) return rc;
         ASURF_DISPATCH_B(grid->basis_dim,
                          run_backward<B_>(side != nullptr ? Lside : L, rays, loss, G, rgb_gt_use, rgb_use, M, true, 2));

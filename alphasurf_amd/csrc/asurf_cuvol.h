@@ -325,11 +325,33 @@ __device__ __forceinline__ void cuvol_load_rows(const KGrid& g, int link, int ch
     }
 }
 
+// The ray of a lane: rpw rays a wave in batch order, or -- an image batch of width tile_w, 64 rays a wave (the host has
+// checked that 8 x 8 tiles partition the image) -- the wave's 8 x 8 pixel tile.
+__device__ __forceinline__ long long cuvol_lane_ray(int rpw, int tile_w) {
+    const int tid = threadIdx.x;
+    const long long wg = (long long)blockIdx.x * (kBlock / 64) + (tid >> 6);
+    if (tile_w > 0) {
+        const int tiles_x = tile_w >> 3, lane = tid & 63;
+        const long long ty = wg / tiles_x, tx = wg - ty * tiles_x;
+        return (ty * 8 + (lane >> 3)) * tile_w + tx * 8 + (lane & 7);
+    }
+    return wg * rpw + (tid & 63);
+}
+
+// The lanes that hold a record this round, in the order of their cells (lane i: the i-th of them; wave_sort64,
+// asurf_bwd_pipeline.h): records of one cell are then served one after the other -- its SH rows fetched once, its
+// gradient rows written once -- wherever the rays that hold them sit in the wave.
+__device__ __forceinline__ int cuvol_serve_order(bool has, int cid) {
+    const int lane = threadIdx.x & 63;
+    const unsigned long long key = has ? (((unsigned long long)(unsigned)cid << 6) | (unsigned)lane) : ~0ull;
+    return (int)(wave_sort64(key) & 63ull);
+}
+
 template <int B, bool CLDS>
 __global__ void __launch_bounds__(kBlock)
 k_cuvol_fwd(KGrid g, KOpt o, int last_sample_opaque, int rpw, const float* __restrict__ origins,
             const float* __restrict__ dirs, long long Q, float* __restrict__ rgb_out,
-            float* __restrict__ log_transmit_out) {
+            float* __restrict__ log_transmit_out, int tile_w) {
     constexpr int SP = CuvolLay<B>::SP;
     extern __shared__ unsigned int s_coarse[];
     __shared__ __attribute__((aligned(16))) float s_sph[kBlock * SP];
@@ -343,7 +365,7 @@ k_cuvol_fwd(KGrid g, KOpt o, int last_sample_opaque, int rpw, const float* __res
     // rpw rays per wave (their lanes 0 .. rpw-1 march; all 64 lanes serve): a wave works its records off one pair
     // after the other, so the length of that chain -- 64 rays x ~60 samples / 2 at ~1.5 us -- is the latency of a call
     // that does not fill the chip; small batches spread their rays over more, shorter-lived waves
-    const long long q = ((long long)blockIdx.x * (kBlock / 64) + (tid >> 6)) * rpw + (tid & 63);
+    const long long q = cuvol_lane_ray(rpw, tile_w);
     const bool valid = (tid & 63) < rpw && q < Q;
     Ray r;
     float world_step;
@@ -388,10 +410,19 @@ k_cuvol_fwd(KGrid g, KOpt o, int last_sample_opaque, int rpw, const float* __res
 #ifdef ASURF_CUVOL_NOSERVE
         need = 0;
 #endif
-        while (need) {
+        // (in cell order for a tile of rays; a row of 64 rays meets its cells in lane order as it is -- there the sort only
+        // costs: forward 7.9 -> 8.3 ms on the bench scene)
+        const int order = tile_w > 0 ? cuvol_serve_order(n > 0, rec_cid) : 0;
+        const int n_rec = __popcll(need);
+        for (int t = 0; t < n_rec; t += 2) {
+            bool two = t + 1 < n_rec;
             int r0, r1;
-            bool two;
-            next_pair(need, &r0, &r1, &two);
+            if (tile_w > 0) {
+                r0 = __builtin_amdgcn_readlane(order, t);
+                r1 = two ? __builtin_amdgcn_readlane(order, t + 1) : r0;
+            } else {
+                next_pair(need, &r0, &r1, &two);
+            }
             const int rr = wbase + (half ? r1 : r0);
             const bool mine = ch < 3 && (half == 0 || two);
             const int cid = s_rec[rr].cid, nr = mine ? s_rec[rr].n : 0;
@@ -445,7 +476,7 @@ __global__ void __launch_bounds__(kBlock)
 k_cuvol_bwd(KGrid g, KOpt o, int last_sample_opaque, int rpw, KGrads G, const float* __restrict__ origins,
             const float* __restrict__ dirs, long long Q, const float* __restrict__ grad_in,
             const float* __restrict__ color_cache, int grad_in_is_rgb,
-            const float* __restrict__ log_transmit_in, float beta_loss, float sparsity_loss) {
+            const float* __restrict__ log_transmit_in, float beta_loss, float sparsity_loss, int tile_w) {
     using C = Coop<B>;
     constexpr int SP = CuvolLay<B>::SP;
     extern __shared__ unsigned int s_coarse[];
@@ -461,7 +492,7 @@ k_cuvol_bwd(KGrid g, KOpt o, int last_sample_opaque, int rpw, KGrads G, const fl
     // rpw rays per wave (their lanes 0 .. rpw-1 march; all 64 lanes serve): a wave works its records off one pair
     // after the other, so the length of that chain -- 64 rays x ~60 samples / 2 at ~1.5 us -- is the latency of a call
     // that does not fill the chip; small batches spread their rays over more, shorter-lived waves
-    const long long q = ((long long)blockIdx.x * (kBlock / 64) + (tid >> 6)) * rpw + (tid & 63);
+    const long long q = cuvol_lane_ray(rpw, tile_w);
     const bool valid = (tid & 63) < rpw && q < Q;
     Ray r;
     float world_step;
@@ -558,10 +589,19 @@ k_cuvol_bwd(KGrid g, KOpt o, int last_sample_opaque, int rpw, KGrads G, const fl
                 }
             }
         };
-        while (need) {
+        // (in cell order for a tile of rays; a row of 64 rays meets its cells in lane order as it is -- there the sort only
+        // costs: forward 7.9 -> 8.3 ms on the bench scene)
+        const int order = tile_w > 0 ? cuvol_serve_order(n > 0, rec_cid) : 0;
+        const int n_rec = __popcll(need);
+        for (int t = 0; t < n_rec; t += 2) {
+            bool two = t + 1 < n_rec;
             int r0, r1;
-            bool two;
-            next_pair(need, &r0, &r1, &two);
+            if (tile_w > 0) {
+                r0 = __builtin_amdgcn_readlane(order, t);
+                r1 = two ? __builtin_amdgcn_readlane(order, t + 1) : r0;
+            } else {
+                next_pair(need, &r0, &r1, &two);
+            }
             // ---- phase A ----
             const int rr = wbase + (half ? r1 : r0);
             const bool mine = ch < 3 && (half == 0 || two);

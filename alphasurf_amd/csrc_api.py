@@ -59,6 +59,7 @@ class RaysSpec:
         self.origins = None
         self.dirs = None
         self.masks = None
+        self.image_width = 0   # extension (asurf_rays::image_width): the rays are a row-major image of this width
 
 
 class RayVoxIntersecSpec:
@@ -199,6 +200,7 @@ def _pack_rays(rays):
     r.dirs = _ptr(rays.dirs)
     r.masks = _ptr(rays.masks)
     r.n_rays = rays.origins.shape[0]
+    r.image_width = int(getattr(rays, "image_width", 0) or 0)
     return r
 
 

@@ -79,6 +79,7 @@ class Rays:
     origins: torch.Tensor
     dirs: torch.Tensor
     masks: Optional[torch.Tensor] = None
+    image_width: int = 0   # extension (asurf_rays::image_width): > 0 says the rays are a row-major image of this width
 
     def __post_init__(self):
         if self.masks is None:
@@ -87,6 +88,7 @@ class Rays:
     def _to_cpp(self):
         spec = _C.RaysSpec()
         spec.origins, spec.dirs, spec.masks = self.origins, self.dirs, self.masks
+        spec.image_width = int(self.image_width or 0)
         return spec
 
     def __getitem__(self, key):
@@ -619,7 +621,10 @@ class SparseGrid(nn.Module):
         holder.mask_out = self.sparse_grad_indexer
         holder.mask_sh_out = sh_indexer
         if backend == "cuvol":  # :3625-3634
-            _C.volume_render_cuvol_fused(self._to_cpp(), rays._to_cpp(), self.opt._to_cpp(randomize=randomize),
+            rspec = rays._to_cpp()
+            if image_width:
+                rspec.image_width = int(image_width)
+            _C.volume_render_cuvol_fused(self._to_cpp(), rspec, self.opt._to_cpp(randomize=randomize),
                                          rgb_gt, beta_loss, sparsity_loss, rgb_out, holder)
             self.sparse_sh_grad_indexer = self.sparse_grad_indexer.clone()
             return finish(rgb_out)
@@ -656,7 +661,10 @@ class SparseGrid(nn.Module):
             return self.volume_render(rays[ids], **kw)["rgb"]
         # (rays per call: _image_batch)
         step = _image_batch(batch_size)
-        parts = [self.volume_render(rays[s:s + step], **kw)["rgb"]
+        # (whole rows a call: the cuvol kernels then take the batch by pixel tiles, asurf_rays::image_width)
+        whole_rows = camera.width if (step % camera.width == 0 or step >= camera.height * camera.width) else 0
+        parts = [self.volume_render(Rays(rays.origins[s:s + step], rays.dirs[s:s + step], rays.masks[s:s + step],
+                                         image_width=whole_rows), **kw)["rgb"]
                  for s in range(0, camera.height * camera.width, step)]
         return torch.cat(parts, dim=0).view(camera.height, camera.width, -1)
 

@@ -31,7 +31,7 @@ class AsurfGrid(C.Structure):
 
 class AsurfRays(C.Structure):
     _fields_ = [("origins", C.c_void_p), ("dirs", C.c_void_p), ("masks", C.c_void_p),
-                ("n_rays", C.c_int64)]
+                ("n_rays", C.c_int64), ("image_width", C.c_int32), ("pad_", C.c_int32)]
 
 
 class AsurfRayVox(C.Structure):

@@ -102,6 +102,13 @@ typedef struct asurf_rays {
     const float* dirs;     /* [n_rays,3] world space, pre-normalised by the caller */
     const uint8_t* masks;  /* [n_rays] bool; carried for ABI parity, unused (surf_trav.cu:1715) */
     int64_t n_rays;
+    /* extension (ABI 4; 0: unknown): > 0 states that the rays are a row-major image (or a stack of images) of this many
+     * rays a row.  The cuvol kernels then give a wave an 8 x 8 pixel tile instead of 64 pixels of a row and serve a
+     * round's records in the order of their cells: a tile's rays pass through the same few cells, whose SH rows are
+     * then fetched once a round and whose gradient rows leave merged.  (The surf_trav fused call takes the same hint
+     * through asurf_fused_params::image_width, or from here when that is 0.) */
+    int32_t image_width;
+    int32_t pad_;
 } asurf_rays;
 
 /* Replaces RayVoxIntersecSpec (data_spec.hpp:156-166), legacy `surface` backend only. */
@@ -511,6 +518,7 @@ int asurf_rows_unpack_add(const int32_t* rows, int64_t n_list, int32_t sh_dim, c
  * batch rendered in tile order throughout, measured slower), ASURF_LAZY (n: batches of up to n rays over planes of
  * `links` alone, measured slower; default 0), ASURF_OPTIM ("list": the masked optimizer steps as list + step kernels),
  * ASURF_RELAXED (n: batches of up to n rays take k_geom / k_bwd_geo compiled without an occupancy bound; default 196608),
+ * ASURF_CUVOL_TILE ("0": the cuvol kernels take an image batch by rows),
  * ASURF_SUM_LIST ("0": the default call takes the full occupancy pass every time; "1": the checksum-vouched list of live
  * rows on grids of any size).
  * The environment variables of these names are read ONCE, by the first entry point that runs; afterwards only this

@@ -60,7 +60,7 @@ def oracle():
 
 _SWITCHES = ("ASURF_DEBUG", "ASURF_WALK_SEG", "ASURF_WALK", "ASURF_RPW", "ASURF_NO_PIPELINE", "ASURF_CUVOL_RPW",
              "ASURF_NO_REPLAY", "ASURF_NO_SPLIT_BWD", "ASURF_EVAL", "ASURF_MASKS", "ASURF_SWEEP", "ASURF_SIDE_STREAM", "ASURF_ORDER",
-             "ASURF_LAZY", "ASURF_BWD_SH", "ASURF_TILES", "ASURF_BWD_TILE", "ASURF_BWD_SORT", "ASURF_OPTIM", "ASURF_RELAXED", "ASURF_SUM_LIST")
+             "ASURF_LAZY", "ASURF_BWD_SH", "ASURF_TILES", "ASURF_BWD_TILE", "ASURF_BWD_SORT", "ASURF_OPTIM", "ASURF_RELAXED", "ASURF_SUM_LIST", "ASURF_CUVOL_TILE")
 
 
 @pytest.fixture(params=["value_planes", "links_planes"])

@@ -53,9 +53,10 @@ def grid_spec(sc, links_epoch=0):
     return g
 
 
-def rays_spec(origins, dirs):
+def rays_spec(origins, dirs, image_width=0):
     d = dev()
     r = _C.RaysSpec()
+    r.image_width = image_width
     r.origins = torch.from_numpy(np.ascontiguousarray(origins, np.float32)).to(d)
     r.dirs = torch.from_numpy(np.ascontiguousarray(dirs, np.float32)).to(d)
     r.masks = torch.ones(r.origins.shape[0], dtype=torch.bool, device=d)
@@ -209,8 +210,8 @@ def cuvol_backward(sc, origins, dirs, opts, grad_out, color_cache):
     return _cuvol_grads_np(gr)
 
 
-def cuvol_fused(sc, origins, dirs, opts, rgb_gt, beta_loss=0.0, sparsity_loss=0.0):
-    g, r, o = grid_spec(sc), rays_spec(origins, dirs), opt_spec(opts)
+def cuvol_fused(sc, origins, dirs, opts, rgb_gt, beta_loss=0.0, sparsity_loss=0.0, image_width=0):
+    g, r, o = grid_spec(sc), rays_spec(origins, dirs, image_width), opt_spec(opts)
     gr = _cuvol_grads(g)
     gt = torch.from_numpy(np.ascontiguousarray(rgb_gt, np.float32)).to(dev())
     rgb = torch.zeros_like(gt)

@@ -291,3 +291,25 @@ def test_rays_per_wave_is_transparent(hip, monkeypatch):
         assert (g["mask"] == ref[1]["mask"]).all()
         for k in ("sh", "density"):
             grad_close(g[k], ref[1][k], 1e-5, f"rpw {rpw} grad_{k}")
+
+
+def test_image_batch_by_pixel_tiles(hip):
+    """asurf_rays::image_width: a wave takes an 8 x 8 pixel tile of the image instead of 64 pixels of a row and serves a
+    round's records in the order of their cells -- the picture bit for bit, the gradients up to the order of the atomic
+    sums; an image the tiles do not partition (width 300) is taken by rows."""
+    from alphasurf_amd import synth
+    sc = synth.make_sparse_scene(64, 9, seed=3, trunc_a=3.0)
+    sc = dict(sc, density=(sc["density"] * 30.0).astype(np.float32))
+    opts = OPTION_SETS["plenoxels"]
+    for width, height in ((320, 264), (300, 250)):
+        o, d = synth.pinhole_rays(synth.orbit_camera(1), width, height)
+        assert o.shape[0] >= 65536     # (64 rays a wave: ASURF_CUVOL_RPW's automatic choice below that is smaller)
+        gt = np.random.RandomState(3).rand(o.shape[0], 3).astype(np.float32)
+        _asurf_lib.config_set("ASURF_CUVOL_RPW", "64")
+        ref = hip.cuvol_fused(sc, o, d, opts, gt, beta_loss=0.05, sparsity_loss=0.01)
+        got = hip.cuvol_fused(sc, o, d, opts, gt, beta_loss=0.05, sparsity_loss=0.01, image_width=width)
+        _asurf_lib.config_set("ASURF_CUVOL_RPW", None)
+        assert float(np.abs(ref[0]).max()) > 0 and np.array_equal(got[0], ref[0]), width
+        assert (got[1]["mask"] == ref[1]["mask"]).all()
+        for k in ("sh", "density"):
+            grad_close(got[1][k], ref[1][k], 1e-5, f"width {width} grad_{k}")

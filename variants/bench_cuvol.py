@@ -7,6 +7,7 @@ from alphasurf_amd import csrc_api as _C, synth
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--width", type=int, default=800)
+ap.add_argument("--no-image-width", action="store_true", help="do not tell the calls that the batch is an image (asurf_rays::image_width)")
 args = ap.parse_args()
 dev = torch.device("cuda:0")
 sc = synth.make_sparse_scene(256, 9, trunc_a=5.0, **synth.BENCH_SCENE)
@@ -19,6 +20,7 @@ o, d = synth.pinhole_rays(synth.orbit_camera(0), args.width, args.width)
 r = _C.RaysSpec()
 r.origins, r.dirs = torch.from_numpy(o).to(dev), torch.from_numpy(d).to(dev)
 r.masks = torch.ones(o.shape[0], dtype=torch.bool, device=dev)
+r.image_width = 0 if args.no_image_width else args.width
 opt = _C.RenderOptions()
 opt.step_size, opt.sigma_thresh, opt.stop_thresh, opt.background_brightness = 0.5, 1e-8, 1e-7, 1.0
 gt = torch.rand(o.shape[0], 3, device=dev)
