@@ -79,7 +79,8 @@ struct Config {
     int relaxed_rays = -1;    // ASURF_RELAXED = n: batches of up to n rays take k_geom / k_bwd_geo without an occupancy bound
     int sum_list = -1;     // ASURF_SUM_LIST=0: the default call (links_epoch = 0) takes the full occupancy pass every time;
                            // =1: the checksum-validated list whatever the grid's size (tests; by default from 128^3 up)
-    int no_cuvol_tile = 0; // ASURF_CUVOL_TILE=0: the cuvol kernels take an image batch (asurf_rays::image_width) by rows
+    int cuvol_tile = 8;    // ASURF_CUVOL_TILE = 0 | 4 | 8 | 16: width of the pixel tile a wave of the cuvol kernels takes of an image
+                           // batch (asurf_rays::image_width; 0: rows)
     int tiles = 0;         // ASURF_TILES=1: image batches (asurf_fused_params::image_width) are rendered in tile order
                            // (measured slower with the kernels as they are: include/asurf.h)
     int lazy_rays = -1;    // ASURF_LAZY = n: batches of up to n rays run over planes of `links` alone (asurf_masks2.h);
@@ -122,7 +123,7 @@ bool config_assign(Config& c, const char* name, const char* value) {
     else if (!strcmp(name, "ASURF_OPTIM")) c.optim_two_step = (value && !strcmp(value, "list")) ? 1 : 0;
     else if (!strcmp(name, "ASURF_RELAXED")) c.relaxed_rays = (value && *value) ? std::max(n, 0) : -1;
     else if (!strcmp(name, "ASURF_SUM_LIST")) c.sum_list = (value && !strcmp(value, "0")) ? 0 : (value && !strcmp(value, "1")) ? 1 : -1;
-    else if (!strcmp(name, "ASURF_CUVOL_TILE")) c.no_cuvol_tile = (value && !strcmp(value, "0")) ? 1 : 0;
+    else if (!strcmp(name, "ASURF_CUVOL_TILE")) c.cuvol_tile = (!value || !*value) ? 8 : (n == 4 || n == 8 || n == 16) ? n : 0;
     else if (!strcmp(name, "ASURF_TILES")) c.tiles = (value && !strcmp(value, "1")) ? 1 : 0;
     else if (!strcmp(name, "ASURF_LAZY")) c.lazy_rays = (value && *value) ? std::max(n, 0) : -1;
     else return false;
@@ -1427,8 +1428,9 @@ static int cuvol_rays_per_wave(long long n_rays) {
 // the image and the batch fills the chip
 static int cuvol_tile_width(const asurf_rays* rays, int rpw) {
     const long long W = rays->image_width, Q = rays->n_rays;
-    if (W <= 0 || rpw != 64 || config().no_cuvol_tile || (W & 7) != 0 || Q % W != 0 || ((Q / W) & 7) != 0) return 0;
-    return (int)W;
+    const int tw = config().cuvol_tile;   // 0: rows; 4 / 8 / 16: the tile's width
+    if (W <= 0 || W >= (1 << 24) || rpw != 64 || tw == 0 || W % tw != 0 || Q % W != 0 || (Q / W) % (64 / tw) != 0) return 0;
+    return (int)W | (tw << 24);
 }
 
 static dim3 cuvol_grid(long long n_rays, int rpw) {

@@ -331,9 +331,11 @@ __device__ __forceinline__ long long cuvol_lane_ray(int rpw, int tile_w) {
     const int tid = threadIdx.x;
     const long long wg = (long long)blockIdx.x * (kBlock / 64) + (tid >> 6);
     if (tile_w > 0) {
-        const int tiles_x = tile_w >> 3, lane = tid & 63;
+        // (the tile's width in the top byte: 4, 8 or 16 pixels; its height 64 / that)
+        const int tw = tile_w >> 24, W = tile_w & 0xffffff, th = 64 / tw;
+        const int tiles_x = W / tw, lane = tid & 63;
         const long long ty = wg / tiles_x, tx = wg - ty * tiles_x;
-        return (ty * 8 + (lane >> 3)) * tile_w + tx * 8 + (lane & 7);
+        return (ty * th + lane / tw) * W + tx * tw + (lane % tw);
     }
     return wg * rpw + (tid & 63);
 }

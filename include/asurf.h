@@ -518,7 +518,7 @@ int asurf_rows_unpack_add(const int32_t* rows, int64_t n_list, int32_t sh_dim, c
  * batch rendered in tile order throughout, measured slower), ASURF_LAZY (n: batches of up to n rays over planes of
  * `links` alone, measured slower; default 0), ASURF_OPTIM ("list": the masked optimizer steps as list + step kernels),
  * ASURF_RELAXED (n: batches of up to n rays take k_geom / k_bwd_geo compiled without an occupancy bound; default 196608),
- * ASURF_CUVOL_TILE ("0": the cuvol kernels take an image batch by rows),
+ * ASURF_CUVOL_TILE (0 / 4 / 8 / 16: width of the pixel tile of an image batch in the cuvol kernels; 0: rows),
  * ASURF_SUM_LIST ("0": the default call takes the full occupancy pass every time; "1": the checksum-vouched list of live
  * rows on grids of any size).
  * The environment variables of these names are read ONCE, by the first entry point that runs; afterwards only this

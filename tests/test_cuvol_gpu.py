@@ -307,9 +307,12 @@ def test_image_batch_by_pixel_tiles(hip):
         gt = np.random.RandomState(3).rand(o.shape[0], 3).astype(np.float32)
         _asurf_lib.config_set("ASURF_CUVOL_RPW", "64")
         ref = hip.cuvol_fused(sc, o, d, opts, gt, beta_loss=0.05, sparsity_loss=0.01)
-        got = hip.cuvol_fused(sc, o, d, opts, gt, beta_loss=0.05, sparsity_loss=0.01, image_width=width)
+        for tile in (None, "4", "16"):     # (8 pixels wide by default)
+            _asurf_lib.config_set("ASURF_CUVOL_TILE", tile)
+            got = hip.cuvol_fused(sc, o, d, opts, gt, beta_loss=0.05, sparsity_loss=0.01, image_width=width)
+            assert float(np.abs(ref[0]).max()) > 0 and np.array_equal(got[0], ref[0]), (width, tile)
+            assert (got[1]["mask"] == ref[1]["mask"]).all()
+            for k in ("sh", "density"):
+                grad_close(got[1][k], ref[1][k], 1e-5, f"width {width} tile {tile} grad_{k}")
+        _asurf_lib.config_set("ASURF_CUVOL_TILE", None)
         _asurf_lib.config_set("ASURF_CUVOL_RPW", None)
-        assert float(np.abs(ref[0]).max()) > 0 and np.array_equal(got[0], ref[0]), width
-        assert (got[1]["mask"] == ref[1]["mask"]).all()
-        for k in ("sh", "density"):
-            grad_close(got[1][k], ref[1][k], 1e-5, f"width {width} grad_{k}")
