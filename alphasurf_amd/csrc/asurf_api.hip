@@ -1213,7 +1213,7 @@ int run_forward(const Launch& L, const asurf_rays* rays, float* rgb_out, int M, 
 template <int B>
 int run_backward(const Launch& L, const asurf_rays* rays, const KLoss& loss, const KGrads& G,
                  const float* grad_in, const float* color_cache, int M, bool fused, int mode,
-                 bool counters_zeroed = false, int image_width = 0) {
+                 bool counters_zeroed = false, int image_width = 0, bool pipeline_ran = false) {
     const float* ca = reinterpret_cast<const float*>(L.ws + L.ML.off_cache_a);
     const float* cw = reinterpret_cast<const float*>(L.ws + L.ML.off_cache_w);
     const float* ct = reinterpret_cast<const float*>(L.ws + L.ML.off_cache_t);
@@ -1222,11 +1222,15 @@ int run_backward(const Launch& L, const asurf_rays* rays, const KLoss& loss, con
     const int* rm = reinterpret_cast<const int*>(L.ws + L.ML.off_rec_m);
     const int* rn = reinterpret_cast<const int*>(L.ws + L.ML.off_rec_n);
     const int* filter = (mode == 2) ? rn : nullptr;
+    // (mode 2 behind the pipeline: the counters that say whether any ray was left to this launch)
+    const int* ctr = reinterpret_cast<const int*>(L.ws + L.ML.off_p_counters);
+    const int* any_a = (mode == 2 && pipeline_ran) ? ctr : nullptr;
+    const int* any_b = (mode == 2 && pipeline_ran) ? ctr + kCtrRecOver : nullptr;
 #define ASURF_BWD(FUSED, CLDS, REC)                                                               \
     hipLaunchKernelGGL((k_backward<B, FUSED, CLDS, REC>), L.ray_grid, dim3(kBlock),               \
                        (REC) ? 0 : L.dyn_lds, L.stream, L.g, L.o, loss, G, rays->origins,          \
                        rays->dirs, (long long)rays->n_rays, grad_in, color_cache, M, ca, cw, ct,  \
-                       cn, rv, rm, rn, filter)
+                       cn, rv, rm, rn, filter, any_a, any_b)
     if (mode == 3) {
         // split replay: sequential scalars per ray, then one sample per wave step (SH) and
         // one sample per lane (geometry)
@@ -1680,7 +1684,8 @@ int asurf_volume_render_surf_trav_fused(const asurf_grid* grid, const asurf_rays
                                           perm == nullptr ? (fused->image_width ? fused->image_width : rays_given->image_width) : 0));
         if (rc) return rc;
         ASURF_DISPATCH_B(grid->basis_dim,
-                         run_backward<B_>(side != nullptr ? Lside : L, rays, loss, G, rgb_gt_use, rgb_use, M, true, 2));
+                         run_backward<B_>(side != nullptr ? Lside : L, rays, loss, G, rgb_gt_use, rgb_use, M, true, 2, false, 0,
+                                          pipe));
         if (rc) return rc;
         if (side != nullptr) {   // join
             if (hipEventRecord(side->ev_join, side->stream) != hipSuccess ||

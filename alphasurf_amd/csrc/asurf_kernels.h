@@ -1419,11 +1419,14 @@ k_backward(KGrid g, KOpt o, KLoss L, KGrads G, const float* __restrict__ origins
            const float* __restrict__ cache_w, const float* __restrict__ cache_t,
            const int* __restrict__ cache_n, const int* __restrict__ rec_v,
            const int* __restrict__ rec_m, const int* __restrict__ rec_n,
-           const int* __restrict__ ray_filter) {
+           const int* __restrict__ ray_filter, const int* __restrict__ any_a, const int* __restrict__ any_b) {
     extern __shared__ unsigned int s_coarse[];
     __shared__ float s_sph[kBlock * kSphPad];
     __shared__ LaneRec s_rec[kBlock];
     const int tid = threadIdx.x;
+    // (the fused call's walking backward: two words say whether ANY ray was left to it -- rays handed to the one-kernel
+    // path, rays whose sample records did not fit: on nearly every call neither, and the launch is two scalar loads)
+    if (any_a != nullptr && *any_a == 0 && *any_b == 0) return;
     const long long q = (long long)blockIdx.x * kBlock + tid;
     bool valid = q < Q;
     if (valid) {

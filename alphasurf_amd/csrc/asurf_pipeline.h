@@ -81,7 +81,10 @@ constexpr int kBandRaysMax = 8192, kBandRaysMin = 256;  // powers of two; every 
 #endif
 constexpr int kRecShards = ASURF_REC_SHARDS;
 constexpr int kCtrRecShard0 = kCtrListShard0 + kListSegs * kCtrShardStride;
-constexpr int kCtrTotal = kCtrRecShard0 + kRecShards * kCtrShardStride;
+// [kCtrRecOver]: some ray's sample records did not fit (k_comp / the one-kernel forward): with [0] -- rays handed to the
+// one-kernel path -- what tells the walking backward of the fused call at a glance that it has nothing to do
+constexpr int kCtrRecOver = kCtrRecShard0 + kRecShards * kCtrShardStride;
+constexpr int kCtrTotal = kCtrRecOver + kCtrShardStride;
 constexpr int kListRayBits = 27;  // rays per call < 2^27 for the list-driven kernels
 constexpr int kRecRayBits = 25;   // the backward's record list: record << 25 | ray (records a ray <= 128, rays < 2^25)
 // The kernels that work through a dense list are launched with a fixed number of blocks and
@@ -852,6 +855,7 @@ k_comp(KGrid g, KOpt o, const float* __restrict__ dirs, long long Q, PipeBuf P,
         for (int k = 0; k < 3; ++k) rgb_out[3 * q + k] = outv[k] + bg;
         if (CACHE) cache_n[q] = sample_i;
         if (do_rec) rec_n[q] = rec_over ? -1 : rec_cnt;
+        if (do_rec && rec_over) P.counters[kCtrRecOver] = 1;
     }
 }
 
