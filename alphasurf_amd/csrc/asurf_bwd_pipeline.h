@@ -9,17 +9,22 @@
 //               index of the fused losses, stop_thresh) and every term that needs the ray's
 //               sample cache; emits per sample: weight, dL/dcolour per channel, the first part
 //               of dL/d(rwalpha) and of dL/dt; appends the visited (record, ray) cells to a dense
-//               list, record-major within a wave (neighbouring entries = neighbouring rays).
+//               list, record-major within a wave (neighbouring entries = neighbouring rays; for an
+//               image batch the wave's 64 rays are an 8 x 8 pixel tile: round 4).
 //   k_bwd_sh  : one SAMPLE per wave step over that list, lanes = (corner, SH coefficient) --
-//               contributions of consecutive samples in the same voxel are summed in registers
-//               and flushed with row-contiguous atomics into grad_sh; d/dpos of the colour from
-//               the voxel's SH rows held in registers.
-//   k_bwd_geo : one SAMPLE per lane over the list -- reloads the voxel, classifies the cubic
-//               (the forward stored the position), finishes dL/d(raw alpha) and dL/dt, root
-//               gradient; a segmented shuffle reduction merges the density / surface
-//               contributions of neighbouring lanes in the same voxel before the scatter.
+//               a chunk of 64 entries (two chunks for a long list) is sorted by voxel first
+//               (wave_sort64 / wave_sort128); contributions of consecutive samples in the same
+//               voxel are summed in registers, the rows of a face shared with the next voxel are
+//               carried over, the rest is flushed with row-contiguous atomics into grad_sh; d/dpos
+//               of the colour from the voxel's SH rows held in registers.
+//   k_bwd_geo : one SAMPLE per lane over the list (chunks sorted likewise) -- reloads the voxel,
+//               classifies the cubic (the forward stored the position), finishes dL/d(raw alpha)
+//               and dL/dt, root gradient; a segmented shuffle reduction merges the density /
+//               surface contributions of neighbouring lanes in the same voxel before the scatter.
 //
 // The last two are launched with a fixed grid of kListBlocks blocks that stride over the list.
+// What an atomic costs there: one request at the L2 per 64-byte line an instruction touches, 21 G
+// requests/s on the whole chip (variants/micro/atomics.hip) -- fewer, longer runs are the lever.
 #pragma once
 #include "asurf_kernels.h"
 #include "asurf_pipeline.h"
