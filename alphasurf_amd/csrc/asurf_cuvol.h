@@ -308,6 +308,16 @@ struct alignas(16) CuvolRec {
     int pad;
 };
 
+// The forward's: no loss gradient, 48 bytes -- with the samples as three floats the block's LDS is 36 KB + the coarse
+// bitmap, four blocks a CU instead of three (the kernel waits for memory 56 % of its wave cycles).
+struct alignas(16) CuvolRecF {
+    int link[8];
+    int cid, n, pad0, pad1;
+};
+struct CuvolF3 {
+    float x, y, z;
+};
+
 template <int B>
 struct CuvolLay {
     static constexpr int SP = (B + 3) / 4 * 4;  // LDS floats per ray for its SH basis
@@ -350,15 +360,15 @@ __device__ __forceinline__ int cuvol_serve_order(bool has, int cid) {
 }
 
 template <int B, bool CLDS>
-__global__ void __launch_bounds__(kBlock)
+__global__ void __launch_bounds__(kBlock, (B <= 9 ? 4 : 2))
 k_cuvol_fwd(KGrid g, KOpt o, int last_sample_opaque, int rpw, const float* __restrict__ origins,
             const float* __restrict__ dirs, long long Q, float* __restrict__ rgb_out,
             float* __restrict__ log_transmit_out, int tile_w) {
     constexpr int SP = CuvolLay<B>::SP;
     extern __shared__ unsigned int s_coarse[];
     __shared__ __attribute__((aligned(16))) float s_sph[kBlock * SP];
-    __shared__ CuvolRec s_rec[kBlock];
-    __shared__ float4 s_smp[kBlock * kCuvolK];
+    __shared__ CuvolRecF s_rec[kBlock];
+    __shared__ CuvolF3 s_smp[kBlock * kCuvolK];
     const int tid = threadIdx.x;
     if constexpr (CLDS) {
         for (int i = tid; i < g.coarse_words; i += kBlock) s_coarse[i] = g.coarse[i];
@@ -406,7 +416,13 @@ k_cuvol_fwd(KGrid g, KOpt o, int last_sample_opaque, int rpw, const float* __res
             s_rec[tid].cid = rec_cid;
             s_rec[tid].n = n;
 #pragma unroll
-            for (int j = 0; j < kCuvolK; ++j) s_smp[tid * kCuvolK + j] = make_float4(smp[j].px, smp[j].py, smp[j].pz, 0.f);
+            for (int j = 0; j < kCuvolK; ++j) {
+                CuvolF3 p3;
+                p3.x = smp[j].px;
+                p3.y = smp[j].py;
+                p3.z = smp[j].pz;
+                s_smp[tid * kCuvolK + j] = p3;
+            }
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
 #ifdef ASURF_CUVOL_NOSERVE
@@ -439,7 +455,7 @@ k_cuvol_fwd(KGrid g, KOpt o, int last_sample_opaque, int rpw, const float* __res
 #pragma unroll
             for (int j = 0; j < kCuvolK; ++j) {
                 if (j < jmax) {
-                    const float4 p = s_smp[rr * kCuvolK + j];
+                    const CuvolF3 p = s_smp[rr * kCuvolK + j];
                     float a = j < nr ? corner_w(c << 0, p.x, p.y, p.z) * d : 0.f;
                     a = dpp_sum8(a);
                     if (c == 7 && j < nr) reinterpret_cast<float*>(&s_smp[rr * kCuvolK + j])[ch] = a;
@@ -450,7 +466,7 @@ k_cuvol_fwd(KGrid g, KOpt o, int last_sample_opaque, int rpw, const float* __res
 #pragma unroll
         for (int j = 0; j < kCuvolK; ++j) {
             if (j < n) {
-                const float4 col = s_smp[tid * kCuvolK + j];
+                const CuvolF3 col = s_smp[tid * kCuvolK + j];
                 outv[0] += smp[j].w * fmaxf(col.x + 0.5f, 0.f);
                 outv[1] += smp[j].w * fmaxf(col.y + 0.5f, 0.f);
                 outv[2] += smp[j].w * fmaxf(col.z + 0.5f, 0.f);
@@ -473,8 +489,10 @@ k_cuvol_fwd(KGrid g, KOpt o, int last_sample_opaque, int rpw, const float* __res
 // SH coefficient as in coop_shade_bwd): grad_sh[c][e] += A[ch(e)][c] * sph[k(e)], accumulated in
 // registers while consecutive records name the same cell and flushed as row-contiguous atomics.
 // ------------------------------------------------------------------------------------
+// (three waves a SIMD: left to itself the compiler takes 172 registers, four over what three waves allow -- the kernel
+// waits for memory 57 % of its wave cycles, every wave more hides some of it)
 template <int B, bool CLDS>
-__global__ void __launch_bounds__(kBlock)
+__global__ void __launch_bounds__(kBlock, (B <= 9 ? 3 : 2))
 k_cuvol_bwd(KGrid g, KOpt o, int last_sample_opaque, int rpw, KGrads G, const float* __restrict__ origins,
             const float* __restrict__ dirs, long long Q, const float* __restrict__ grad_in,
             const float* __restrict__ color_cache, int grad_in_is_rgb,
