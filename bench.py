@@ -113,6 +113,14 @@ ATOMIC_PEAK_GREQ = 21.0         # G atomic requests/s at the L2, one per 64-byte
                                 # 8 / 16 / 27 / 32 / 64 floats all run at 20.7-21.2 G lines/s; 21 G x 64 B = the 1.3 TB/s above)
 N_SIMD, CLOCK_HZ, VALU_CYCLES = 1024, 2.4e9, 2   # 256 CUs x 4 SIMD-32; a wave64 VALU instruction holds its SIMD 2 cycles
 ATOMIC_KERNELS = ("k_bwd_sh", "k_bwd_geo", "k_backward_fallback")
+# What a wave64 vector instruction of each kernel costs its SIMD ON AVERAGE, by the kernel's static instruction mix
+# (variants/isa_mix.py over the library's ISA) priced with the per-class costs variants/micro/issue_mix.hip measured
+# (profiles/r4_micro_issue_mix.txt: f32 fma/add/mul, integer add and the bit-wise logic 2.6-2.9 cycles; shifts, bit
+# fields, compares, selects, integer multiplies, conversions 4.2-4.5; f64 4.9; rcp/sqrt 8.3).  `valu_mix_frac` prices a
+# kernel's instructions with ITS figure; `valu_issue_frac` -- the one `frac` and `bound` use -- with the 2 cycles of
+# the fma rate, which no kernel of this path can reach.
+VALU_MIX_CYCLES = {"k_build_masks2": 4.01, "k_sweep": 3.67, "k_geom": 4.18, "k_comp": 3.78, "k_bwd_seq": 3.88,
+                   "k_bwd_sh": 3.89, "k_bwd_geo": 4.45}
 
 
 def config_key(a):
@@ -137,7 +145,7 @@ def load_counters(path, cfg_key):
     return None
 
 
-def kernel_ceilings(ms, c):
+def kernel_ceilings(ms, c, name=None):
     """Utilisation of the three ceilings this path can meet, each a fraction <= 1 of a hardware rate, from the
     kernel's measured time and its PMC counters: HBM (FETCH_SIZE doubled + WRITE_SIZE, the guide's gfx950
     correction), VALU issue (SQ_INSTS_VALU x 2 cycles over 1024 SIMDs at 2.4 GHz) and, for the scatter kernels, float
@@ -153,6 +161,8 @@ def kernel_ceilings(ms, c):
         out["hbm_frac"] = round(c["hbm_bytes"] / t / 1e9 / HBM_PEAK_GBPS, 4)
     if c.get("valu_insts") is not None:
         out["valu_issue_frac"] = round(c["valu_insts"] * VALU_CYCLES / (N_SIMD * CLOCK_HZ * t), 4)
+        if name in VALU_MIX_CYCLES:
+            out["valu_mix_frac"] = round(c["valu_insts"] * VALU_MIX_CYCLES[name] / (N_SIMD * CLOCK_HZ * t), 4)
     if c.get("atomic_requests") is not None and c.get("atomic_bytes") is not None:   # (the scatter kernels only)
         out["atomic_Greq_s"] = round(c["atomic_requests"] / t / 1e9, 2)
         out["atomic_frac"] = round(c["atomic_requests"] / t / 1e9 / ATOMIC_PEAK_GREQ, 4)
@@ -180,7 +190,7 @@ def build_roofline(spans, shares, dom_name, call_ms, model_bytes, cfg_key, count
         if c is not None:
             c = dict(c)
             c["atomic_bytes"] = c.get("write_bytes") if name in ATOMIC_KERNELS else None
-        ceil[name] = kernel_ceilings(ms, c)
+        ceil[name] = kernel_ceilings(ms, c, name)
     dom = ceil[dom_name]
     dom_ms = spans[dom_name]
     model_dom = shares.get(dom_name, 0.0)
@@ -223,7 +233,7 @@ def build_roofline(spans, shares, dom_name, call_ms, model_bytes, cfg_key, count
                 ceilings=ceil, whole_call=whole, counters_file=os.path.relpath(counters_path, ROOT),
                 note="frac = utilisation of the ceiling that binds the dominant kernel; ceilings: every kernel against "
                      "HBM bytes (PMC FETCH_SIZE x 2 + WRITE_SIZE), VALU issue (SQ_INSTS_VALU x 2 cycles / 1024 SIMDs / "
-                     "2.4 GHz) and, for the scatter kernels, atomic requests at the L2 (TCC_ATOMIC_sum against the 21 G 64-byte "
+                     "2.4 GHz -- the fma rate; valu_mix_frac prices the same count with the kernel's own mix, variants/isa_mix.py) and, for the scatter kernels, atomic requests at the L2 (TCC_ATOMIC_sum against the 21 G 64-byte "
                      "line requests/s variants/micro/atomics.hip reaches); wait_frac = SQ_WAIT_ANY / SQ_WAVE_CYCLES",
                 reference_model=ref_model)
 

@@ -28,6 +28,7 @@ run heavy_fake --heavy fake --no-cpu-baseline
 for a in "--rays 5184 --verify" "--rays 5184 --graph" "--rays 5184 --graph --graph-static" "--rays 100000" "" "--graph"; do timeout -k 10 200 python variants/bench_iteration.py $a 2>/dev/null | tail -1; done > $O/${TAG}_bench_training_iteration.json
 python variants/host_overhead.py 2>/dev/null | tail -3 > $O/${TAG}_host_overhead.txt
 ./variants/micro/issue > $O/${TAG}_micro_issue.txt 2>&1
+./variants/micro/issue_mix > $O/${TAG}_micro_issue_mix.txt 2>&1 || true
 ./variants/micro/atomics > $O/${TAG}_micro_atomics.txt 2>&1 || true
 timeout -k 10 300 python variants/bench_eval.py > $O/${TAG}_bench_eval_renders.json 2>/dev/null || true
 cat $O/${TAG}_bench_training_iteration.json $O/${TAG}_host_overhead.txt
