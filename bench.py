@@ -115,12 +115,13 @@ N_SIMD, CLOCK_HZ, VALU_CYCLES = 1024, 2.4e9, 2   # 256 CUs x 4 SIMD-32; a wave64
 ATOMIC_KERNELS = ("k_bwd_sh", "k_bwd_geo", "k_backward_fallback")
 # What a wave64 vector instruction of each kernel costs its SIMD ON AVERAGE, by the kernel's static instruction mix
 # (variants/isa_mix.py over the library's ISA) priced with the per-class costs variants/micro/issue_mix.hip measured
-# (profiles/r4_micro_issue_mix.txt: f32 fma/add/mul, integer add and the bit-wise logic 2.6-2.9 cycles; shifts, bit
-# fields, compares, selects, integer multiplies, conversions 4.2-4.5; f64 4.9; rcp/sqrt 8.3).  `valu_mix_frac` prices a
+# (profiles/r4_micro_issue_mix.txt: f32 fma/add/mul, integer add/sub, two-operand bit-wise logic and moves 2.5-3.0
+# cycles; shifts, bit fields, compares, selects, min/max, three-operand integer forms, integer multiplies, conversions,
+# readlane 4.2-4.7; f64 4.9-5.0; rcp/sqrt 8.3-8.6).  `valu_mix_frac` prices a
 # kernel's instructions with ITS figure; `valu_issue_frac` -- the one `frac` and `bound` use -- with the 2 cycles of
 # the fma rate, which no kernel of this path can reach.
-VALU_MIX_CYCLES = {"k_build_masks2": 4.01, "k_sweep": 3.67, "k_geom": 4.18, "k_comp": 3.78, "k_bwd_seq": 3.88,
-                   "k_bwd_sh": 3.89, "k_bwd_geo": 4.45}
+VALU_MIX_CYCLES = {"k_build_masks2": 4.04, "k_sweep": 3.87, "k_geom": 4.23, "k_comp": 3.87, "k_bwd_seq": 3.95,
+                   "k_bwd_sh": 3.94, "k_bwd_geo": 4.47}
 
 
 def config_key(a):

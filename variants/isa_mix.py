@@ -10,9 +10,12 @@ kernel or an optimistic one."""
 import collections, json, re, sys
 
 # cycles a wave64 instruction occupies its SIMD, four waves a SIMD, 2.4 GHz nominal (profiles/r4_micro_issue_mix.txt)
-COST = {"full": 2.7, "half": 4.4, "f64": 4.9, "trans": 8.3}
-FULL = re.compile(r"v_(fma|fmac|mac|mad|add|sub|subrev|mul|min|max)_f32|v_(add|sub|subrev)_(u32|i32|co_u32)|v_(addc|subb|subbrev)_co_u32|"
-                  r"v_(and|or|xor|not|and_or|or3|xad|bfi)_b32|v_mov_b32|v_(add3|lshl_add|add_lshl|lshl_or)_u32|v_accvgpr|v_fma_mix")
+COST = {"full": 2.8, "half": 4.4, "f64": 4.9, "trans": 8.4}
+# full rate (measured: fma / add / mul f32, add / sub u32, and_b32, mov; assumed alike: the other two-operand adds,
+# subtractions and bit-wise logic).  Measured HALF rate and therefore not here: v_min / v_max (f32 and i32), every
+# three-operand integer form (v_lshl_add_u32, v_or3_b32, v_mad_u32_u24, ...), v_bcnt, v_readlane.
+FULL = re.compile(r"v_(fma|fmac|mac|mad|add|sub|subrev|mul)_f32|v_(add|sub|subrev)_(u32|i32|co_u32)|v_(addc|subb|subbrev)_co_u32|"
+                  r"v_(and|or|xor|not)_b32|v_mov_b32|v_fma_mix")
 TRANS = re.compile(r"v_(rcp|rsq|sqrt|exp|log|sin|cos)_(f32|f16|f64)|v_rcp_iflag")
 F64 = re.compile(r"v_\w+_f64")
 

@@ -4,8 +4,10 @@
 //   hipcc --offload-arch=gfx950 -O3 -o issue_mix issue_mix.hip && ./issue_mix
 // Each wave runs a loop of 64 independent instructions of ONE class (8 accumulators x 8), no memory, four waves a SIMD.
 // Findings (profiles/r4_micro_issue_mix.txt):
-//   * f32 fma / add / mul, integer add, bit-wise logic: 2.6 - 3.1 cycles; shifts, bit fields, compares, selects,
-//     integer multiplies, conversions, 64-bit shifts, packed fma: 4.2 - 4.7; f64: 4.8 - 5.2; rcp / sqrt: 8.3 - 8.5.
+//   * f32 fma / add / mul, integer add / sub, two-operand bit-wise logic, v_mov: 2.5 - 3.1 cycles; shifts, bit fields,
+//     compares, selects, v_min / v_max (f32, i32), three-operand integer forms (v_lshl_add_u32, v_or3_b32,
+//     v_mad_u32_u24), v_bcnt, v_readlane, integer multiplies, conversions, v_floor, 64-bit shifts, packed fma:
+//     4.2 - 4.7; f64: 4.8 - 5.2; rcp / sqrt: 8.3 - 8.6.
 //     variants/isa_mix.py prices a kernel's static mix with these (bench.py's valu_mix_frac).
 //   * v_cndmask_b32 in its SHORT encoding (VOP2, `_e32`: the condition is the implicit VCC) costs 4.4 cycles the first
 //     time it reads a freshly written VCC and ~18 every further time: a compare followed by eight selects on the same
@@ -43,6 +45,16 @@
 #define S_CND1(i) "v_cndmask_b32 %" #i ", %" #i ", %9, vcc\n"
 #define S_CND1S(i) "v_cndmask_b32_e64 %" #i ", %" #i ", %9, s[20:21]\n"
 #define S_CND1V64(i) "v_cndmask_b32_e64 %" #i ", %" #i ", %9, vcc\n"
+#define S_MOV(i) "v_mov_b32 %" #i ", %8\n"
+#define S_MAXF(i) "v_max_f32 %" #i ", %" #i ", %8\n"
+#define S_MAXI(i) "v_max_i32 %" #i ", %" #i ", %8\n"
+#define S_FLOOR(i) "v_floor_f32 %" #i ", %" #i "\n"
+#define S_LSHLADD(i) "v_lshl_add_u32 %" #i ", %" #i ", 1, %8\n"
+#define S_OR3(i) "v_or3_b32 %" #i ", %" #i ", %8, %9\n"
+#define S_BCNT(i) "v_bcnt_u32_b32 %" #i ", %" #i ", %8\n"
+#define S_MAD24(i) "v_mad_u32_u24 %" #i ", %" #i ", %8, %9\n"
+#define S_RDLANE(i) "v_readlane_b32 s20, %" #i ", 3\n"
+#define S_SUBU(i) "v_sub_u32 %" #i ", %" #i ", %8\n"
 #define S_CNDS(i) "v_cndmask_b32_e64 %" #i ", %" #i ", %8, s[20:21]\n"
 #define S_CNDK(i) "v_cndmask_b32 %" #i ", 0, %" #i ", vcc\n"
 #define S_CNDD(i) "v_cndmask_b32 %" #i ", %9, %8, vcc\n"
@@ -76,6 +88,16 @@ __global__ void __launch_bounds__(256) k_mix(float* out, int iters) {
                 if constexpr (KIND == 11) RUN32(S_SQRT, m, c);
                 if constexpr (KIND == 12) RUN32(S_CVT, m, c);
                 if constexpr (KIND == 18) RUN32(S_CNDS, m, c);
+                if constexpr (KIND == 40) RUN32(S_MOV, m, c);
+                if constexpr (KIND == 41) RUN32(S_MAXF, m, c);
+                if constexpr (KIND == 42) RUN32(S_MAXI, um, c);
+                if constexpr (KIND == 43) RUN32(S_FLOOR, m, c);
+                if constexpr (KIND == 44) RUN32(S_LSHLADD, um, c);
+                if constexpr (KIND == 45) RUN32(S_OR3, um, c);
+                if constexpr (KIND == 46) RUN32(S_BCNT, um, c);
+                if constexpr (KIND == 47) RUN32(S_MAD24, um, c);
+                if constexpr (KIND == 48) RUN32(S_RDLANE, um, c);
+                if constexpr (KIND == 49) RUN32(S_SUBU, um, c);
                 if constexpr (KIND == 24) RUN32(S_TRIV, m, c);
                 if constexpr (KIND == 26) RUNG("v_cmp_lt_f32 vcc, %0, %8\n");
                 if constexpr (KIND == 27) RUNG("v_cmp_lt_f32_e64 s[20:21], %0, %8\n s_xor_b64 vcc, s[20:21], s[22:23]\n");
@@ -149,6 +171,16 @@ int main() {
     run<10>("v_rcp_f32", out);
     run<11>("v_sqrt_f32", out);
     run<12>("v_cvt_f32_i32", out);
+    run<40>("v_mov_b32", out);
+    run<41>("v_max_f32", out);
+    run<42>("v_max_i32", out);
+    run<43>("v_floor_f32", out);
+    run<44>("v_lshl_add_u32", out);
+    run<45>("v_or3_b32", out);
+    run<46>("v_bcnt_u32_b32", out);
+    run<47>("v_mad_u32_u24", out);
+    run<48>("v_readlane_b32", out);
+    run<49>("v_sub_u32", out);
     run<13>("v_fma_f64", out);
     run<14>("v_add_f64", out);
     run<15>("v_mul_f64", out);
