@@ -1607,6 +1607,11 @@ int asurf_volume_render_surf_trav_fused(const asurf_grid* grid, const asurf_rays
     const asurf_rays* rays_given = rays;
     const bool tiles = rays->n_rays >= kOrderMinRays && fused->order_rays != 1 && fused->image_width >= 16 &&
                        rays->n_rays % fused->image_width == 0 && rays->n_rays / fused->image_width >= 16 && config().tiles;
+    // rays DECLARED to come in image order (asurf_fused_params::image_width / asurf_rays::image_width) are coherent by
+    // that declaration: the call neither asks what the last batch looked like nor probes this one (a kernel, a copy
+    // to the host and an event less a call; the call's time is the same within the spread: 0.785 ms either way)
+    const int declared_w = fused->image_width > 0 ? fused->image_width : rays->image_width;
+    const bool declared_image = declared_w > 0 && rays->n_rays % declared_w == 0;
     if (tiles) {   // an image batch: 8 x 8 pixel tiles (asurf_order.hip, k_tile_scatter)
         unsigned* pm = reinterpret_cast<unsigned*>(L.ws + L.ML.off_ord_perm);
         float* o_s = reinterpret_cast<float*>(L.ws + L.ML.off_ord_o);
@@ -1620,7 +1625,7 @@ int asurf_volume_render_surf_trav_fused(const asurf_grid* grid, const asurf_rays
         rgb_gt_use = gt_s;
         rgb_use = reinterpret_cast<float*>(L.ws + L.ML.off_ord_rgb);
         perm = pm;
-    } else if (rays->n_rays >= kOrderMinRays && fused->order_rays != 1) {
+    } else if (rays->n_rays >= kOrderMinRays && fused->order_rays != 1 && (!declared_image || fused->order_rays == 2)) {
         hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
         const bool capturing = hipStreamIsCapturing(L.stream, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone;
         int* d_probe = reinterpret_cast<int*>(L.ws + L.ML.off_ord_probe);

@@ -204,7 +204,9 @@ typedef struct asurf_fused_params {
      * 0.171 -> 0.124 ms, k_bwd_geo 0.107 -> 0.083 ms, the call 730 -> 800 Mrays/s; the tile's width is
      * ASURF_BWD_TILE (4 / 8 / 16 / 32; 0: rows), images it does not partition are taken by rows.
      * ASURF_TILES=1 (off: measured slower) renders the WHOLE call in tile order -- the rays copied inside the
-     * call, the colours scattered back.  (The field was `reserved_`, always 0, in ABI version 3: same layout.) */
+     * call, the colours scattered back.  A batch declared an image is also taken as coherent: under order_rays = 0
+     * the call neither consults nor runs the coherence probe (one kernel, one copy to the host and one event less a
+     * call); order_rays = 2 still orders it.  (The field was `reserved_`, always 0, in ABI version 3: same layout.) */
     int32_t image_width;
 } asurf_fused_params;
 
