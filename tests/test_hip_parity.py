@@ -756,6 +756,45 @@ def test_ray_ordering_inside_the_fused_call_is_transparent(hip):
             grad_close(g2[k], g1[k], 2e-5, f"order_rays {mode} grad_{k}")
 
 
+def test_a_declared_image_batch_is_taken_as_coherent(hip):
+    """asurf_fused_params::image_width states that the rays come in image order: under order_rays = 0 the call then
+    neither consults nor queues the coherence probe (the library's own spans show which kernels a call launched); the
+    same batch without the declaration ends with the probe.  Same colours, gradients and masks either way."""
+    import torch
+    from alphasurf_amd import csrc_api as _C, synth
+    sc = synth.make_sparse_scene(96, 9, seed=4, trunc_a=4.0)
+    W = 265
+    o, d = synth.pinhole_rays(synth.orbit_camera(2), W, W)
+    assert o.shape[0] >= 65536
+    gt = np.random.RandomState(6).rand(o.shape[0], 3).astype(np.float32)
+    g, r, op = hip.grid_spec(sc), hip.rays_spec(o, d), hip.opt_spec(OPTION_SETS["syn_yaml"])
+    gt_t = torch.from_numpy(gt).cuda()
+    fused = dict(lambda_l2=1.0, lambda_l_entropy=1e-4, lambda_conv_mode_samp=1e-6)
+    args = [fused.get(k, dflt) for k, dflt in hip.FUSED_ORDER]
+
+    def run(image_width):
+        gr = hip.zero_grads(g)
+        rgb = torch.zeros_like(gt_t)
+        _C.volume_render_surf_trav_fused(g, r, op, gt_t, *args, rgb, gr, order_rays=0, image_width=image_width)
+        torch.cuda.synchronize()
+        return rgb.cpu().numpy(), hip.grads_np(gr), [n for n, _ in _asurf_lib.profile_read_spans()]
+
+    _asurf_lib.profile_enable(True)
+    try:
+        run(0)
+        rgb0, g0, names0 = run(0)
+        run(W)
+        rgb1, g1, names1 = run(W)
+    finally:
+        _asurf_lib.profile_enable(False)
+    assert "k_order_probe" in names0, names0
+    assert "k_order_probe" not in names1 and "ray_order" not in names1, names1
+    assert np.abs(rgb1 - rgb0).max() <= 2.5e-7
+    assert (g1["mask"] == g0["mask"]).all()
+    for k in ("sh", "density", "surface"):
+        grad_close(g1[k], g0[k], 2e-5, f"image_width grad_{k}")
+
+
 def test_fallback_kernels_beside_the_backward_pipeline(hip, oracle):
     """A scene that hands many rays to the one-kernel path (dense noisy shell, fake samples in every voxel): the fused
     call as it is (one stream) against the same call with its fallback kernels on the library's side stream
